@@ -1,0 +1,175 @@
+/* modegpt_hip.h -- C ABI of libmodegpt_hip.so, the MI355X (gfx950) engine for MoDeGPT's per-layer
+ * compression path: activation-covariance accumulation, Nystrom / CR / SVD factorisation of the MLP and
+ * attention weights, and the compressed-weight build.
+ *
+ * The reference (cbacary/MoDeGPT) has no FFI: its seam is Python.  This ABI sits directly
+ * beneath the reference's five hot-path functions; each entry point below names the reference lines it
+ * replaces (paths relative to the reference root).  INTEGRATION.md shows the ctypes stubs a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; the library borrows it for the call
+ *     and owns no memory across calls (workspaces are passed in; query their size with the *_ws_bytes twin)
+ *   - matrices are row-major with an explicit leading dimension in ELEMENTS
+ *   - `stream` is a hipStream_t (NULL = default stream); calls only enqueue work unless documented as
+ *     synchronising
+ *   - return value: MDG_OK or a negative MDG_ERR_* code; mdg_last_error() gives the message (thread-local)
+ *   - re-entrant per device, no global lock, callable from any host thread
+ */
+#ifndef MODEGPT_HIP_H
+#define MODEGPT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDG_ABI_VERSION 1
+
+enum mdg_status {
+  MDG_OK = 0,
+  MDG_ERR_BAD_ARG = -1,     /* shape / pointer / alignment / workspace-size problem */
+  MDG_ERR_HIP = -2,         /* a HIP runtime call failed */
+  MDG_ERR_NOT_PD = -3,      /* Cholesky met a non-positive pivot (torch.linalg.cholesky would raise) */
+  MDG_ERR_NO_CONVERGE = -4, /* Jacobi eigensolver hit its sweep limit */
+  MDG_ERR_NO_DEVICE = -5    /* no gfx950 device visible */
+};
+
+enum mdg_dtype { MDG_BF16 = 0, MDG_F16 = 1, MDG_F32 = 2, MDG_F64 = 3 };
+
+/* QK scoring variants (compress_qk.py:244-285) */
+enum mdg_qk_mode {
+  MDG_QK_ROPE_GROUPED = 0, /* compress_head_llama_grouped, compress_qk.py:320-382 */
+  MDG_QK_ROPE_MHA = 1,     /* compress_head_llama,         compress_qk.py:387-436 */
+  MDG_QK_OPT = 2           /* compress_head_opt,           compress_qk.py:439-476 */
+};
+
+int mdg_abi_version(void);
+const char* mdg_last_error(void);
+/* Fills name (<= cap bytes) with the gcnArchName of `device`; MDG_ERR_NO_DEVICE if HIP sees no GPU. */
+int mdg_device_info(int device, char* name, int cap, int* n_cu, int64_t* hbm_bytes);
+
+/* ------------------------------------------------------------------ covariance (calibration hooks)
+ * sigma[b] (lower triangle incl. diagonal tiles) += X_b^T X_b, products and sums in fp64 of the exactly
+ * converted inputs.  X is [n_tokens, >= batch*n_feat] row-major (ld elements per token); problem b reads
+ * columns [b*n_feat, (b+1)*n_feat).  batch=1: replaces `H.T @ H` (LlamaAdapter.py:127-136, model_adapter.py:546-554)
+ * and `sum(X.mT @ X, 0)` (LlamaAdapter.py:138-147); batch=n_heads, n_feat=head_dim: replaces the permute + bmm of
+ * LlamaAdapter.py:115-125 / model_adapter.py:556-567 without the permute copy.
+ * Only the lower triangle of sigma is valid until mdg_cov_finalize mirrors it.
+ * relu != 0 applies max(x, 0) on load (OPT fc1 hook).  ws may be NULL when mdg_cov_accum_ws_bytes says 0;
+ * it holds split-K partials (reduced in fixed order -> run-to-run deterministic). */
+size_t mdg_cov_accum_ws_bytes(int64_t n_tokens, int64_t n_feat, int64_t batch);
+int mdg_cov_accum(const void* x, int dtype, int64_t n_tokens, int64_t n_feat, int64_t batch, int64_t ld,
+                  int relu, double* sigma, int64_t ld_sigma, int64_t sigma_batch_stride, void* ws,
+                  size_t ws_bytes, void* stream);
+/* sigma[b] <- scale * sigma[b] on the lower triangle, mirrored into the upper.  scale = 1/(n_texts*2048)
+ * reproduces calibration.py:141-146. */
+int mdg_cov_finalize(double* sigma, int64_t n, int64_t batch, int64_t ld_sigma, int64_t sigma_batch_stride,
+                     double scale, void* stream);
+/* Block-Influence partial: *out += sum over tokens of (1 - cos(x_in[t], x_out[t])) in fp64
+ * (calibration.py:118-124; the caller divides by T and n_texts).  ws: mdg_bi_ws_bytes(n_tokens). */
+size_t mdg_bi_ws_bytes(int64_t n_tokens);
+int mdg_bi_accum(const void* x_in, const void* x_out, int dtype, int64_t n_tokens, int64_t d, int64_t ld,
+                 double* out, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------ dense fp64 building blocks
+ * C = alpha * op(A) * op(B) + beta * C on v_mfma_f64_16x16x4_f64.  Element (i,k) of op(A) is
+ * A[i*sa_i + k*sa_k] (or A[a_rows[i]*sa_i + k*sa_k] when a_rows != NULL), element (k,j) of op(B) is
+ * B[k*sb_k + j*sb_j]; C is row-major [M, N] with ldc, dtype f64 or bf16 (bf16: beta must be 0, rounding as
+ * torch's .to(bfloat16)).  flags: MDG_GEMM_*.  Batched with element strides. */
+#define MDG_GEMM_LOWER_ONLY 1   /* M==N: only tiles with row-block >= col-block are computed (SYRK update) */
+#define MDG_GEMM_A_LOWER_TRI 2  /* op(A)[i,k] = 0 for k > i (k range clipped per row tile) */
+#define MDG_GEMM_B_LOWER_TRI 4  /* op(B)[k,j] = 0 for k < j (k range clipped per col tile) */
+#define MDG_GEMM_A_UPPER_TRI 8  /* op(A)[i,k] = 0 for k < i */
+int mdg_gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const void* A, int a_dtype, int64_t sa_i,
+                 int64_t sa_k, const int64_t* a_rows, const void* B, int b_dtype, int64_t sb_k,
+                 int64_t sb_j, double beta, void* C, int c_dtype, int64_t ldc, int64_t batch,
+                 int64_t a_batch_stride, int64_t b_batch_stride, int64_t c_batch_stride, int flags,
+                 void* stream);
+
+/* In-place lower Cholesky A = L L^T (upper triangle left untouched), blocked right-looking with 128-wide
+ * panels; inv_diag receives the inverses of the 128x128 diagonal blocks of L ([ceil(n/128)][128][128],
+ * identity-padded).  SYNCHRONISES the stream once at the end to read the pivot flag.
+ * Replaces torch.linalg.cholesky at compress_mlp.py:20,56. */
+size_t mdg_potrf_inv_diag_elems(int64_t n);
+int mdg_potrf_lower(double* A, int64_t n, int64_t lda, double* inv_diag, void* stream);
+/* X (n x nrhs, ldx, in place) <- (L L^T)^-1 X, by blocked substitution with the inverted diagonal blocks.
+ * Replaces torch.cholesky_solve at compress_mlp.py:57. */
+int mdg_potrs_lower(const double* L, int64_t n, int64_t ldl, const double* inv_diag, double* X, int64_t nrhs,
+                    int64_t ldx, void* stream);
+/* out[j] = ((L L^T)^-1)_jj = || L^-1 e_j ||^2.  ws: mdg_inv_diag_of_spd_ws_bytes(n).
+ * Replaces torch.cholesky_inverse + torch.diag at compress_mlp.py:21-23. */
+size_t mdg_chol_inverse_diag_ws_bytes(int64_t n);
+int mdg_chol_inverse_diag(const double* L, int64_t n, int64_t ldl, const double* inv_diag, double* out,
+                          void* ws, size_t ws_bytes, void* stream);
+
+/* Batched symmetric eigensolver, n <= 128 and even: cyclic Jacobi in LDS, one workgroup per matrix.
+ * A [batch][n][n] (symmetric, destroyed), evals [batch][n] DESCENDING, evecs [batch][n][n] with eigenvector j
+ * in COLUMN j.  SYNCHRONISES to read the convergence flag.  (The reference reaches torch.linalg.eigh / svd
+ * through sqrt_M, compression_utils.py:21, and compress_vo.py:130,187,194.) */
+int mdg_syevj_batched(double* A, int64_t n, int64_t batch, double* evals, double* evecs, void* stream);
+
+/* ------------------------------------------------------------------ MLP: ridge-leverage + Nystrom
+ * scores = diag((C + ridge I)^-1).  `ridge` is added as given: pass the fp32-rounded lambda to reproduce the
+ * float32 eye of compress_mlp.py:18.  C is not modified.  ws: mdg_ridge_scores_ws_bytes(n).  SYNCHRONISES. */
+size_t mdg_ridge_scores_ws_bytes(int64_t n);
+int mdg_ridge_scores(const double* C, int64_t n, int64_t ldc, double ridge, double* scores, void* ws,
+                     size_t ws_bytes, void* stream);
+/* idx[0..k) = indices of the k smallest scores, ascending index order (topk(largest=False) + sort,
+ * compress_mlp.py:45-47).  Ties: lower index first.  NaN ranks as largest. */
+int mdg_select_smallest_sorted(const double* scores, int64_t n, int64_t k, int64_t* idx, void* stream);
+/* out[i,:] = src[rows[i],:] for 2-byte elements (W_u[topk,:], W_g[topk,:], compress_mlp.py:49-50;
+ * Q/K row gathers, compress_qk.py:375-376). */
+int mdg_gather_rows_16(const void* src, int64_t ld_src, const int64_t* rows, int64_t n_rows, int64_t n_cols,
+                       void* out, int64_t ld_out, void* stream);
+/* down_out [d, r] (bf16, ld_out) = ((C[idx,idx] + eps I)^-1 C[idx,:] W_d^T)^T, W_d bf16 [d, n] (ld_wd).
+ * compress_mlp.py:52-62,97.  down_f64 (optional, [r, d] row-major) receives the fp64 solution before the
+ * cast.  ws: mdg_nystrom_down_ws_bytes(n, r, d).  SYNCHRONISES. */
+size_t mdg_nystrom_down_ws_bytes(int64_t n, int64_t r, int64_t d);
+int mdg_nystrom_down(const double* C, int64_t n, int64_t ldc, const int64_t* idx, int64_t r, const void* Wd,
+                     int64_t d, int64_t ld_wd, double eps, void* down_out, int64_t ld_out, double* down_f64,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------ QK: CR selection
+ * mask [n_kv, rank] (int64, score-descending, NOT sorted: compress_qk.py:366-367,418-419,464),
+ * q_rows [n_heads*rank] / k_rows [n_kv*rank]: absolute row indices into W_q / W_k for mdg_gather_rows_16.
+ * cov_q [n_heads, hd, hd], cov_k [n_kv, hd, hd] fp64.  Scores use ||col_j(sqrt(C + rho I))||^2 = C_jj + rho
+ * (exact for symmetric PSD C; DESIGN.md section "Identities").  ROPE modes need even rank. */
+int mdg_qk_select(const double* cov_q, const double* cov_k, int n_heads, int n_kv, int hd, double ridge_q,
+                  double ridge_k, int rank, int mode, int64_t* mask, int64_t* q_rows, int64_t* k_rows,
+                  void* stream);
+
+/* ------------------------------------------------------------------ VO: SVD of sqrt(C) W_v^T
+ * v_out [n_kv*rank, d] bf16, o_out [d, n_heads*rank] bf16 (compress_vo.py:89-90).  W_v [n_kv*hd, d],
+ * W_o [d, n_heads*hd] bf16.  n_kv == n_heads selects the two-SVD MHA variant (compress_vo.py:162-223), else the
+ * grouped one (:112-159).  Works on the Gram matrix W_v (C + rho I) W_v^T (DESIGN.md "Identities"), so the
+ * d x d eigensolve and inverse of compress_vo.py:43-45 never happen.  v_f64 / o_f64 optional fp64 copies of
+ * the factors.  ws: mdg_vo_compress_ws_bytes.  SYNCHRONISES. */
+size_t mdg_vo_compress_ws_bytes(int64_t d, int n_heads, int n_kv, int hd);
+int mdg_vo_compress(const double* cov_x, int64_t d, int64_t ldc, const void* Wv, int64_t ld_wv, const void* Wo,
+                    int64_t ld_wo, int n_heads, int n_kv, int hd, int rank, double ridge, void* v_out,
+                    int64_t ld_v, void* o_out, int64_t ld_o, double* v_f64, double* o_f64, void* ws,
+                    size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------ sqrt_M (compression_utils.py:15-55)
+ * root = V diag(sqrt(max(lambda + ridge*scale, 0))) V^T, inv_root (optional) with the 1e-12 clamp;
+ * scale = max eigenvalue if scaled else 1.  n <= 128 and even, batched.  evals_out optional [batch][n]
+ * (pre-ridge, descending) for the caller's diagnostics.  SYNCHRONISES. */
+int mdg_sqrt_psd_small(const double* M, int64_t n, int64_t batch, double ridge, int scaled, double* root,
+                       double* inv_root, double* evals_out, void* ws, size_t ws_bytes, void* stream);
+size_t mdg_sqrt_psd_small_ws_bytes(int64_t n, int64_t batch);
+
+/* ------------------------------------------------------------------ utilities
+ * out_bf16[j, i] = bf16(in_f64[i, j])  (transpose + cast with torch's double->float->bf16 rounding) */
+int mdg_cast_transpose_f64_bf16(const double* in, int64_t rows, int64_t cols, int64_t ld_in, void* out,
+                                int64_t ld_out, void* stream);
+/* Raw fp64 MFMA issue-rate probe used by bench.py to state the measured peak next to the spec:
+ * returns TFLOP/s over `iters` back-to-back v_mfma_f64_16x16x4_f64 per wave on every CU.  SYNCHRONISES. */
+int mdg_probe_mfma_f64(int iters, double* tflops, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MODEGPT_HIP_H */

@@ -1,0 +1,82 @@
+// Error plumbing, device query and the fp64-MFMA issue-rate probe of libmodegpt_hip.so.
+#include <stdarg.h>
+
+#include "common.hpp"
+
+namespace mdg {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// Each wave issues `iters` x 16 independent-accumulator v_mfma_f64_16x16x4_f64; operands never leave registers.
+__global__ __launch_bounds__(256) void probe_mfma_f64_kernel(int iters, double* sink) {
+  d4 acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) acc[i] = (d4){0., 0., 0., 0.};
+  double a = 1.0 + threadIdx.x * 1e-3, b = 0.5 + threadIdx.x * 1e-3;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = 0.;
+#pragma unroll
+  for (int i = 0; i < 16; i++) s += acc[i].x + acc[i].y + acc[i].z + acc[i].w;
+  if (s == 123.456) sink[0] = s;  // keep the chain alive without a store on the normal path
+}
+
+}  // namespace mdg
+
+using namespace mdg;
+
+extern "C" int mdg_abi_version(void) { return MDG_ABI_VERSION; }
+extern "C" const char* mdg_last_error(void) { return g_err; }
+
+extern "C" int mdg_device_info(int device, char* name, int cap, int* n_cu, int64_t* hbm_bytes) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device >= count) {
+    set_error("mdg_device_info: no HIP device %d (count %d)", device, count);
+    return MDG_ERR_NO_DEVICE;
+  }
+  hipDeviceProp_t prop;
+  MDG_HIP(hipGetDeviceProperties(&prop, device));
+  if (name && cap > 0) {
+    strncpy(name, prop.gcnArchName, cap - 1);
+    name[cap - 1] = 0;
+  }
+  if (n_cu) *n_cu = prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+  return MDG_OK;
+}
+
+extern "C" int mdg_probe_mfma_f64(int iters, double* tflops, void* stream) {
+  MDG_CHECK_ARG(iters > 0 && tflops, "mdg_probe_mfma_f64: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  int dev = 0, n_cu = 0;
+  MDG_HIP(hipGetDevice(&dev));
+  MDG_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  double* sink = nullptr;
+  MDG_HIP(hipMalloc((void**)&sink, 64));
+  hipEvent_t e0, e1;
+  MDG_HIP(hipEventCreate(&e0));
+  MDG_HIP(hipEventCreate(&e1));
+  const int blocks = n_cu * 2;  // 8 waves per CU = 2 per SIMD
+  hipLaunchKernelGGL(probe_mfma_f64_kernel, dim3(blocks), dim3(256), 0, st, iters / 8 + 1, sink);  // warm
+  MDG_HIP(hipEventRecord(e0, st));
+  hipLaunchKernelGGL(probe_mfma_f64_kernel, dim3(blocks), dim3(256), 0, st, iters, sink);
+  MDG_HIP(hipEventRecord(e1, st));
+  MDG_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  MDG_HIP(hipEventElapsedTime(&ms, e0, e1));
+  const double flop = (double)blocks * 4 /*waves*/ * (double)iters * 16 * (2.0 * 16 * 16 * 4);
+  *tflops = flop / (ms * 1e-3) / 1e12;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(sink);
+  return MDG_OK;
+}

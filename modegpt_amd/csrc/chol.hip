@@ -1,0 +1,286 @@
+// Blocked fp64 Cholesky, Cholesky solve and diag-of-inverse for the Nystrom MLP path
+// (compress_mlp.py:13-25 get_ridge_scores, :52-57 reduced solve).  128-wide panels: the diagonal block is
+// factorised AND inverted inside one workgroup's LDS; everything else is GEMM on the fp64 MFMA core
+// (panel solve = multiply by the inverted diagonal block, trailing update = lower-only SYRK).
+#include "common.hpp"
+
+namespace mdg {
+
+int gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const void* A, int a_dtype, int64_t sa_i, int64_t sa_k,
+             const int64_t* a_rows, const void* B, int b_dtype, int64_t sb_k, int64_t sb_j, double beta, void* C,
+             int c_dtype, int64_t ldc, int64_t batch, int64_t a_bs, int64_t b_bs, int64_t c_bs, int flags,
+             hipStream_t st);
+
+constexpr int NB = 128;
+constexpr int DP = NB + 1;  // LDS pitch (fp64) of the diagonal block: odd pitch -> conflict-free column walks
+
+// Factorise the nb x nb diagonal block at A (lower), write L back, write inv(L) (identity padded to 128x128)
+// to inv.  info: first failing global pivot index + 1 (atomicMin-style, 0 = ok).
+__global__ __launch_bounds__(256) void potrf_diag_kernel(double* A, int64_t lda, int nb, int64_t k0, double* inv,
+                                                         int* info) {
+  __shared__ double a[NB * DP];
+  __shared__ double piv[NB];   // pivots d_j, later 1/L_jj
+  __shared__ double xd[NB];    // diagonal of inv(L)
+  const int tid = threadIdx.x;
+  for (int e = tid; e < nb * nb; e += 256) {
+    int i = e / nb, j = e % nb;
+    a[i * DP + j] = (j <= i) ? A[(int64_t)i * lda + j] : 0.;
+  }
+  __syncthreads();
+  // right-looking, scaling deferred: after step j column j holds the unscaled L column, a[j][j] the pivot.
+  const int tr = tid >> 4, tc = tid & 15;
+  for (int j = 0; j < nb; j++) {
+    double d = a[j * DP + j];
+    if (!(d > 0.)) {  // also catches NaN
+      if (tid == 0) {
+        int want = (int)(k0 + j + 1);
+        int old = atomicCAS(info, 0, want);
+        (void)old;
+      }
+      d = 1.;
+      __syncthreads();
+      if (tid == 0) a[j * DP + j] = 1.;
+    }
+    const double rd = 1. / d;
+    for (int i = j + 1 + tr; i < nb; i += 16) {
+      const double lij = a[i * DP + j] * rd;
+      for (int k = j + 1 + tc; k <= i; k += 16) a[i * DP + k] -= lij * a[k * DP + j];
+    }
+    __syncthreads();
+  }
+  if (tid < nb) piv[tid] = 1. / sqrt(a[tid * DP + tid]);
+  __syncthreads();
+  for (int e = tid; e < nb * nb; e += 256) {
+    int i = e / nb, j = e % nb;
+    if (j < i) a[i * DP + j] *= piv[j];
+  }
+  __syncthreads();
+  if (tid < nb) {
+    a[tid * DP + tid] = 1. / piv[tid];  // L_jj = sqrt(d_j)
+    xd[tid] = piv[tid];                 // X_jj = 1 / L_jj
+  }
+  __syncthreads();
+  for (int e = tid; e < nb * nb; e += 256) {
+    int i = e / nb, j = e % nb;
+    if (j <= i) A[(int64_t)i * lda + j] = a[i * DP + j];
+  }
+  // inv(L): X starts as I; for k: row k of X final after scaling; rows below get X[i][:] -= L[i][k] X[k][:].
+  // X[i][j] (i > j) is kept transposed in the (unused) upper triangle: a[j][i].  Upper triangle is zero here.
+  for (int k = 0; k < nb; k++) {
+    // scale row k: X[k][j] for j < k  (X[k][k] = xd[k] already holds 1/L_kk)
+    // combined with the update below by carrying the scale: process row k scaling first.
+    for (int j = tid; j < k; j += 256) a[j * DP + k] *= xd[k];
+    __syncthreads();
+    const int rows = nb - 1 - k;
+    for (int e = tid; e < rows * (k + 1); e += 256) {
+      int i = k + 1 + e % rows, j = e / rows;
+      double xkj = (j == k) ? xd[k] : a[j * DP + k];
+      a[j * DP + i] -= a[i * DP + k] * xkj;
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < NB * NB; e += 256) {
+    int i = e / NB, j = e % NB;
+    double v;
+    if (i >= nb || j >= nb) v = (i == j) ? 1. : 0.;
+    else if (j < i) v = a[j * DP + i];
+    else if (j == i) v = xd[i];
+    else v = 0.;
+    inv[e] = v;
+  }
+}
+
+// dst lower triangle (incl. diagonal) = src + ridge*I ; optional row/col gather through idx.
+__global__ __launch_bounds__(256) void copy_lower_kernel(const double* src, int64_t lds_, const int64_t* idx, double* dst,
+                                                         int64_t ldd, int64_t n, double ridge) {
+  const int64_t i = blockIdx.y;
+  const int64_t si = idx ? idx[i] : i;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j <= i; j += (int64_t)gridDim.x * 256) {
+    int64_t sj = idx ? idx[j] : j;
+    double v = src[si * lds_ + sj];
+    if (j == i) v += ridge;
+    dst[i * ldd + j] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void place_inv_diag_kernel(const double* inv, double* X, int64_t ldx, int64_t n) {
+  const int64_t b = blockIdx.x;
+  const double* src = inv + b * NB * NB;
+  for (int e = threadIdx.x; e < NB * NB; e += 256) {
+    int64_t i = b * NB + e / NB, j = b * NB + e % NB;
+    if (i < n && j < n) X[i * ldx + j] = src[e];
+  }
+}
+
+// out[j] = sum_{i >= j} X[i][j]^2 ; one workgroup per 64 columns, 4 row-strided waves.
+__global__ __launch_bounds__(256) void lower_colnorm2_kernel(const double* X, int64_t ldx, int64_t n, double* out) {
+  __shared__ double red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t j = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t i0 = (int64_t)blockIdx.x * 64;
+  double s = 0.;
+  if (j < n)
+    for (int64_t i = i0 + wave; i < n; i += 4)
+      if (i >= j) {
+        double v = X[i * ldx + j];
+        s += v * v;
+      }
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && j < n) out[j] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+
+static int read_flag(int* dflag, hipStream_t st, int* host) {
+  MDG_HIP(hipMemcpyAsync(host, dflag, sizeof(int), hipMemcpyDeviceToHost, st));
+  MDG_HIP(hipStreamSynchronize(st));
+  return MDG_OK;
+}
+
+int potrf_lower(double* A, int64_t n, int64_t lda, double* inv_diag, hipStream_t st) {
+  const int64_t nblk = ceil_div(n, NB);
+  int* dflag = (int*)(inv_diag + nblk * NB * NB);
+  MDG_HIP(hipMemsetAsync(dflag, 0, sizeof(int), st));
+  for (int64_t b = 0; b < nblk; b++) {
+    const int64_t k0 = b * NB;
+    const int nb = (int)(n - k0 < NB ? n - k0 : NB);
+    double* Akk = A + k0 * lda + k0;
+    double* inv = inv_diag + b * NB * NB;
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, st, Akk, lda, nb, k0, inv, dflag);
+    MDG_LAUNCH_CHECK();
+    const int64_t rest = n - k0 - nb;
+    if (rest <= 0) break;
+    double* A21 = A + (k0 + nb) * lda + k0;
+    // L21 = A21 * inv(L11)^T  (in place: one tile column, each workgroup reads only its own rows)
+    MDG_TRY(gemm_f64(rest, nb, nb, 1.0, A21, MDG_F64, lda, 1, nullptr, inv, MDG_F64, 1, NB, 0.0, A21, MDG_F64, lda, 1,
+                     0, 0, 0, 0, st));
+    // A22 -= L21 L21^T (lower tiles only)
+    double* A22 = A + (k0 + nb) * lda + (k0 + nb);
+    MDG_TRY(gemm_f64(rest, rest, nb, -1.0, A21, MDG_F64, lda, 1, nullptr, A21, MDG_F64, 1, lda, 1.0, A22, MDG_F64,
+                     lda, 1, 0, 0, 0, MDG_GEMM_LOWER_ONLY, st));
+  }
+  int flag = 0;
+  MDG_TRY(read_flag(dflag, st, &flag));
+  if (flag != 0) {
+    set_error("Cholesky: the factorization could not be completed because the input is not positive-definite "
+              "(the leading minor of order %d is not positive-definite)", flag);
+    return MDG_ERR_NOT_PD;
+  }
+  return MDG_OK;
+}
+
+int potrs_lower(const double* L, int64_t n, int64_t ldl, const double* inv_diag, double* X, int64_t nrhs,
+                int64_t ldx, hipStream_t st) {
+  const int64_t nblk = ceil_div(n, NB);
+  for (int64_t b = 0; b < nblk; b++) {  // L Y = B
+    const int64_t k0 = b * NB;
+    const int64_t nb = n - k0 < NB ? n - k0 : NB;
+    double* Xb = X + k0 * ldx;
+    MDG_TRY(gemm_f64(nb, nrhs, nb, 1.0, inv_diag + b * NB * NB, MDG_F64, NB, 1, nullptr, Xb, MDG_F64, ldx, 1, 0.0, Xb,
+                     MDG_F64, ldx, 1, 0, 0, 0, 0, st));
+    const int64_t rest = n - k0 - nb;
+    if (rest > 0)
+      MDG_TRY(gemm_f64(rest, nrhs, nb, -1.0, L + (k0 + nb) * ldl + k0, MDG_F64, ldl, 1, nullptr, Xb, MDG_F64, ldx, 1,
+                       1.0, X + (k0 + nb) * ldx, MDG_F64, ldx, 1, 0, 0, 0, 0, st));
+  }
+  for (int64_t b = nblk - 1; b >= 0; b--) {  // L^T X = Y
+    const int64_t k0 = b * NB;
+    const int64_t nb = n - k0 < NB ? n - k0 : NB;
+    double* Xb = X + k0 * ldx;
+    MDG_TRY(gemm_f64(nb, nrhs, nb, 1.0, inv_diag + b * NB * NB, MDG_F64, 1, NB, nullptr, Xb, MDG_F64, ldx, 1, 0.0, Xb,
+                     MDG_F64, ldx, 1, 0, 0, 0, 0, st));
+    if (k0 > 0)
+      MDG_TRY(gemm_f64(k0, nrhs, nb, -1.0, L + k0 * ldl, MDG_F64, 1, ldl, nullptr, Xb, MDG_F64, ldx, 1, 1.0, X,
+                       MDG_F64, ldx, 1, 0, 0, 0, 0, st));
+  }
+  return MDG_OK;
+}
+
+// X = inv(L) by recursive doubling on the block size, then column norms.
+int chol_inverse_diag(const double* L, int64_t n, int64_t ldl, const double* inv_diag, double* out, double* X,
+                      double* T, hipStream_t st) {
+  const int64_t nblk = ceil_div(n, NB);
+  const int64_t ldx = n;
+  hipLaunchKernelGGL(place_inv_diag_kernel, dim3((unsigned)nblk), dim3(256), 0, st, inv_diag, X, ldx, n);
+  MDG_LAUNCH_CHECK();
+  for (int64_t s = NB; s < n; s *= 2) {
+    // pair p: Cb = [2ps, 2ps+s), R = [2ps+s, min(2ps+2s, n))
+    const int64_t full = n / (2 * s);                 // pairs with a complete R
+    const int64_t r0_last = full * 2 * s + s;         // a trailing ragged pair exists if r0_last < n
+    const int64_t pair_stride_L = 2 * s * ldl + 2 * s, pair_stride_X = 2 * s * ldx + 2 * s;
+    for (int pass = 0; pass < 2; pass++) {
+      int64_t p0, cnt, m;
+      if (pass == 0) { p0 = 0; cnt = full; m = s; }
+      else { p0 = full; cnt = r0_last < n ? 1 : 0; m = n - r0_last; }
+      if (cnt <= 0) continue;
+      const int64_t c0 = p0 * 2 * s, r0 = c0 + s;
+      // T_p = L[R, Cb] * X[Cb, Cb]      (X[Cb,Cb] lower triangular)
+      MDG_TRY(gemm_f64(m, s, s, 1.0, L + r0 * ldl + c0, MDG_F64, ldl, 1, nullptr, X + c0 * ldx + c0, MDG_F64, ldx, 1,
+                       0.0, T, MDG_F64, s, cnt, pair_stride_L, pair_stride_X, s * s, MDG_GEMM_B_LOWER_TRI, st));
+      // X[R, Cb] = -X[R, R] * T_p       (X[R,R] lower triangular)
+      MDG_TRY(gemm_f64(m, s, m, -1.0, X + r0 * ldx + r0, MDG_F64, ldx, 1, nullptr, T, MDG_F64, s, 1, 0.0,
+                       X + r0 * ldx + c0, MDG_F64, ldx, cnt, pair_stride_X, s * s, pair_stride_X,
+                       MDG_GEMM_A_LOWER_TRI, st));
+    }
+  }
+  hipLaunchKernelGGL(lower_colnorm2_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, st, X, ldx, n, out);
+  MDG_LAUNCH_CHECK();
+  return MDG_OK;
+}
+
+int copy_lower(const double* src, int64_t ld_src, const int64_t* idx, double* dst, int64_t ldd, int64_t n,
+               double ridge, hipStream_t st) {
+  MDG_CHECK_ARG(n < 65536 * 4, "copy_lower: n too large");
+  unsigned gx = (unsigned)(ceil_div(n, 256) < 64 ? ceil_div(n, 256) : 64);
+  hipLaunchKernelGGL(copy_lower_kernel, dim3(gx, (unsigned)n), dim3(256), 0, st, src, ld_src, idx, dst, ldd, n, ridge);
+  MDG_LAUNCH_CHECK();
+  return MDG_OK;
+}
+
+}  // namespace mdg
+
+using namespace mdg;
+
+extern "C" size_t mdg_potrf_inv_diag_elems(int64_t n) { return (size_t)ceil_div(n, NB) * NB * NB + 16; }
+
+extern "C" int mdg_potrf_lower(double* A, int64_t n, int64_t lda, double* inv_diag, void* stream) {
+  MDG_CHECK_ARG(A && inv_diag && n > 0 && lda >= n, "mdg_potrf_lower: bad arguments");
+  return potrf_lower(A, n, lda, inv_diag, (hipStream_t)stream);
+}
+
+extern "C" int mdg_potrs_lower(const double* L, int64_t n, int64_t ldl, const double* inv_diag, double* X,
+                               int64_t nrhs, int64_t ldx, void* stream) {
+  MDG_CHECK_ARG(L && inv_diag && X && n > 0 && nrhs > 0 && ldl >= n && ldx >= nrhs, "mdg_potrs_lower: bad arguments");
+  return potrs_lower(L, n, ldl, inv_diag, X, nrhs, ldx, (hipStream_t)stream);
+}
+
+extern "C" size_t mdg_chol_inverse_diag_ws_bytes(int64_t n) {
+  return ((size_t)n * n + (size_t)n * n / 4 + NB * NB) * sizeof(double);
+}
+
+extern "C" int mdg_chol_inverse_diag(const double* L, int64_t n, int64_t ldl, const double* inv_diag, double* out,
+                                     void* ws, size_t ws_bytes, void* stream) {
+  MDG_CHECK_ARG(L && inv_diag && out && n > 0 && ldl >= n, "mdg_chol_inverse_diag: bad arguments");
+  MDG_CHECK_ARG(ws && ws_bytes >= mdg_chol_inverse_diag_ws_bytes(n), "mdg_chol_inverse_diag: workspace too small");
+  double* X = (double*)ws;
+  double* T = X + (size_t)n * n;
+  return chol_inverse_diag(L, n, ldl, inv_diag, out, X, T, (hipStream_t)stream);
+}
+
+extern "C" size_t mdg_ridge_scores_ws_bytes(int64_t n) {
+  return (size_t)n * n * sizeof(double) + mdg_potrf_inv_diag_elems(n) * sizeof(double) +
+         mdg_chol_inverse_diag_ws_bytes(n);
+}
+
+extern "C" int mdg_ridge_scores(const double* C, int64_t n, int64_t ldc, double ridge, double* scores, void* ws,
+                                size_t ws_bytes, void* stream) {
+  MDG_CHECK_ARG(C && scores && n > 0 && ldc >= n, "mdg_ridge_scores: bad arguments");
+  MDG_CHECK_ARG(ws && ws_bytes >= mdg_ridge_scores_ws_bytes(n), "mdg_ridge_scores: workspace %zu < required %zu",
+                ws_bytes, mdg_ridge_scores_ws_bytes(n));
+  hipStream_t st = (hipStream_t)stream;
+  double* Lb = (double*)ws;
+  double* inv = Lb + (size_t)n * n;
+  double* rest = inv + mdg_potrf_inv_diag_elems(n);
+  MDG_TRY(copy_lower(C, ldc, nullptr, Lb, n, n, ridge, st));
+  MDG_TRY(potrf_lower(Lb, n, n, inv, st));
+  return chol_inverse_diag(Lb, n, n, inv, scores, rest, rest + (size_t)n * n, st);
+}

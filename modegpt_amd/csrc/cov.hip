@@ -1,0 +1,367 @@
+// Activation-covariance accumulation: sigma (lower) += X^T X in fp64 on v_mfma_f64_16x16x4_f64.
+//
+// Replaces the calibration hooks' `H.T @ H`, `sum(X.mT @ X, 0)` and per-head bmm
+// (LlamaAdapter.py:115-147, model_adapter.py:546-567) -- >98 % of the path's flops.
+//
+// Launch shape: one 256-thread workgroup per 128x128 output tile of the LOWER triangle (x batch x k-split);
+// the token dimension is streamed through LDS in 16-token stages, converted to fp64 once while staging, so
+// the inner loop is LDS reads + 16 MFMAs per 4 tokens.  The kernel is fp64-MFMA bound: at 128x128 tiles the
+// operand traffic is 2 B/cycle/CU (DESIGN.md "cov_accum").
+#include "common.hpp"
+
+namespace mdg {
+
+struct CovArgs {
+  const void* x;
+  int64_t ld, n_tokens;
+  int n_feat, batch, tiles, ntri;
+  double* sigma;
+  int64_t ld_sigma, sigma_bs;
+  int ksplit;
+  int64_t tokens_per_split;
+  double* partial;
+  int vec_ok;
+};
+
+template <int DT> struct Stage {
+  typedef typename ElemOf<DT>::type T;
+  static constexpr int VEC = 16 / (int)sizeof(T);        // elements per 16-byte chunk
+  static constexpr int CPR = TILE / VEC;                 // chunks per token row
+  static constexpr int CPT = BK * CPR / 256;             // chunks per thread
+  union Chunk {
+    uint4 q;
+    T e[VEC];
+  };
+};
+
+template <int DT, bool RELU>
+__device__ __forceinline__ void load_panel(const CovArgs& a, int64_t tok0, int64_t tok_end, int64_t col0,
+                                           int col_lim, int tid, typename Stage<DT>::Chunk* regs) {
+  typedef Stage<DT> S;
+  typedef typename S::T T;
+  const T* x = (const T*)a.x;
+#pragma unroll
+  for (int p = 0; p < S::CPT; p++) {
+    int c = tid + 256 * p;
+    int row = c / S::CPR;
+    int col = (c % S::CPR) * S::VEC;
+    int64_t tok = tok0 + row;
+    typename S::Chunk ch;
+    ch.q = make_uint4(0, 0, 0, 0);
+    if (tok < tok_end) {
+      const T* src = x + tok * a.ld + col0 + col;
+      if (a.vec_ok && col + S::VEC <= col_lim) {
+        ch.q = *(const uint4*)src;
+      } else {
+#pragma unroll
+        for (int e = 0; e < S::VEC; e++)
+          if (col + e < col_lim) ch.e[e] = src[e];
+      }
+    }
+    regs[p] = ch;
+  }
+}
+
+template <int DT, bool RELU>
+__device__ __forceinline__ void store_panel(double* panel, int tid, const typename Stage<DT>::Chunk* regs) {
+  typedef Stage<DT> S;
+#pragma unroll
+  for (int p = 0; p < S::CPT; p++) {
+    int c = tid + 256 * p;
+    int row = c / S::CPR;
+    int col = (c % S::CPR) * S::VEC;
+    double* dst = panel + row * PITCH + col;
+#pragma unroll
+    for (int e = 0; e < S::VEC; e += 2) {
+      double v0 = load_f64<DT>(regs[p].e, e), v1 = load_f64<DT>(regs[p].e, e + 1);
+      if (RELU) {
+        v0 = v0 > 0. ? v0 : 0.;
+        v1 = v1 > 0. ? v1 : 0.;
+      }
+      *(d2*)(dst + e) = (d2){v0, v1};
+    }
+  }
+}
+
+template <int DT, bool RELU>
+__global__ __launch_bounds__(256, 2) void cov_accum_kernel(CovArgs a) {
+  typedef Stage<DT> S;
+  __shared__ double lds[4 * PANEL];  // As[2], Bs[2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int b = blockIdx.x / a.ntri, t = blockIdx.x % a.ntri;
+  int bi, bj;
+  tri_decode(t, bi, bj);
+  const bool diag = (bi == bj);
+  const int split = blockIdx.y;
+  const int64_t tok_begin = (int64_t)split * a.tokens_per_split;
+  int64_t tok_end = tok_begin + a.tokens_per_split;
+  if (tok_end > a.n_tokens) tok_end = a.n_tokens;
+  const int64_t colA = (int64_t)b * a.n_feat + (int64_t)bi * TILE;
+  const int64_t colB = (int64_t)b * a.n_feat + (int64_t)bj * TILE;
+  const int limA = min(TILE, a.n_feat - bi * TILE), limB = min(TILE, a.n_feat - bj * TILE);
+
+  Acc acc;
+  acc_zero(acc);
+  typename S::Chunk ra[S::CPT], rb[S::CPT];
+  const int64_t n_stage = tok_end > tok_begin ? (tok_end - tok_begin + BK - 1) / BK : 0;
+
+  if (n_stage > 0) {
+    load_panel<DT, RELU>(a, tok_begin, tok_end, colA, limA, tid, ra);
+    if (!diag) load_panel<DT, RELU>(a, tok_begin, tok_end, colB, limB, tid, rb);
+    store_panel<DT, RELU>(lds, tid, ra);
+    if (!diag) store_panel<DT, RELU>(lds + 2 * PANEL, tid, rb);
+  }
+  __syncthreads();
+  for (int64_t s = 0; s < n_stage; s++) {
+    const int cur = (int)(s & 1);
+    const bool more = s + 1 < n_stage;
+    if (more) {
+      int64_t tk = tok_begin + (s + 1) * BK;
+      load_panel<DT, RELU>(a, tk, tok_end, colA, limA, tid, ra);
+      if (!diag) load_panel<DT, RELU>(a, tk, tok_end, colB, limB, tid, rb);
+    }
+    const double* As = lds + cur * PANEL;
+    const double* Bs = diag ? As : lds + (2 + cur) * PANEL;
+    mma_stage(As, Bs, wr, wc, lane, acc);
+    if (more) {
+      store_panel<DT, RELU>(lds + (cur ^ 1) * PANEL, tid, ra);
+      if (!diag) store_panel<DT, RELU>(lds + (2 + (cur ^ 1)) * PANEL, tid, rb);
+    }
+    __syncthreads();
+  }
+
+  // epilogue
+  if (a.ksplit == 1) {
+    double* sg = a.sigma + (int64_t)b * a.sigma_bs;
+#pragma unroll
+    for (int sa = 0; sa < 4; sa++)
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) {
+        int r = acc_row(wr, lane, sa, reg);
+        int64_t gr = (int64_t)bi * TILE + r;
+        if (gr >= a.n_feat) continue;
+        int c0 = acc_col(wc, lane, 0);
+        int64_t gc0 = (int64_t)bj * TILE + c0;
+        double* row = sg + gr * a.ld_sigma + gc0;
+#pragma unroll
+        for (int sb = 0; sb < 4; sb++)
+          if (gc0 + sb < a.n_feat) row[sb] += acc.v[sa][sb][reg];
+      }
+  } else {
+    double* pt = a.partial + ((int64_t)split * gridDim.x + blockIdx.x) * (TILE * TILE);
+#pragma unroll
+    for (int sa = 0; sa < 4; sa++)
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) {
+        int r = acc_row(wr, lane, sa, reg);
+        int c0 = acc_col(wc, lane, 0);
+        d4 v = {acc.v[sa][0][reg], acc.v[sa][1][reg], acc.v[sa][2][reg], acc.v[sa][3][reg]};
+        *(d4*)(pt + r * TILE + c0) = v;
+      }
+  }
+}
+
+// sigma tile += sum over splits (fixed order) of the partial tiles.
+__global__ __launch_bounds__(256) void cov_reduce_kernel(CovArgs a) {
+  const int b = blockIdx.x / a.ntri, t = blockIdx.x % a.ntri;
+  int bi, bj;
+  tri_decode(t, bi, bj);
+  double* sg = a.sigma + (int64_t)b * a.sigma_bs;
+  const int64_t tile_stride = (int64_t)gridDim.x * (TILE * TILE);
+  const double* pt = a.partial + (int64_t)blockIdx.x * (TILE * TILE);
+  for (int e = threadIdx.x; e < TILE * TILE; e += 256) {
+    int r = e / TILE, c = e % TILE;
+    int64_t gr = (int64_t)bi * TILE + r, gc = (int64_t)bj * TILE + c;
+    if (gr >= a.n_feat || gc >= a.n_feat) continue;
+    double s = 0.;
+    for (int k = 0; k < a.ksplit; k++) s += pt[k * tile_stride + e];
+    sg[gr * a.ld_sigma + gc] += s;
+  }
+}
+
+// lower -> scaled lower + mirrored upper, 32x32 tiles through LDS.
+__global__ __launch_bounds__(256) void cov_finalize_kernel(double* sigma, int n, int64_t ld, int64_t bs, int tiles,
+                                                           int ntri, double scale) {
+  __shared__ double tl[32][33];
+  const int b = blockIdx.x / ntri, t = blockIdx.x % ntri;
+  int ti, tj;
+  tri_decode(t, ti, tj);
+  double* sg = sigma + (int64_t)b * bs;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    int gr = ti * 32 + r, gc = tj * 32 + tx;
+    tl[r][tx] = (gr < n && gc < n) ? sg[(int64_t)gr * ld + gc] * scale : 0.;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    int gr = ti * 32 + r, gc = tj * 32 + tx;
+    if (gr < n && gc < n) {
+      double v = (ti == tj && tx > r) ? tl[tx][r] : tl[r][tx];
+      sg[(int64_t)gr * ld + gc] = v;
+    }
+    if (ti != tj) {
+      int ur = tj * 32 + r, uc = ti * 32 + tx;  // transposed tile
+      if (ur < n && uc < n) sg[(int64_t)ur * ld + uc] = tl[tx][r];
+    }
+  }
+}
+
+// ---------------------------------------------------------------- BI score
+template <int DT>
+__global__ __launch_bounds__(256) void bi_partial_kernel(const void* xin, const void* xout, int64_t n_tokens,
+                                                         int64_t d, int64_t ld, double* partial) {
+  __shared__ double red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double local = 0.;
+  for (int64_t tok = (int64_t)blockIdx.x * 4 + wave; tok < n_tokens; tok += (int64_t)gridDim.x * 4) {
+    double dot = 0., na = 0., nb = 0.;
+    for (int64_t j = lane; j < d; j += 64) {
+      double u = load_f64<DT>(xin, tok * ld + j), v = load_f64<DT>(xout, tok * ld + j);
+      dot += u * v;
+      na += u * u;
+      nb += v * v;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      dot += __shfl_xor(dot, o);
+      na += __shfl_xor(na, o);
+      nb += __shfl_xor(nb, o);
+    }
+    const double eps = 1e-8;  // torch.cosine_similarity default
+    double den = fmax(sqrt(na), eps) * fmax(sqrt(nb), eps);
+    local += 1.0 - dot / den;
+  }
+  if (lane == 0) red[wave] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void bi_final_kernel(const double* partial, int n, double* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.;
+    for (int i = 0; i < n; i++) s += partial[i];
+    *out += s;
+  }
+}
+
+// ---------------------------------------------------------------- host side
+static int cov_ksplit(int64_t n_tokens, int64_t n_feat, int64_t batch, int64_t* tokens_per_split) {
+  int64_t T = ceil_div(n_feat, TILE);
+  int64_t blocks = batch * T * (T + 1) / 2;
+  int64_t want = blocks >= 768 ? 1 : ceil_div(1024, blocks);
+  int64_t max_split = n_tokens / (8 * BK);  // at least 128 tokens per split
+  if (max_split < 1) max_split = 1;
+  if (want > max_split) want = max_split;
+  int64_t tps = align_up((size_t)ceil_div(n_tokens, want), BK);
+  if (tps < BK) tps = BK;
+  int ks = (int)ceil_div(n_tokens > 0 ? n_tokens : 1, tps);
+  *tokens_per_split = tps;
+  return ks < 1 ? 1 : ks;
+}
+
+template <int DT>
+static void launch_cov(const CovArgs& a, int relu, hipStream_t st) {
+  dim3 grid(a.batch * a.ntri, a.ksplit);
+  if (relu)
+    hipLaunchKernelGGL((cov_accum_kernel<DT, true>), grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((cov_accum_kernel<DT, false>), grid, dim3(256), 0, st, a);
+}
+
+}  // namespace mdg
+
+using namespace mdg;
+
+extern "C" size_t mdg_cov_accum_ws_bytes(int64_t n_tokens, int64_t n_feat, int64_t batch) {
+  if (n_tokens <= 0 || n_feat <= 0 || batch <= 0) return 0;
+  int64_t tps;
+  int ks = cov_ksplit(n_tokens, n_feat, batch, &tps);
+  if (ks == 1) return 0;
+  int64_t T = ceil_div(n_feat, TILE);
+  return (size_t)ks * batch * (T * (T + 1) / 2) * TILE * TILE * sizeof(double);
+}
+
+extern "C" int mdg_cov_accum(const void* x, int dtype, int64_t n_tokens, int64_t n_feat, int64_t batch,
+                             int64_t ld, int relu, double* sigma, int64_t ld_sigma, int64_t sigma_bs, void* ws,
+                             size_t ws_bytes, void* stream) {
+  MDG_CHECK_ARG(n_tokens >= 0 && n_feat > 0 && batch > 0, "mdg_cov_accum: bad sizes (tokens=%lld feat=%lld batch=%lld)",
+                (long long)n_tokens, (long long)n_feat, (long long)batch);
+  MDG_CHECK_ARG(dtype >= MDG_BF16 && dtype <= MDG_F64, "mdg_cov_accum: unknown dtype %d", dtype);
+  MDG_CHECK_ARG(ld >= n_feat * batch, "mdg_cov_accum: ld %lld < batch*n_feat %lld", (long long)ld,
+                (long long)(n_feat * batch));
+  MDG_CHECK_ARG(ld_sigma >= n_feat, "mdg_cov_accum: ld_sigma %lld < n_feat", (long long)ld_sigma);
+  MDG_CHECK_ARG(batch == 1 || sigma_bs >= n_feat * ld_sigma - (ld_sigma - n_feat),
+                "mdg_cov_accum: sigma batch stride too small");
+  MDG_CHECK_ARG(n_feat < (1 << 30) && batch * n_feat < (1ll << 31), "mdg_cov_accum: n_feat too large");
+  if (n_tokens == 0) return MDG_OK;
+  MDG_CHECK_ARG(x && sigma, "mdg_cov_accum: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  CovArgs a;
+  a.x = x;
+  a.ld = ld;
+  a.n_tokens = n_tokens;
+  a.n_feat = (int)n_feat;
+  a.batch = (int)batch;
+  a.tiles = (int)ceil_div(n_feat, TILE);
+  a.ntri = a.tiles * (a.tiles + 1) / 2;
+  a.sigma = sigma;
+  a.ld_sigma = ld_sigma;
+  a.sigma_bs = sigma_bs;
+  a.ksplit = cov_ksplit(n_tokens, n_feat, batch, &a.tokens_per_split);
+  a.partial = (double*)ws;
+  size_t esz = dtype_size(dtype);
+  a.vec_ok = ((uintptr_t)x % 16 == 0) && ((ld * esz) % 16 == 0) && ((n_feat * esz) % 16 == 0 || batch == 1);
+  if (a.ksplit > 1) {
+    size_t need = mdg_cov_accum_ws_bytes(n_tokens, n_feat, batch);
+    MDG_CHECK_ARG(ws && ws_bytes >= need, "mdg_cov_accum: workspace %zu < required %zu", ws_bytes, need);
+  }
+  MDG_CHECK_ARG((int64_t)a.batch * a.ntri < (1ll << 31) && a.ksplit < 65536, "mdg_cov_accum: grid too large");
+  switch (dtype) {
+    case MDG_BF16: launch_cov<MDG_BF16>(a, relu, st); break;
+    case MDG_F16: launch_cov<MDG_F16>(a, relu, st); break;
+    case MDG_F32: launch_cov<MDG_F32>(a, relu, st); break;
+    default: launch_cov<MDG_F64>(a, relu, st); break;
+  }
+  MDG_LAUNCH_CHECK();
+  if (a.ksplit > 1) {
+    hipLaunchKernelGGL(cov_reduce_kernel, dim3(a.batch * a.ntri), dim3(256), 0, st, a);
+    MDG_LAUNCH_CHECK();
+  }
+  return MDG_OK;
+}
+
+extern "C" int mdg_cov_finalize(double* sigma, int64_t n, int64_t batch, int64_t ld_sigma, int64_t sigma_bs,
+                                double scale, void* stream) {
+  MDG_CHECK_ARG(sigma && n > 0 && batch > 0 && ld_sigma >= n, "mdg_cov_finalize: bad arguments");
+  int tiles = (int)ceil_div(n, 32);
+  int64_t ntri = (int64_t)tiles * (tiles + 1) / 2;
+  MDG_CHECK_ARG(batch * ntri < (1ll << 31), "mdg_cov_finalize: grid too large");
+  hipLaunchKernelGGL(cov_finalize_kernel, dim3((unsigned)(batch * ntri)), dim3(256), 0, (hipStream_t)stream, sigma,
+                     (int)n, ld_sigma, sigma_bs, tiles, (int)ntri, scale);
+  MDG_LAUNCH_CHECK();
+  return MDG_OK;
+}
+
+static const int BI_MAX_BLOCKS = 2048;
+extern "C" size_t mdg_bi_ws_bytes(int64_t n_tokens) { return (size_t)BI_MAX_BLOCKS * sizeof(double); }
+
+extern "C" int mdg_bi_accum(const void* x_in, const void* x_out, int dtype, int64_t n_tokens, int64_t d, int64_t ld,
+                            double* out, void* ws, size_t ws_bytes, void* stream) {
+  MDG_CHECK_ARG(x_in && x_out && out && n_tokens >= 0 && d > 0 && ld >= d, "mdg_bi_accum: bad arguments");
+  MDG_CHECK_ARG(ws && ws_bytes >= mdg_bi_ws_bytes(n_tokens), "mdg_bi_accum: workspace too small");
+  if (n_tokens == 0) return MDG_OK;
+  int blocks = (int)(ceil_div(n_tokens, 4) < BI_MAX_BLOCKS ? ceil_div(n_tokens, 4) : BI_MAX_BLOCKS);
+  hipStream_t st = (hipStream_t)stream;
+  double* partial = (double*)ws;
+  switch (dtype) {
+    case MDG_BF16: hipLaunchKernelGGL(bi_partial_kernel<MDG_BF16>, dim3(blocks), dim3(256), 0, st, x_in, x_out, n_tokens, d, ld, partial); break;
+    case MDG_F16: hipLaunchKernelGGL(bi_partial_kernel<MDG_F16>, dim3(blocks), dim3(256), 0, st, x_in, x_out, n_tokens, d, ld, partial); break;
+    case MDG_F32: hipLaunchKernelGGL(bi_partial_kernel<MDG_F32>, dim3(blocks), dim3(256), 0, st, x_in, x_out, n_tokens, d, ld, partial); break;
+    case MDG_F64: hipLaunchKernelGGL(bi_partial_kernel<MDG_F64>, dim3(blocks), dim3(256), 0, st, x_in, x_out, n_tokens, d, ld, partial); break;
+    default: MDG_CHECK_ARG(false, "mdg_bi_accum: unknown dtype %d", dtype);
+  }
+  MDG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bi_final_kernel, dim3(1), dim3(64), 0, st, partial, blocks, out);
+  MDG_LAUNCH_CHECK();
+  return MDG_OK;
+}

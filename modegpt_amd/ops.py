@@ -1,0 +1,298 @@
+"""torch-tensor front ends of the C ABI: pointer/stride extraction, workspace allocation, stream hand-off.
+
+PyTorch is plumbing here (device memory + the current HIP stream); all arithmetic happens in
+libmodegpt_hip.so.  Every function requires CUDA(HIP) tensors and raises otherwise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+_DT = {torch.bfloat16: _lib.MDG_BF16, torch.float16: _lib.MDG_F16, torch.float32: _lib.MDG_F32,
+       torch.float64: _lib.MDG_F64}
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _need_gpu(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("modegpt_amd ops run on the GPU only (got a CPU tensor); there is no CPU fallback")
+
+
+def _ws(nbytes: int, device) -> Tuple[Optional[torch.Tensor], int]:
+    if nbytes == 0:
+        return None, 0
+    t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return t, t.data_ptr()
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------ covariance
+def cov_accum(sigma: torch.Tensor, x: torch.Tensor, n_heads: int = 1, relu: bool = False) -> None:
+    """sigma (lower triangle) += X^T X in fp64.  x: [..., n_heads*feat] (bf16/f16/f32/f64, last dim
+    contiguous, viewed as [tokens, n_heads*feat]); sigma: [feat, feat] or [n_heads, feat, feat] fp64.
+    Only the lower triangle is valid until cov_finalize()."""
+    _need_gpu(sigma, x)
+    lib = _lib.load()
+    if sigma.dtype != torch.float64 or not sigma.is_contiguous():
+        raise ValueError("sigma must be a contiguous float64 tensor")
+    x2 = x.detach().reshape(-1, x.shape[-1])
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    feat = sigma.shape[-1]
+    if sigma.shape[-2] != feat or x2.shape[1] != n_heads * feat:
+        raise ValueError(f"shape mismatch: x {tuple(x.shape)} vs sigma {tuple(sigma.shape)} with n_heads={n_heads}")
+    if sigma.dim() == 3 and sigma.shape[0] != n_heads:
+        raise ValueError("sigma batch dimension must equal n_heads")
+    n_tok = x2.shape[0]
+    nbytes = lib.mdg_cov_accum_ws_bytes(n_tok, feat, n_heads)
+    ws, wsp = _ws(nbytes, x.device)
+    with torch.cuda.device(x.device):
+        check(lib.mdg_cov_accum(x2.data_ptr(), _DT[x2.dtype], n_tok, feat, n_heads, x2.stride(0), int(relu),
+                                sigma.data_ptr(), feat, feat * feat, wsp, nbytes, _stream(x)), "mdg_cov_accum")
+
+
+def cov_finalize(sigma: torch.Tensor, scale: float) -> None:
+    """sigma <- scale * sigma (lower) mirrored into the upper triangle."""
+    _need_gpu(sigma)
+    lib = _lib.load()
+    n = sigma.shape[-1]
+    batch = 1 if sigma.dim() == 2 else sigma.shape[0]
+    with torch.cuda.device(sigma.device):
+        check(lib.mdg_cov_finalize(sigma.data_ptr(), n, batch, n, n * n, float(scale), _stream(sigma)),
+              "mdg_cov_finalize")
+
+
+def bi_accum(out: torch.Tensor, x_in: torch.Tensor, x_out: torch.Tensor) -> None:
+    """out[0] += sum_tokens (1 - cos(x_in, x_out)); out: 1-element fp64 device tensor."""
+    _need_gpu(out, x_in, x_out)
+    lib = _lib.load()
+    a = x_in.detach().reshape(-1, x_in.shape[-1])
+    b = x_out.detach().reshape(-1, x_out.shape[-1])
+    if a.dtype != b.dtype or a.shape != b.shape:
+        raise ValueError("x_in / x_out must match in dtype and shape")
+    a = a if a.is_contiguous() else a.contiguous()
+    b = b if b.is_contiguous() else b.contiguous()
+    nbytes = lib.mdg_bi_ws_bytes(a.shape[0])
+    ws, wsp = _ws(nbytes, a.device)
+    with torch.cuda.device(a.device):
+        check(lib.mdg_bi_accum(a.data_ptr(), b.data_ptr(), _DT[a.dtype], a.shape[0], a.shape[1], a.stride(0),
+                               out.data_ptr(), wsp, nbytes, _stream(a)), "mdg_bi_accum")
+
+
+# ------------------------------------------------------------------ dense blocks
+def gemm(A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, alpha: float = 1.0, beta: float = 0.0,
+         trans_a: bool = False, trans_b: bool = False, a_rows: Optional[torch.Tensor] = None, flags: int = 0) -> None:
+    """C_out = alpha * op(A) @ op(B) + beta * C_out for 2-D row-major tensors (f64 or bf16)."""
+    _need_gpu(A, B, C_out)
+    lib = _lib.load()
+    M, N = C_out.shape
+    K = A.shape[0] if trans_a else A.shape[1]
+    sa_i, sa_k = (A.stride(1), A.stride(0)) if trans_a else (A.stride(0), A.stride(1))
+    sb_k, sb_j = (B.stride(1), B.stride(0)) if trans_b else (B.stride(0), B.stride(1))
+    with torch.cuda.device(A.device):
+        check(lib.mdg_gemm_f64(M, N, K, alpha, A.data_ptr(), _DT[A.dtype], sa_i, sa_k, _p(a_rows), B.data_ptr(),
+                               _DT[B.dtype], sb_k, sb_j, beta, C_out.data_ptr(), _DT[C_out.dtype], C_out.stride(0),
+                               1, 0, 0, 0, flags, _stream(A)), "mdg_gemm_f64")
+
+
+def potrf_lower(A: torch.Tensor) -> torch.Tensor:
+    """In-place lower Cholesky of the square fp64 matrix A; returns the inverted-diagonal-block buffer."""
+    _need_gpu(A)
+    lib = _lib.load()
+    n = A.shape[0]
+    inv = torch.empty(lib.mdg_potrf_inv_diag_elems(n), dtype=torch.float64, device=A.device)
+    with torch.cuda.device(A.device):
+        check(lib.mdg_potrf_lower(A.data_ptr(), n, A.stride(0), inv.data_ptr(), _stream(A)), "mdg_potrf_lower")
+    return inv
+
+
+def potrs_lower(L: torch.Tensor, inv: torch.Tensor, X: torch.Tensor) -> None:
+    """X <- (L L^T)^-1 X in place."""
+    _need_gpu(L, inv, X)
+    lib = _lib.load()
+    with torch.cuda.device(L.device):
+        check(lib.mdg_potrs_lower(L.data_ptr(), L.shape[0], L.stride(0), inv.data_ptr(), X.data_ptr(), X.shape[1],
+                                  X.stride(0), _stream(L)), "mdg_potrs_lower")
+
+
+def syevj(A: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Eigen-decomposition of a batch of symmetric matrices [b, n, n] (n <= 128, even).
+    Returns (evals descending [b, n], evecs [b, n, n], eigenvector j in column j).  A is not modified."""
+    _need_gpu(A)
+    lib = _lib.load()
+    A3 = A.reshape(-1, A.shape[-2], A.shape[-1]).to(torch.float64).clone()
+    b, n, _ = A3.shape
+    evals = torch.empty(b, n, dtype=torch.float64, device=A.device)
+    evecs = torch.empty(b, n, n, dtype=torch.float64, device=A.device)
+    with torch.cuda.device(A.device):
+        check(lib.mdg_syevj_batched(A3.data_ptr(), n, b, evals.data_ptr(), evecs.data_ptr(), _stream(A)),
+              "mdg_syevj_batched")
+    return evals, evecs
+
+
+def sqrt_psd_small(M: torch.Tensor, ridge: float, scaled: bool, want_inverse: bool):
+    """Batched sqrt_M for n <= 128: returns (root, inv_root or None, evals descending pre-ridge)."""
+    _need_gpu(M)
+    lib = _lib.load()
+    M3 = M.reshape(-1, M.shape[-2], M.shape[-1]).to(torch.float64).contiguous()
+    b, n, _ = M3.shape
+    root = torch.empty_like(M3)
+    inv_root = torch.empty_like(M3) if want_inverse else None
+    evals = torch.empty(b, n, dtype=torch.float64, device=M.device)
+    nbytes = lib.mdg_sqrt_psd_small_ws_bytes(n, b)
+    ws, wsp = _ws(nbytes, M.device)
+    with torch.cuda.device(M.device):
+        check(lib.mdg_sqrt_psd_small(M3.data_ptr(), n, b, float(ridge), int(scaled), root.data_ptr(), _p(inv_root),
+                                     evals.data_ptr(), wsp, nbytes, _stream(M)), "mdg_sqrt_psd_small")
+    return root.reshape(M.shape), (None if inv_root is None else inv_root.reshape(M.shape)), evals
+
+
+# ------------------------------------------------------------------ MLP
+def ridge_scores(Cm: torch.Tensor, ridge: float) -> torch.Tensor:
+    """diag((C + ridge I)^-1) for a symmetric PD fp64 matrix."""
+    _need_gpu(Cm)
+    lib = _lib.load()
+    if Cm.dtype != torch.float64 or Cm.stride(1) != 1:
+        raise ValueError("C must be float64 with unit column stride")
+    n = Cm.shape[0]
+    scores = torch.empty(n, dtype=torch.float64, device=Cm.device)
+    nbytes = lib.mdg_ridge_scores_ws_bytes(n)
+    ws, wsp = _ws(nbytes, Cm.device)
+    with torch.cuda.device(Cm.device):
+        check(lib.mdg_ridge_scores(Cm.data_ptr(), n, Cm.stride(0), float(ridge), scores.data_ptr(), wsp, nbytes,
+                                   _stream(Cm)), "mdg_ridge_scores")
+    return scores
+
+
+def select_smallest_sorted(scores: torch.Tensor, k: int) -> torch.Tensor:
+    """Indices of the k smallest scores in ascending index order (topk(largest=False) + sort)."""
+    _need_gpu(scores)
+    lib = _lib.load()
+    s = scores.to(torch.float64).contiguous()
+    idx = torch.empty(k, dtype=torch.int64, device=s.device)
+    with torch.cuda.device(s.device):
+        check(lib.mdg_select_smallest_sorted(s.data_ptr(), s.numel(), k, idx.data_ptr(), _stream(s)),
+              "mdg_select_smallest_sorted")
+    return idx
+
+
+def gather_rows(W: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
+    """W[rows, :] for a 2-byte dtype (bf16/f16) row-major matrix."""
+    _need_gpu(W, rows)
+    lib = _lib.load()
+    if W.element_size() != 2 or W.stride(1) != 1:
+        raise ValueError("gather_rows needs a 2-byte dtype with unit column stride")
+    rows = rows.to(torch.int64).contiguous()
+    out = torch.empty(rows.numel(), W.shape[1], dtype=W.dtype, device=W.device)
+    with torch.cuda.device(W.device):
+        check(lib.mdg_gather_rows_16(W.data_ptr(), W.stride(0), rows.data_ptr(), rows.numel(), W.shape[1],
+                                     out.data_ptr(), out.stride(0), _stream(W)), "mdg_gather_rows_16")
+    return out
+
+
+def nystrom_down(Cm: torch.Tensor, idx: torch.Tensor, W_down: torch.Tensor, eps: float = 1e-6,
+                 want_f64: bool = False):
+    """down' [d, r] bf16 = ((C[idx,idx] + eps I)^-1 C[idx,:] W_down^T)^T;  W_down: [d, n] bf16."""
+    _need_gpu(Cm, idx, W_down)
+    lib = _lib.load()
+    if W_down.dtype != torch.bfloat16:
+        W_down = W_down.to(torch.bfloat16)
+    if W_down.stride(1) != 1:
+        W_down = W_down.contiguous()
+    n, r, d = Cm.shape[0], idx.numel(), W_down.shape[0]
+    idx = idx.to(torch.int64).contiguous()
+    out = torch.empty(d, r, dtype=torch.bfloat16, device=Cm.device)
+    f64 = torch.empty(r, d, dtype=torch.float64, device=Cm.device) if want_f64 else None
+    nbytes = lib.mdg_nystrom_down_ws_bytes(n, r, d)
+    ws, wsp = _ws(nbytes, Cm.device)
+    with torch.cuda.device(Cm.device):
+        check(lib.mdg_nystrom_down(Cm.data_ptr(), n, Cm.stride(0), idx.data_ptr(), r, W_down.data_ptr(), d,
+                                   W_down.stride(0), float(eps), out.data_ptr(), out.stride(0), _p(f64), wsp, nbytes,
+                                   _stream(Cm)), "mdg_nystrom_down")
+    return (out, f64) if want_f64 else out
+
+
+# ------------------------------------------------------------------ QK / VO
+def qk_select(cov_q: torch.Tensor, cov_k: torch.Tensor, rank: int, mode: int, ridge_q: float, ridge_k: float):
+    """Returns (mask [n_kv, rank] int64, q_rows [n_heads*rank], k_rows [n_kv*rank])."""
+    _need_gpu(cov_q, cov_k)
+    lib = _lib.load()
+    cq = cov_q.to(torch.float64).contiguous()
+    ck = cov_k.to(torch.float64).contiguous()
+    n_heads, hd, _ = cq.shape
+    n_kv = ck.shape[0]
+    dev = cq.device
+    mask = torch.empty(n_kv, rank, dtype=torch.int64, device=dev)
+    q_rows = torch.empty(n_heads * rank, dtype=torch.int64, device=dev)
+    k_rows = torch.empty(n_kv * rank, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.mdg_qk_select(cq.data_ptr(), ck.data_ptr(), n_heads, n_kv, hd, float(ridge_q), float(ridge_k), rank,
+                                mode, mask.data_ptr(), q_rows.data_ptr(), k_rows.data_ptr(), _stream(cq)),
+              "mdg_qk_select")
+    return mask, q_rows, k_rows
+
+
+def vo_compress(cov_x: torch.Tensor, W_v: torch.Tensor, W_o: torch.Tensor, n_heads: int, n_kv: int, hd: int, rank: int,
+                ridge: float, want_f64: bool = False):
+    """Returns (v_proj [n_kv*rank, d] bf16, o_proj [d, n_heads*rank] bf16[, v_f64, o_f64])."""
+    _need_gpu(cov_x, W_v, W_o)
+    lib = _lib.load()
+    Wv = W_v.to(torch.bfloat16)
+    Wo = W_o.to(torch.bfloat16)
+    Wv = Wv if Wv.stride(1) == 1 else Wv.contiguous()
+    Wo = Wo if Wo.stride(1) == 1 else Wo.contiguous()
+    Cx = cov_x if (cov_x.dtype == torch.float64 and cov_x.stride(1) == 1) else cov_x.to(torch.float64).contiguous()
+    d = Cx.shape[0]
+    dev = Cx.device
+    v_out = torch.empty(n_kv * rank, d, dtype=torch.bfloat16, device=dev)
+    o_out = torch.empty(d, n_heads * rank, dtype=torch.bfloat16, device=dev)
+    v64 = torch.empty(n_kv * rank, d, dtype=torch.float64, device=dev) if want_f64 else None
+    o64 = torch.empty(d, n_heads * rank, dtype=torch.float64, device=dev) if want_f64 else None
+    nbytes = lib.mdg_vo_compress_ws_bytes(d, n_heads, n_kv, hd)
+    ws, wsp = _ws(nbytes, dev)
+    with torch.cuda.device(dev):
+        check(lib.mdg_vo_compress(Cx.data_ptr(), d, Cx.stride(0), Wv.data_ptr(), Wv.stride(0), Wo.data_ptr(),
+                                  Wo.stride(0), n_heads, n_kv, hd, rank, float(ridge), v_out.data_ptr(),
+                                  v_out.stride(0), o_out.data_ptr(), o_out.stride(0), _p(v64), _p(o64), wsp, nbytes,
+                                  _stream(Cx)), "mdg_vo_compress")
+    return (v_out, o_out, v64, o64) if want_f64 else (v_out, o_out)
+
+
+def cast_transpose(x: torch.Tensor) -> torch.Tensor:
+    """bf16(x^T) for an fp64 matrix, with torch's double->float->bf16 rounding."""
+    _need_gpu(x)
+    lib = _lib.load()
+    out = torch.empty(x.shape[1], x.shape[0], dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.mdg_cast_transpose_f64_bf16(x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), out.data_ptr(),
+                                              out.stride(0), _stream(x)), "mdg_cast_transpose_f64_bf16")
+    return out
+
+
+def probe_mfma_f64(iters: int = 4096) -> float:
+    """Measured fp64-MFMA issue rate of this device in TFLOP/s (register-resident operands)."""
+    lib = _lib.load()
+    out = C.c_double(0.0)
+    check(lib.mdg_probe_mfma_f64(iters, C.byref(out), torch.cuda.current_stream().cuda_stream), "mdg_probe_mfma_f64")
+    return out.value
+
+
+def device_info(device: int = 0):
+    lib = _lib.load()
+    name = C.create_string_buffer(64)
+    n_cu = C.c_int(0)
+    hbm = C.c_int64(0)
+    check(lib.mdg_device_info(device, name, 64, C.byref(n_cu), C.byref(hbm)), "mdg_device_info")
+    return name.value.decode(), n_cu.value, hbm.value

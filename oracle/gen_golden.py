@@ -1,0 +1,336 @@
+"""Generate tests/golden/*.npz by importing the REFERENCE hot-path functions on CPU.
+
+TEST INFRASTRUCTURE ONLY (see oracle/modegpt_oracle.py).  Runs in the build
+container only -- /root/reference does not exist on the GPU box; the vectors it
+writes are committed so they travel instead.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [--ref /root/reference]
+
+What is pinned by the reference's own code (imported, device constants patched
+"cuda:0" -> "cpu"):
+  G1 sigma_mlp via LlamaAdapter._llama_pre_gate_hook / ModelAdapter._make_fc_hook
+     (sigma_x / sigma_q / sigma_k hooks carry a literal "cuda" and cannot run on
+     CPU; those come from the oracle restatement and are marked `restated`)
+  G2 get_ridge_scores, compress_weights
+  G3 sqrt_M incl. a rank-deficient input
+  G4 compress_head_llama_grouped / compress_head_llama / compress_head_opt
+  G5 compress_head_grouped / compress_head
+  G6 allocate_global_sparsity
+  G7 rank rules of compress_qk / compress_vo (captured through stubs)
+While generating, every reference output is also compared with the oracle and
+the max deviation is printed.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import signal
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle import modegpt_oracle as O  # noqa: E402
+
+F64 = torch.float64
+BF16 = torch.bfloat16
+
+
+def bf16_bits(t: torch.Tensor) -> np.ndarray:
+    return t.detach().to(BF16).contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def make_acts(gen, tokens, feat, lo=0.05, hi=2.0):
+    """bf16 activations with a per-feature log-uniform scale (non-flat spectrum)."""
+    z = torch.randn(tokens, feat, generator=gen, dtype=torch.float32)
+    c = torch.exp(torch.empty(feat).uniform_(np.log(lo), np.log(hi), generator=gen))
+    return (z * c).to(BF16)
+
+
+def make_weight(gen, rows, cols):
+    return (torch.randn(rows, cols, generator=gen, dtype=torch.float32) * 0.02).to(BF16)
+
+
+def load_reference(ref_root):
+    sys.path.insert(0, ref_root)
+    import src.model_utils  # noqa: F401
+    import src.compression_utils as cu
+    import src.compression.compress_mlp as cm
+    import src.compression.compress_qk as cq
+    import src.compression.compress_vo as cv
+    import src.adapters.LlamaAdapter as la
+    import src.adapters.model_adapter as ma
+    for mod in (cu, cm, cq, cv):
+        for name in ("d1", "d2"):
+            if hasattr(mod, name):
+                setattr(mod, name, "cpu")
+    la.calib_device = "cpu"
+    ma.calib_device = "cpu"
+    return types.SimpleNamespace(cu=cu, cm=cm, cq=cq, cv=cv, la=la, ma=ma)
+
+
+def maxrel(a, b):
+    a = a.to(F64)
+    b = b.to(F64)
+    return ((a - b).abs().max() / (b.abs().max() + 1e-300)).item()
+
+
+def canon_sign_rows(v: torch.Tensor) -> torch.Tensor:
+    """Rows of a [r, d] factor: make the largest-|.| element of each row positive."""
+    i = v.abs().argmax(dim=1)
+    s = torch.sign(v[torch.arange(v.shape[0]), i])
+    s[s == 0] = 1
+    return s
+
+
+def gen_case(R, name, arch, d, d_ff, n_h, n_kv, hd, tokens, n_texts, keep, seed, ridges, outdir):
+    gen = torch.Generator().manual_seed(seed)
+    H = make_acts(gen, tokens, d_ff)
+    if arch == "opt":  # the fc hook applies ReLU to fc1's output itself
+        H_pre = H
+    X = make_acts(gen, tokens, d)
+    Qp = make_acts(gen, tokens, n_h * hd, 0.1, 3.0)
+    Kp = make_acts(gen, tokens, n_kv * hd, 0.1, 3.0)
+    W = {
+        "up": make_weight(gen, d_ff, d), "gate": make_weight(gen, d_ff, d), "down": make_weight(gen, d, d_ff),
+        "q": make_weight(gen, n_h * hd, d), "k": make_weight(gen, n_kv * hd, d),
+        "v": make_weight(gen, n_kv * hd, d), "o": make_weight(gen, d, n_h * hd),
+    }
+    out = {"meta_arch": np.array(arch), "meta_dims": np.array([d, d_ff, n_h, n_kv, hd, tokens, n_texts]),
+           "meta_keep": np.array(keep), "meta_ridges": np.array([ridges["nystrom_ridge"], ridges["ridge_qk"],
+                                                                  ridges["ridge_vo"]])}
+    for k, v in W.items():
+        out["w_" + k] = bf16_bits(v)
+    out["act_h"], out["act_x"], out["act_q"], out["act_k"] = map(bf16_bits, (H, X, Qp, Kp))
+
+    # ---- G1: sigma accumulation, two batches to pin the += semantics ----
+    half = tokens // 2
+    cov_mlp = [torch.zeros(d_ff, d_ff, dtype=F64)]
+    if arch == "opt":
+        hook = R.ma.ModelAdapter._make_fc_hook(0, cov_mlp)
+        hook(None, None, H_pre[:half].view(1, half, d_ff))
+        hook(None, None, H_pre[half:].view(1, tokens - half, d_ff))
+    else:
+        hook = R.la.LlamaAdapter._llama_pre_gate_hook(0, cov_mlp)
+        hook(None, (H[:half].view(1, half, d_ff),))
+        hook(None, (H[half:].view(1, tokens - half, d_ff),))
+    sig_mlp = cov_mlp[0] / (n_texts * 2048)  # calibration.py:141-143
+    o_mlp = torch.zeros(d_ff, d_ff, dtype=F64)
+    for part in (H[:half], H[half:]):
+        (O.cov_accum_tokens_relu if arch == "opt" else O.cov_accum_tokens)(o_mlp, part)
+    O.cov_finalize(o_mlp, n_texts)
+    print(f"[{name}] sigma_mlp oracle vs ref hook: {maxrel(o_mlp, sig_mlp):.2e}")
+    # restated (literal "cuda" in the reference hooks)
+    sig_x = torch.zeros(d, d, dtype=F64)
+    sig_q = torch.zeros(n_h, hd, hd, dtype=F64)
+    sig_k = torch.zeros(n_kv, hd, hd, dtype=F64)
+    for sl in (slice(0, half), slice(half, tokens)):
+        O.cov_accum_tokens(sig_x, X[sl])
+        O.cov_accum_heads(sig_q, Qp[sl], n_h, hd)
+        O.cov_accum_heads(sig_k, Kp[sl], n_kv, hd)
+    for s in (sig_x, sig_q, sig_k):
+        O.cov_finalize(s, n_texts)
+    out["sigma_mlp"], out["sigma_x"], out["sigma_q"], out["sigma_k"] = (
+        sig_mlp.numpy(), sig_x.numpy(), sig_q.numpy(), sig_k.numpy())
+    out["meta_restated"] = np.array("sigma_x,sigma_q,sigma_k")
+
+    # ---- G2: MLP ----
+    lin = lambda w: types.SimpleNamespace(weight=w)  # noqa: E731
+    comps = types.SimpleNamespace(up_proj=lin(W["up"]), gate_proj=lin(W["gate"]), down_proj=lin(W["down"]))
+    scores = R.cm.get_ridge_scores(sig_mlp, layer_idx=0, ridge_lambda=ridges["nystrom_ridge"])
+    up_T, down64_as_bf16, gate_T, rank = R.cm.compress_weights(comps, sig_mlp, keep, 0, ridges["nystrom_ridge"])
+    # fp64 pre-cast W_d' : repeat the reference's lines with its own helpers' outputs
+    idx_ref = torch.sort(torch.topk(scores, k=rank, largest=False, dim=0).indices)[0]
+    o_out, (o_idx, o_down64, o_scores) = O.compress_mlp_layer(
+        W["up"], None if arch == "opt" else W["gate"], W["down"], sig_mlp, keep, ridges["nystrom_ridge"])
+    assert torch.equal(o_idx, idx_ref), "oracle selection differs from reference"
+    assert torch.equal(o_out["up"], up_T.T), "up rows differ"
+    print(f"[{name}] ridge scores oracle vs ref: {maxrel(o_scores, scores):.2e}; "
+          f"down bf16 equal: {torch.equal(o_out['down'], down64_as_bf16.T)}")
+    out["mlp_scores"] = scores.numpy()
+    out["mlp_idx"] = idx_ref.numpy()
+    out["mlp_rank"] = np.array(rank)
+    out["mlp_up"] = bf16_bits(up_T.T)
+    out["mlp_gate"] = bf16_bits(gate_T.T)
+    out["mlp_down"] = bf16_bits(down64_as_bf16.T)  # [d, r] as saved (compress_mlp.py:97)
+    out["mlp_down_f64"] = o_down64.numpy()  # oracle's fp64 (reference exposes only the bf16 cast)
+
+    # ---- G3: sqrt_M ----
+    s_vo, is_vo = R.cu.sqrt_M(sig_x, ridge_lambda=ridges["ridge_vo"], inverse_sqrt=True)
+    o_s, o_is = O.sqrt_M(sig_x, ridge_lambda=ridges["ridge_vo"], inverse_sqrt=True)
+    print(f"[{name}] sqrt_M oracle vs ref: {maxrel(o_s, s_vo):.2e} / inv {maxrel(o_is, is_vo):.2e}")
+    out["sqrt_x"], out["invsqrt_x"] = s_vo.numpy(), is_vo.numpy()
+
+    # ---- G4: QK ----
+    r_qk = O.qk_rank(hd, keep, arch)
+    Wq_h = W["q"].view(n_h, hd, -1)
+    Wk_h = W["k"].view(n_kv, hd, -1)
+    Qo, Ko, masks = [], [], []
+    grouped = n_kv != n_h
+    for h in range(n_kv):
+        if arch in ("llama", "qwen3") and grouped:
+            R.cq.compress_head_llama_grouped(
+                kv_head_idx=h, kv_head_ratio=n_h // n_kv, cov_q_layer=sig_q, cov_k_layer=sig_k,
+                Wq_heads=Wq_h, Wk_heads=Wk_h, Q_heads_out=Qo, K_heads_out=Ko, layer_rotary_mask=masks,
+                rank=r_qk, ridge_lambda=ridges["ridge_qk"])
+        elif arch == "llama":
+            R.cq.compress_head_llama(sig_q[h], sig_k[h], Wq_h[h], Wk_h[h], Q_heads_out=Qo, K_heads_out=Ko,
+                                     layer_rotary_mask=masks, rank=r_qk)
+        else:
+            bq = torch.zeros(n_h * hd)
+            bo = []
+            qn, kn, _, _ = R.cq.compress_head_opt(sig_q[h], sig_k[h], Wq_h[h], Wk_h[h], bq[:hd], bq[:hd],
+                                                  Qo, Ko, bo, bo, rank=r_qk)
+            # recover the mask the reference used (it does not return it): match rows
+            sc = O.qk_scores_opt(sig_q[h], sig_k[h])
+            m = torch.topk(sc, k=r_qk).indices
+            assert torch.equal(Wq_h[h][m], qn)
+            masks.append(m)
+    mask_ref = torch.cat([m.to(torch.int64) for m in masks]).reshape(n_kv, -1)
+    q_ref = torch.cat(Qo, dim=0).to(BF16)
+    k_ref = torch.cat(Ko, dim=0).to(BF16)
+    o_qk, o_mask = O.compress_qk_layer(W["q"], W["k"], sig_q, sig_k, n_h, n_kv, hd, r_qk, arch, ridges["ridge_qk"])
+    assert torch.equal(o_mask, mask_ref), "oracle qk mask differs"
+    assert torch.equal(o_qk["q_proj"], q_ref) and torch.equal(o_qk["k_proj"], k_ref)
+    print(f"[{name}] qk masks/rows identical (rank {r_qk})")
+    out["qk_rank"], out["qk_mask"] = np.array(r_qk), mask_ref.numpy()
+    out["qk_q"], out["qk_k"] = bf16_bits(q_ref), bf16_bits(k_ref)
+
+    # ---- G5: VO ----
+    r_vo = O.vo_rank(hd, keep, arch)
+    sC = R.cu.sqrt_M(sig_x, ridge_lambda=ridges["ridge_vo"])
+    isC = torch.linalg.inv(sC)  # compress_vo.py:45
+    Vn, On = [], []
+    for h in range(n_kv):
+        if grouped:
+            R.cv.compress_head_grouped(kv_head_idx=h, kv_head_ratio=n_h // n_kv, head_dim=hd, rank=r_vo,
+                                       W_v=W["v"], W_o=W["o"], sqrt_C=sC, inv_sqrt_C=isC,
+                                       new_heads_V=Vn, new_heads_O=On)
+        else:
+            R.cv.compress_head(head_idx=h, head_dim=hd, rank_i=r_vo, W_v=W["v"], W_o=W["o"], sqrt_C=sC,
+                               inv_sqrt_C=isC, new_heads_V=Vn, new_heads_O=On)
+    v64 = torch.cat(Vn, dim=0)
+    o64 = torch.cat(On, dim=1)
+    o_vo, (ov64, oo64) = O.compress_vo_layer(W["v"], W["o"], sig_x, n_h, n_kv, hd, r_vo, ridges["ridge_vo"])
+    # sign-invariant comparison: per kv head, |v rows| and the product o'v'
+    g = n_h // n_kv
+    worst = 0.0
+    for h in range(n_kv):
+        for j in range(g):
+            qh = h * g + j
+            P_ref = o64[:, qh * r_vo:(qh + 1) * r_vo] @ v64[h * r_vo:(h + 1) * r_vo]
+            P_or = oo64[:, qh * r_vo:(qh + 1) * r_vo] @ ov64[h * r_vo:(h + 1) * r_vo]
+            worst = max(worst, maxrel(P_or, P_ref))
+    print(f"[{name}] vo per-head products oracle vs ref: {worst:.2e} (rank {r_vo})")
+    out["vo_rank"] = np.array(r_vo)
+    out["vo_v_f64"], out["vo_o_f64"] = v64.numpy(), o64.numpy()
+    out["vo_v"], out["vo_o"] = bf16_bits(v64), bf16_bits(o64)
+
+    np.savez_compressed(os.path.join(outdir, f"{name}.npz"), **out)
+
+
+def _alarm(signum, frame):
+    raise TimeoutError
+
+
+def gen_misc(R, outdir):
+    out = {}
+    # ---- G3b: rank-deficient sqrt_M (tokens < n) ----
+    gen = torch.Generator().manual_seed(77)
+    Xd = make_acts(gen, 24, 48).to(F64)
+    Md = Xd.T @ Xd / 24
+    s, si = R.cu.sqrt_M(Md, ridge_lambda=1e-5, inverse_sqrt=True)
+    s2 = R.cu.sqrt_M(Md, ridge_lambda=1e-3, scaled=True)
+    out["rd_M"], out["rd_sqrt"], out["rd_invsqrt"], out["rd_sqrt_scaled"] = Md.numpy(), s.numpy(), si.numpy(), s2.numpy()
+    o_s, o_si = O.sqrt_M(Md, 1e-5, inverse_sqrt=True)
+    print(f"[misc] rank-deficient sqrt_M oracle vs ref: {maxrel(o_s, s):.2e} / {maxrel(o_si, si):.2e}")
+
+    # ---- G6: allocate_global_sparsity grid ----
+    rng = np.random.default_rng(5)
+    cases = []
+    for L, ratio, smooth, cap in [(12, 0.2, 0.15, 0.8), (32, 0.3, 0.15, 0.8), (32, 0.4, 0.015, 0.8),
+                                  (40, 0.3, 0.05, 0.6), (32, 0.5, 0.15, 0.8), (16, 0.6, 0.3, 0.8),
+                                  (24, 0.45, 0.1, 0.7), (32, 0.55, 0.2, 0.75), (8, 0.7, 0.01, 0.8)]:
+        bi = (rng.random(L) * 0.4 + 0.02).tolist()
+        # the reference's clamp loop (compression_utils.py:110-122) need not terminate: entries already
+        # pinned at the cap count as "free" again.  Guard the call and skip such inputs.
+        signal.signal(signal.SIGALRM, _alarm)
+        signal.alarm(5)
+        try:
+            keep = R.cu.allocate_global_sparsity(bi, ratio, smoothing=smooth, max_sparsity=cap)
+        except TimeoutError:
+            print(f"[misc] reference allocate_global_sparsity did not terminate for L={L} ratio={ratio} "
+                  f"smoothing={smooth} cap={cap}; case skipped")
+            continue
+        finally:
+            signal.alarm(0)
+        mine = O.allocate_global_sparsity(bi, ratio, smoothing=smooth, max_sparsity=cap)
+        assert keep == mine, "oracle allocation differs from reference"
+        print(f"[misc]   L={L} ratio={ratio} smoothing={smooth} cap={cap}: "
+              f"{sum(abs(k - (1 - cap)) < 1e-12 for k in keep)} layers at the cap")
+        cases.append((bi, ratio, smooth, cap, keep))
+    for i, (bi, ratio, smooth, cap, keep) in enumerate(cases):
+        out[f"alloc{i}_bi"] = np.array(bi)
+        out[f"alloc{i}_par"] = np.array([ratio, smooth, cap])
+        out[f"alloc{i}_keep"] = np.array(keep)
+    out["alloc_n"] = np.array(len(cases))
+    print(f"[misc] allocate_global_sparsity: {len(cases)} cases bit-identical")
+
+    # ---- G7: rank rules, captured by stubbing the per-layer workers ----
+    rows = []
+    for arch in ("llama", "qwen3", "opt"):
+        for hd in (16, 64, 128):
+            for keep in (0.05, 0.2, 0.33, 0.5, 0.6, 0.695, 0.7, 0.8, 0.99, 1.0):
+                seen = {}
+                ad = types.SimpleNamespace(n_layers=1, head_dim=hd, arch=arch, model=None, n_heads=4, n_kv_heads=2,
+                                           config=types.SimpleNamespace(ridge_vo=1e-4))
+                orig = R.cq.compress_layer
+                R.cq.compress_layer = lambda a, i, rank, **kw: seen.__setitem__("qk", rank)
+                try:
+                    R.cq.compress_qk(ad, ([None], [None]), [keep], target_layers=[0])
+                finally:
+                    R.cq.compress_layer = orig
+
+                def stub(**kw):
+                    seen["vo"] = kw.get("rank", kw.get("rank_i"))
+                    raise KeyboardInterrupt  # unwind out of the reference loop
+                ad.get_attn_components = lambda layer: types.SimpleNamespace(
+                    v_proj=types.SimpleNamespace(weight=None), o_proj=types.SimpleNamespace(weight=None))
+                o1, o2 = R.cv.compress_head_grouped, R.cv.compress_head
+                R.cv.compress_head_grouped = R.cv.compress_head = stub
+                try:
+                    R.cv.compress_vo(ad, [torch.eye(4, dtype=F64)], keep_ratios=[keep], target_layers=[0])
+                except KeyboardInterrupt:
+                    pass
+                finally:
+                    R.cv.compress_head_grouped, R.cv.compress_head = o1, o2
+                assert seen["qk"] == O.qk_rank(hd, keep, arch) and seen["vo"] == O.vo_rank(hd, keep, arch)
+                rows.append((["llama", "qwen3", "opt"].index(arch), hd, keep, seen["qk"], seen["vo"]))
+    out["rank_rules"] = np.array(rows, dtype=np.float64)
+    print(f"[misc] rank rules: {len(rows)} rows identical")
+    np.savez_compressed(os.path.join(outdir, "misc.npz"), **out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    torch.set_num_threads(8)
+    R = load_reference(a.ref)
+    recipe = {"nystrom_ridge": 1e-4, "ridge_qk": 1e-2, "ridge_vo": 1e-5}  # tests.sh:100-104
+    default = {"nystrom_ridge": 1e-2, "ridge_qk": 1e-6, "ridge_vo": 1e-4}  # CompressionConfig.py:19,32-33
+    gen_case(R, "tiny_gqa", "llama", 64, 160, 4, 2, 16, 512, 2, 0.7, 11, recipe, a.out)
+    gen_case(R, "tiny_gqa_k06", "qwen3", 64, 160, 4, 2, 16, 384, 3, 0.6, 12, default, a.out)
+    gen_case(R, "tiny_mha", "llama", 64, 160, 4, 4, 16, 512, 2, 0.8, 13, recipe, a.out)
+    gen_case(R, "tiny_opt", "opt", 64, 160, 4, 4, 16, 512, 2, 0.8, 14, default, a.out)
+    gen_case(R, "med_gqa", "llama", 128, 384, 2, 1, 64, 1024, 4, 0.7, 15, recipe, a.out)
+    gen_misc(R, a.out)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,55 @@
+"""Load tests/golden/*.npz (written by oracle/gen_golden.py from the imported reference) as torch tensors."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = ["tiny_gqa", "tiny_gqa_k06", "tiny_mha", "tiny_opt", "med_gqa"]
+
+
+def bf16_from_bits(a: np.ndarray) -> torch.Tensor:
+    return torch.from_numpy(a.view(np.int16).copy()).view(torch.bfloat16)
+
+
+class Case:
+    def __init__(self, name):
+        z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.name = name
+        self.arch = str(z["meta_arch"])
+        (self.d, self.d_ff, self.n_h, self.n_kv, self.hd, self.tokens, self.n_texts) = [int(v) for v in z["meta_dims"]]
+        self.keep = float(z["meta_keep"])
+        r = z["meta_ridges"]
+        self.ridges = {"nystrom_ridge": float(r[0]), "ridge_qk": float(r[1]), "ridge_vo": float(r[2])}
+        self.W = {k[2:]: bf16_from_bits(z[k]) for k in z.files if k.startswith("w_")}
+        self.act = {k[4:]: bf16_from_bits(z[k]) for k in z.files if k.startswith("act_")}
+        self.f64 = {k: torch.from_numpy(z[k]) for k in ("sigma_mlp", "sigma_x", "sigma_q", "sigma_k", "mlp_scores",
+                                                         "mlp_down_f64", "sqrt_x", "invsqrt_x", "vo_v_f64", "vo_o_f64")}
+        self.bf = {k: bf16_from_bits(z[k]) for k in ("mlp_up", "mlp_gate", "mlp_down", "qk_q", "qk_k", "vo_v", "vo_o")}
+        self.mlp_idx = torch.from_numpy(z["mlp_idx"])
+        self.mlp_rank = int(z["mlp_rank"])
+        self.qk_rank = int(z["qk_rank"])
+        self.qk_mask = torch.from_numpy(z["qk_mask"])
+        self.vo_rank = int(z["vo_rank"])
+
+
+def load_misc():
+    return np.load(os.path.join(GOLDEN_DIR, "misc.npz"))
+
+
+def vo_products(v, o, n_h, n_kv, r):
+    """Sign/rotation-invariant view of the VO factors: per query head o'[:, head] @ v'[kv(head)]."""
+    g = n_h // n_kv
+    out = []
+    for qh in range(n_h):
+        h = qh // g
+        out.append(o[:, qh * r:(qh + 1) * r].double() @ v[h * r:(h + 1) * r].double())
+    return torch.stack(out)
+
+
+def canon_rows(v, r):
+    """Flip each row of a [n*r, d] factor so its largest-|.| entry is positive; returns (v', signs)."""
+    i = v.abs().argmax(dim=1)
+    s = torch.sign(v[torch.arange(v.shape[0]), i])
+    s[s == 0] = 1
+    return v * s[:, None], s

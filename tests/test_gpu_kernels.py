@@ -1,0 +1,293 @@
+"""GPU parity tests of the individual C-ABI entry points against the CPU oracle (tests only import oracle/)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import modegpt_oracle as O
+from tests.golden_util import CASES, Case, canon_rows, vo_products
+
+pytestmark = pytest.mark.gpu
+F64 = torch.float64
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-300)).item()
+
+
+@pytest.fixture(scope="module")
+def ops(dev):
+    from modegpt_amd import ops as _ops
+    return _ops
+
+
+def acts(gen, tokens, feat, dtype=torch.bfloat16):
+    z = torch.randn(tokens, feat, generator=gen)
+    c = torch.exp(torch.empty(feat).uniform_(np.log(0.05), np.log(2.0), generator=gen))
+    return (z * c).to(dtype)
+
+
+# ---------------------------------------------------------------- covariance
+@pytest.mark.parametrize("name", CASES)
+def test_cov_golden(ops, dev, name):
+    c = Case(name)
+    half = c.tokens // 2
+    relu = c.arch == "opt"
+    sig = {"mlp": torch.zeros(c.d_ff, c.d_ff, dtype=F64, device=dev), "x": torch.zeros(c.d, c.d, dtype=F64, device=dev),
+           "q": torch.zeros(c.n_h, c.hd, c.hd, dtype=F64, device=dev),
+           "k": torch.zeros(c.n_kv, c.hd, c.hd, dtype=F64, device=dev)}
+    for sl in (slice(0, half), slice(half, c.tokens)):
+        ops.cov_accum(sig["mlp"], c.act["h"][sl].to(dev), relu=relu)
+        ops.cov_accum(sig["x"], c.act["x"][sl].to(dev).view(1, -1, c.d))
+        ops.cov_accum(sig["q"], c.act["q"][sl].to(dev), n_heads=c.n_h)
+        ops.cov_accum(sig["k"], c.act["k"][sl].to(dev), n_heads=c.n_kv)
+    for k in sig:
+        ops.cov_finalize(sig[k], 1.0 / (c.n_texts * 2048))
+        want = c.f64["sigma_" + k]
+        got = sig[k].cpu()
+        assert rel(got, want) < 1e-13, (k, rel(got, want))
+        assert torch.equal(got, got.transpose(-1, -2)), "finalize must leave an exactly symmetric matrix"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32, torch.float64])
+@pytest.mark.parametrize("tokens,feat,heads", [(777, 384, 1), (1024, 256, 1), (300, 200, 1), (515, 128, 3),
+                                               (2048, 64, 4), (40, 16, 2), (0, 64, 1), (5000, 1024, 1)])
+def test_cov_shapes(ops, dev, dtype, tokens, feat, heads):
+    gen = torch.Generator().manual_seed(tokens * 31 + feat)
+    x = acts(gen, tokens, feat * heads, dtype)
+    sig = torch.zeros(heads, feat, feat, dtype=F64)
+    O.cov_accum_heads(sig, x, heads, feat)
+    O.cov_accum_heads(sig, x, heads, feat)
+    got = torch.zeros(heads, feat, feat, dtype=F64, device=dev)
+    xd = x.to(dev)
+    ops.cov_accum(got, xd, n_heads=heads)
+    ops.cov_accum(got, xd, n_heads=heads)
+    ops.cov_finalize(got, 1.0)
+    if tokens == 0:
+        assert got.abs().max().item() == 0.0
+    else:
+        assert rel(got, sig) < 1e-13
+
+
+def test_cov_strided_rows_and_relu(ops, dev):
+    gen = torch.Generator().manual_seed(3)
+    full = acts(gen, 600, 512)
+    x = full[:, 128:384]  # row stride 512, unit column stride, 16-byte aligned offset
+    sig = torch.zeros(256, 256, dtype=F64)
+    O.cov_accum_tokens_relu(sig, x)
+    got = torch.zeros(256, 256, dtype=F64, device=dev)
+    ops.cov_accum(got, full.to(dev)[:, 128:384], relu=True)
+    ops.cov_finalize(got, 1.0)
+    assert rel(got, sig) < 1e-13
+    y = full[:, 3:259]  # misaligned column offset -> scalar staging path
+    sig2 = torch.zeros(256, 256, dtype=F64)
+    O.cov_accum_tokens(sig2, y)
+    got2 = torch.zeros(256, 256, dtype=F64, device=dev)
+    ops.cov_accum(got2, full.to(dev)[:, 3:259])
+    ops.cov_finalize(got2, 1.0)
+    assert rel(got2, sig2) < 1e-13
+
+
+def test_cov_deterministic(ops, dev):
+    gen = torch.Generator().manual_seed(9)
+    x = acts(gen, 4096, 128 * 8).to(dev)
+    outs = []
+    for _ in range(2):
+        s = torch.zeros(8, 128, 128, dtype=F64, device=dev)
+        ops.cov_accum(s, x, n_heads=8)  # split-K path
+        outs.append(s.clone())
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_bi_accum(ops, dev):
+    gen = torch.Generator().manual_seed(5)
+    a = acts(gen, 3 * 50, 192).view(3, 50, 192)
+    b = (a.float() + 0.3 * torch.randn(3, 50, 192, generator=gen)).to(torch.bfloat16)
+    want = O.bi_score_batch(a, b) * 50  # oracle returns mean over T of the sum over B
+    out = torch.zeros(1, dtype=F64, device=dev)
+    ops.bi_accum(out, a.to(dev), b.to(dev))
+    assert abs(out.item() - want) / abs(want) < 1e-12
+
+
+# ---------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (200, 130, 77), (64, 300, 512), (1, 1, 1), (257, 129, 16)])
+@pytest.mark.parametrize("ta,tb", [(False, False), (True, False), (False, True), (True, True)])
+def test_gemm(ops, dev, M, N, K, ta, tb):
+    gen = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn((K, M) if ta else (M, K), generator=gen, dtype=F64)
+    B = torch.randn((N, K) if tb else (K, N), generator=gen, dtype=F64)
+    C0 = torch.randn(M, N, generator=gen, dtype=F64)
+    want = 0.5 * (A.T if ta else A) @ (B.T if tb else B) - 2.0 * C0
+    Cd = C0.to(dev)
+    ops.gemm(A.to(dev), B.to(dev), Cd, alpha=0.5, beta=-2.0, trans_a=ta, trans_b=tb)
+    assert rel(Cd, want) < 1e-13
+
+
+def test_gemm_bf16_gather(ops, dev):
+    gen = torch.Generator().manual_seed(1)
+    A = torch.randn(300, 200, generator=gen, dtype=F64)
+    rows = torch.randperm(300, generator=gen)[:150].sort().values
+    B = torch.randn(90, 200, generator=gen).to(torch.bfloat16)  # used transposed
+    want = A[rows] @ B.double().T
+    out = torch.empty(150, 90, dtype=F64, device=dev)
+    ops.gemm(A.to(dev), B.to(dev), out, trans_b=True, a_rows=rows.to(dev))
+    assert rel(out, want) < 1e-13
+    outb = torch.empty(150, 90, dtype=torch.bfloat16, device=dev)
+    ops.gemm(A.to(dev), B.to(dev), outb, trans_b=True, a_rows=rows.to(dev))
+    assert torch.equal(outb.cpu(), want.to(torch.bfloat16))
+
+
+# ---------------------------------------------------------------- Cholesky family
+def spd(gen, n, cond_pow=3.0):
+    Q, _ = torch.linalg.qr(torch.randn(n, n, generator=gen, dtype=F64))
+    lam = torch.logspace(0, -cond_pow, n, dtype=F64)
+    return (Q * lam) @ Q.T
+
+
+@pytest.mark.parametrize("n", [16, 128, 129, 300, 640, 1000])
+def test_potrf_potrs(ops, dev, n):
+    gen = torch.Generator().manual_seed(n)
+    A = spd(gen, n)
+    L = torch.linalg.cholesky(A)
+    Ad = A.to(dev).clone()
+    inv = ops.potrf_lower(Ad)
+    assert rel(torch.tril(Ad), L) < 1e-11
+    B = torch.randn(n, 70, generator=gen, dtype=F64)
+    X = torch.cholesky_solve(B, L)
+    Bd = B.to(dev).clone()
+    ops.potrs_lower(Ad, inv, Bd)
+    assert rel(Bd, X) < 1e-9
+
+
+def test_potrf_not_pd(ops, dev):
+    A = torch.eye(200, dtype=F64)
+    A[150, 150] = -1.0
+    with pytest.raises(torch.linalg.LinAlgError):
+        ops.potrf_lower(A.to(dev))
+
+
+@pytest.mark.parametrize("n", [64, 160, 384, 704, 1100])
+def test_ridge_scores(ops, dev, n):
+    gen = torch.Generator().manual_seed(n + 1)
+    H = acts(gen, 3 * n, n).double()
+    Cm = H.T @ H / (3 * n)
+    lam = float(torch.tensor(1e-4, dtype=torch.float32).double())
+    want = O.ridge_scores(Cm, 1e-4)
+    got = ops.ridge_scores(Cm.to(dev), lam)
+    assert rel(got, want) < 1e-9
+
+
+@pytest.mark.parametrize("n,k", [(160, 112), (14336, 10035), (1000, 1), (1000, 1000), (5, 3)])
+def test_select(ops, dev, n, k):
+    gen = torch.Generator().manual_seed(n + k)
+    s = torch.rand(n, generator=gen, dtype=F64)
+    want = O.mlp_select(s, k)
+    got = ops.select_smallest_sorted(s.to(dev), k)
+    assert torch.equal(got.cpu(), want)
+
+
+def test_select_ties_lower_index_first(ops, dev):
+    s = torch.tensor([3.0, 1.0, 2.0, 1.0, 1.0, 5.0, float("nan"), 0.5], dtype=F64)
+    got = ops.select_smallest_sorted(s.to(dev), 3)
+    assert got.cpu().tolist() == [1, 3, 7]
+
+
+def test_gather_rows(ops, dev):
+    gen = torch.Generator().manual_seed(2)
+    W = torch.randn(500, 264, generator=gen).to(torch.bfloat16)
+    rows = torch.randperm(500, generator=gen)[:123]
+    assert torch.equal(ops.gather_rows(W.to(dev), rows.to(dev)).cpu(), W[rows])
+    W2 = torch.randn(50, 37, generator=gen).to(torch.bfloat16)  # odd width -> scalar path
+    assert torch.equal(ops.gather_rows(W2.to(dev), rows[:20].to(dev) % 50).cpu(), W2[rows[:20] % 50])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_mlp_golden(ops, dev, name):
+    c = Case(name)
+    Cm = c.f64["sigma_mlp"].to(dev)
+    lam32 = float(torch.tensor(c.ridges["nystrom_ridge"], dtype=torch.float32).double())
+    scores = ops.ridge_scores(Cm, lam32)
+    assert rel(scores, c.f64["mlp_scores"]) < 1e-9
+    idx = ops.select_smallest_sorted(scores, c.mlp_rank)
+    assert torch.equal(idx.cpu(), c.mlp_idx), "rank selection must be bit-identical"
+    assert torch.equal(ops.gather_rows(c.W["up"].to(dev), idx).cpu(), c.bf["mlp_up"])
+    down, down64 = ops.nystrom_down(Cm, idx, c.W["down"].to(dev), want_f64=True)
+    assert rel(down64, c.f64["mlp_down_f64"]) < 1e-7
+    mism = (down.cpu().view(torch.int16) != c.bf["mlp_down"].view(torch.int16)).float().mean().item()
+    assert mism < 1e-3, f"bf16 down_proj differs on {mism:.2%} of elements"
+    assert rel(down, c.bf["mlp_down"]) < 2 ** -7
+
+
+# ---------------------------------------------------------------- eigen / QK / VO
+@pytest.mark.parametrize("n,batch", [(16, 3), (64, 5), (128, 2), (2, 1)])
+def test_syevj(ops, dev, n, batch):
+    gen = torch.Generator().manual_seed(n)
+    A = torch.randn(batch, n, n, generator=gen, dtype=F64)
+    A = A @ A.transpose(1, 2) / n
+    lam, V = ops.syevj(A.to(dev))
+    lam, V = lam.cpu(), V.cpu()
+    want = torch.linalg.eigvalsh(A).flip(-1)
+    assert rel(lam, want) < 1e-13
+    recon = V @ torch.diag_embed(lam) @ V.transpose(1, 2)
+    assert rel(recon, A) < 1e-13
+    eye = torch.eye(n, dtype=F64).expand(batch, n, n)
+    assert (V.transpose(1, 2) @ V - eye).abs().max().item() < 1e-13
+
+
+def test_sqrt_psd_small(ops, dev):
+    from tests.golden_util import load_misc
+    z = load_misc()
+    M = torch.from_numpy(z["rd_M"])
+    root, inv, _ = ops.sqrt_psd_small(M.to(dev), 1e-5, False, True)
+    assert rel(root, torch.from_numpy(z["rd_sqrt"])) < 1e-10
+    assert rel(inv, torch.from_numpy(z["rd_invsqrt"])) < 1e-8
+    root2, _, _ = ops.sqrt_psd_small(M.to(dev), 1e-3, True, False)
+    assert rel(root2, torch.from_numpy(z["rd_sqrt_scaled"])) < 1e-10
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_qk_golden(ops, dev, name):
+    from modegpt_amd import _lib
+    c = Case(name)
+    grouped = c.n_kv != c.n_h
+    if c.arch == "opt":
+        mode, rq, rk = _lib.MDG_QK_OPT, 1e-4, 1e-4
+    elif grouped:
+        mode, rq, rk = _lib.MDG_QK_ROPE_GROUPED, 1e-4, c.ridges["ridge_qk"]
+    else:
+        mode, rq, rk = _lib.MDG_QK_ROPE_MHA, 1e-4, 1e-4
+    mask, q_rows, k_rows = ops.qk_select(c.f64["sigma_q"].to(dev), c.f64["sigma_k"].to(dev), c.qk_rank, mode, rq, rk)
+    assert torch.equal(mask.cpu(), c.qk_mask), "QK mask (order included) must be bit-identical"
+    assert torch.equal(ops.gather_rows(c.W["q"].to(dev), q_rows).cpu(), c.bf["qk_q"])
+    assert torch.equal(ops.gather_rows(c.W["k"].to(dev), k_rows).cpu(), c.bf["qk_k"])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_vo_golden(ops, dev, name):
+    c = Case(name)
+    v, o, v64, o64 = ops.vo_compress(c.f64["sigma_x"].to(dev), c.W["v"].to(dev), c.W["o"].to(dev), c.n_h, c.n_kv, c.hd,
+                                     c.vo_rank, c.ridges["ridge_vo"], want_f64=True)
+    r = c.vo_rank
+    # invariant: per-head products
+    P_got = vo_products(v64.cpu(), o64.cpu(), c.n_h, c.n_kv, r)
+    P_ref = vo_products(c.f64["vo_v_f64"], c.f64["vo_o_f64"], c.n_h, c.n_kv, r)
+    assert rel(P_got, P_ref) < 1e-8
+    # factors up to a per-component sign
+    vg, sg = canon_rows(v64.cpu(), r)
+    vr, sr = canon_rows(c.f64["vo_v_f64"], r)
+    assert rel(vg, vr) < 1e-6
+    g = c.n_h // c.n_kv
+    for qh in range(c.n_h):
+        h = qh // g
+        og = o64.cpu()[:, qh * r:(qh + 1) * r] * sg[h * r:(h + 1) * r]
+        orf = c.f64["vo_o_f64"][:, qh * r:(qh + 1) * r] * sr[h * r:(h + 1) * r]
+        assert rel(og, orf) < 1e-6
+    # bf16 outputs are the casts of the fp64 factors
+    assert torch.equal(v.cpu(), v64.cpu().to(torch.bfloat16))
+    assert torch.equal(o.cpu(), o64.cpu().to(torch.bfloat16))
+
+
+def test_probe(ops, dev):
+    tf = ops.probe_mfma_f64(2048)
+    print(f"fp64 MFMA probe: {tf:.1f} TFLOP/s")
+    assert 20 < tf < 200
