@@ -67,6 +67,10 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm must bring in ITS libamdhip64 first: the kernels run on torch's streams and device pointers, so
+    # both have to share one HIP runtime instance (loading ours first binds /opt/rocm's copy and the process ends
+    # up with a runtime that sees no device).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ModeGPTLibraryError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -1,0 +1,135 @@
+"""Llama adapter (reference: src/adapters/LlamaAdapter.py).  Hook sites as the reference registers them
+(LlamaAdapter.py:71-100): pre-hook on mlp.down_proj, forward hooks on input_layernorm, q_proj, k_proj
+(pre-RoPE statistics; the post-RoPE variant is disabled upstream)."""
+from __future__ import annotations
+
+import copy
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from .. import ops
+from .model_adapter import (AttentionComponents, MLPComponents, MLPTensors, ModelAdapter, QKComponents, QKTensors,
+                            VOComponents, VOTensors)
+
+
+class LlamaAdapter(ModelAdapter):
+    @property
+    def arch(self) -> str:
+        return "llama"
+
+    def get_transformer_blocks(self) -> nn.ModuleList:
+        return self.model.model.layers
+
+    def _block(self, layer_idx: int) -> nn.Module:
+        return self.get_transformer_blocks()[layer_idx]
+
+    # ---- hooks ----
+    def register_hooks(self, layer_idx, block, cov_mlp_list, cov_q_list, cov_k_list, cov_x_list, handles, logger):
+        handles.append(block.mlp.down_proj.register_forward_pre_hook(self._llama_pre_gate_hook(layer_idx, cov_mlp_list)))
+        handles.append(block.input_layernorm.register_forward_hook(self._input_hook(layer_idx, cov_x_list)))
+        handles.append(block.self_attn.k_proj.register_forward_hook(
+            self._make_proj_hook(layer_idx, cov_k_list, self.n_kv_heads, self.head_dim, block)))
+        handles.append(block.self_attn.q_proj.register_forward_hook(
+            self._make_proj_hook(layer_idx, cov_q_list, self.n_heads, self.head_dim, block)))
+
+    @staticmethod
+    def _llama_pre_gate_hook(layer_idx, cov_mlp_list):
+        """sigma_mlp += H^T H, H = the input of down_proj (LlamaAdapter.py:127-136)."""
+        @torch.no_grad()
+        def hook(module, input: Tuple[Tensor]):
+            ops.cov_accum(cov_mlp_list[layer_idx], input[0])
+            return None
+        return hook
+
+    @staticmethod
+    def _input_hook(layer_idx, cov_list):
+        """sigma_x += sum_b X_b^T X_b, X = input_layernorm's output (LlamaAdapter.py:138-147)."""
+        @torch.no_grad()
+        def hook(module, inp, out):
+            ops.cov_accum(cov_list[layer_idx], out)
+        return hook
+
+    def compute_layer_energy(self, layer_idx: int, Ca: Optional[Tensor] = None) -> MLPTensors:
+        raise NotImplementedError("compute_layer_energy not imp for llama")
+
+    def calibrate_model(self, n_samples: int, batch_size: int, target_layers, dataset="wikitext"):
+        raise NotImplementedError("custom calibrate model not impl for llama")
+
+    # ---- components ----
+    def get_mlp_components(self, layer_idx: int, expert_idx: Optional[int] = None) -> MLPComponents:
+        b = self._block(layer_idx)
+        return MLPComponents(block=b, up_proj=b.mlp.up_proj, down_proj=b.mlp.down_proj, gate_proj=b.mlp.gate_proj)
+
+    def get_mlp_tensors(self, layer_idx: int, expert_idx: Optional[int] = None) -> MLPTensors:
+        b = self._block(layer_idx)
+        return MLPTensors(up_proj=b.mlp.up_proj.weight, down_proj=b.mlp.down_proj.weight,
+                          gate_proj=b.mlp.gate_proj.weight)
+
+    def get_vo_components(self, layer_idx: int, expert_idx: Optional[int] = None) -> VOComponents:
+        b = self._block(layer_idx)
+        return VOComponents(block=b, v_proj=b.self_attn.v_proj, o_proj=b.self_attn.o_proj)
+
+    def get_vo_tensors(self, layer_idx: int, expert_idx: Optional[int] = None) -> VOTensors:
+        b = self._block(layer_idx)
+        return VOTensors(v_proj=b.self_attn.v_proj.weight, o_proj=b.self_attn.o_proj.weight)
+
+    def get_qk_components(self, layer_idx: int, expert_idx: Optional[int] = None) -> QKComponents:
+        b = self._block(layer_idx)
+        return QKComponents(block=b, query_proj=b.self_attn.q_proj, key_proj=b.self_attn.k_proj)
+
+    def get_qk_tensors(self, layer_idx: int, expert_idx: Optional[int] = None) -> QKTensors:
+        b = self._block(layer_idx)
+        return QKTensors(query_proj=b.self_attn.q_proj.weight, key_proj=b.self_attn.k_proj.weight)
+
+    def get_attn_components(self, layer_idx: int) -> AttentionComponents:
+        a = self._block(layer_idx).self_attn
+        return AttentionComponents(block=self._block(layer_idx), q_proj=a.q_proj, k_proj=a.k_proj, v_proj=a.v_proj,
+                                   o_proj=a.o_proj)
+
+    def get_qk_weights(self, layer_idx: int) -> Tuple[Tensor, Tensor]:
+        a = self._block(layer_idx).self_attn
+        return a.q_proj.weight, a.k_proj.weight
+
+    def get_vo_weights(self, layer_idx: int) -> Tuple[Tensor, Tensor]:
+        a = self._block(layer_idx).self_attn
+        return a.v_proj.weight, a.o_proj.weight
+
+    # ---- rebuild ----
+    def replace_mlp_layers(self, layer_idx, new_up, new_down, new_gate=None, expert_idx=None) -> None:
+        mlp = self._block(layer_idx).mlp
+        mlp.up_proj, mlp.down_proj = new_up, new_down
+        if new_gate is not None:
+            mlp.gate_proj = new_gate
+
+    def replace_attn_layers(self, layer_idx, new_q, new_k, new_v, new_o) -> None:
+        a = self._block(layer_idx).self_attn
+        for name, mod in (("q_proj", new_q), ("k_proj", new_k), ("v_proj", new_v), ("o_proj", new_o)):
+            if mod is not None:
+                setattr(a, name, mod)
+
+    def patch_config(self):
+        """Stamp the per-layer ranks and the auto_map the patched modeling files expect (LlamaAdapter.py:250-302)."""
+        cfg = self.model.config
+        original = copy.deepcopy(cfg)
+        ranks = {k: [] for k in ("q", "k", "v", "o", "gate")}
+        for i in range(cfg.num_hidden_layers):
+            qk, vo, mlp = self.get_qk_tensors(i), self.get_vo_tensors(i), self.get_mlp_tensors(i)
+            ranks["q"].append(qk.query_proj.shape[0])
+            ranks["k"].append(qk.key_proj.shape[0])
+            ranks["v"].append(vo.v_proj.shape[0])
+            ranks["o"].append(vo.o_proj.shape[1])
+            ranks["gate"].append(mlp.gate_proj.shape[0])
+        cfg.ffn_dim = -1
+        cfg.q_ranks, cfg.k_ranks, cfg.v_ranks, cfg.o_ranks = ranks["q"], ranks["k"], ranks["v"], ranks["o"]
+        cfg.gate_ranks = ranks["gate"]
+        mt = cfg.model_type
+        if mt == "opt":
+            cfg.auto_map = {"AutoModelForCausalLM": "OPTRebuild.OPTForCausalLM"}
+        if mt == "llama":
+            cfg.auto_map = {"AutoModelForCausalLM": "LlamaRebuild.LlamaForCausalLM"}
+        if "qwen" in mt:
+            cfg.auto_map = {"AutoModelForCausalLM": "DenseQwenRebuild.Qwen3ForCausalLM"}
+        return original

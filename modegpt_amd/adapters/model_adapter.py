@@ -1,0 +1,294 @@
+"""The model-adapter plug-in surface (reference: src/adapters/model_adapter.py).
+
+Same class / method / property names and argument meanings, so adapters written against the reference ABC
+drop in.  What differs is underneath: the statistic hooks hand the activation's device pointer to the HIP
+covariance kernel (ops.cov_accum -> mdg_cov_accum) instead of upcasting to fp64 and calling torch matmul.
+Between hook calls a sigma buffer holds only its LOWER triangle; `load_calibs` mirrors and normalises it
+once at the end (mdg_cov_finalize).
+"""
+from __future__ import annotations
+
+import json
+import logging
+import os
+from abc import ABC, abstractmethod
+from dataclasses import dataclass
+from datetime import datetime
+from typing import Any, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from .. import ops
+from .CompressionConfig import CompressionConfig
+
+
+# ---- carriers between adapters and compressors (model_adapter.py:19-82) ----
+@dataclass
+class MLPTensors:
+    up_proj: Tensor
+    down_proj: Tensor
+    gate_proj: Optional[Tensor]
+
+    def to(self, dtype):
+        self.up_proj = self.up_proj.to(dtype=dtype)
+        self.down_proj = self.down_proj.to(dtype=dtype)
+        if self.gate_proj is not None:
+            self.gate_proj = self.gate_proj.to(dtype=dtype)
+        return self
+
+
+@dataclass
+class VOTensors:
+    v_proj: Tensor
+    o_proj: Tensor
+
+    def to(self, dtype):
+        self.v_proj, self.o_proj = self.v_proj.to(dtype=dtype), self.o_proj.to(dtype=dtype)
+        return self
+
+
+@dataclass
+class QKTensors:
+    query_proj: Tensor
+    key_proj: Tensor
+
+    def to(self, dtype):
+        self.query_proj, self.key_proj = self.query_proj.to(dtype=dtype), self.key_proj.to(dtype=dtype)
+        return self
+
+
+@dataclass
+class MLPComponents:
+    block: Optional[nn.Module]
+    up_proj: nn.Module
+    down_proj: nn.Module
+    gate_proj: Optional[nn.Module] = None
+
+
+@dataclass
+class QKComponents:
+    block: Optional[nn.Module]
+    query_proj: nn.Module
+    key_proj: nn.Module
+
+
+@dataclass
+class VOComponents:
+    block: Optional[nn.Module]
+    v_proj: nn.Module
+    o_proj: nn.Module
+
+
+@dataclass
+class AttentionComponents:
+    block: nn.Module
+    q_proj: nn.Module
+    k_proj: nn.Module
+    v_proj: Optional[nn.Module] = None
+    o_proj: Optional[nn.Module] = None
+
+
+def build_metrics(all_metrics: dict) -> dict:
+    """model_adapter.py:85-94."""
+    now = datetime.now()
+    run = now.strftime("%Y_%m_%d--%H_%M_%S")
+    m = {"RunName": run, "RunDate": now.strftime("%b %d, %Y %I:%M %p"), "latent_moe_metrics": {}}
+    all_metrics[run] = m
+    return m
+
+
+class ModelAdapter(ABC):
+    _metrics: dict = {}
+
+    def __init__(self, model: nn.Module, tokenizer=None):
+        self.model = model
+        self.model_config = model.config
+        self.config: CompressionConfig = CompressionConfig()
+        self.tokenizer = tokenizer
+        self.calibs = None
+        ModelAdapter.load_metrics()
+        self.metrics = build_metrics(ModelAdapter._metrics)
+
+    # ---- construction (model_adapter.py:118-135) ----
+    @staticmethod
+    def from_model(model: nn.Module, tokenizer) -> "ModelAdapter":
+        from .LlamaAdapter import LlamaAdapter
+        from .OPTAdapter import OPTAdapter
+        from .QwenAdapter import QwenAdapter
+        inner = getattr(model, "model", None)
+        if inner is not None and hasattr(inner, "decoder"):
+            return OPTAdapter(model, tokenizer=tokenizer)
+        if inner is not None and hasattr(inner, "layers"):
+            if "qwen3" in (getattr(model.config, "model_type", None) or ""):
+                return QwenAdapter(model, tokenizer=tokenizer)
+            return LlamaAdapter(model, tokenizer=tokenizer)
+        raise RuntimeError("Unsupported model architecture")
+
+    # ---- metrics (model_adapter.py:137-182) ----
+    @staticmethod
+    def load_metrics(path="./metrics/metrics.json"):
+        if not ModelAdapter._metrics and os.path.exists(path):
+            with open(path) as f:
+                ModelAdapter._metrics = json.load(f)
+
+    @staticmethod
+    def save_metrics_static(path="./metrics/metrics.json", backup_dir="./metrics/backups/",
+                            jsons_path="./metrics/jsons/", run_metrics: Optional[dict] = None):
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        os.makedirs(backup_dir, exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(ModelAdapter._metrics, f, indent=4)
+        if run_metrics:
+            os.makedirs(jsons_path, exist_ok=True)
+            note = (run_metrics.get("note") or "")[:15]
+            with open(os.path.join(jsons_path, f"{run_metrics['RunName']}--{note}.json"), "w") as f:
+                json.dump(run_metrics, f, indent=4)
+
+    def save_metrics(self, path="./metrics/metrics.json", backup_dir="./metrics/backups/"):
+        ModelAdapter.save_metrics_static(path=path, backup_dir=backup_dir, run_metrics=self.metrics)
+
+    # ---- reconstruction: per-(layer, stage) artefacts and the final swap (model_adapter.py:184-237) ----
+    def save_layer(self, output_dir: str, suffix: str, weights: dict, layer_idx):
+        """torch.save({name: bf16 tensor}) to <output_dir>/layer_<i>_<suffix>; env vars in the path expand."""
+        output_dir = os.path.expandvars(output_dir)
+        os.makedirs(output_dir, exist_ok=True)
+        torch.save(weights, os.path.join(output_dir, f"layer_{layer_idx}_{suffix}"))
+
+    @torch.no_grad()
+    def convert_model(self, saved_layers_dir: str = "./compressed_output/layers/", suffixes=("mlp", "qk", "vo"),
+                      device: str = "cuda"):
+        """Swap every layer's Linears for bias-free bf16 Linears built from the saved artefacts."""
+        saved_layers_dir = os.path.expandvars(saved_layers_dir)
+
+        def linear_of(w: Tensor) -> nn.Linear:
+            lin = nn.Linear(w.shape[1], w.shape[0], bias=False, device=device, dtype=torch.bfloat16)
+            lin.weight.data.copy_(w.to(torch.bfloat16))
+            return lin
+
+        for suffix in suffixes:
+            for i in range(self.n_layers):
+                art = torch.load(os.path.join(saved_layers_dir, f"layer_{i}_{suffix}"), map_location=device)
+                if suffix == "mlp":
+                    gate = art.get("gate")
+                    self.replace_mlp_layers(i, new_up=linear_of(art["up"]), new_down=linear_of(art["down"]),
+                                            new_gate=None if gate is None else linear_of(gate))
+                elif suffix == "qk":
+                    self.replace_attn_layers(i, new_q=linear_of(art["q_proj"]), new_k=linear_of(art["k_proj"]),
+                                             new_v=None, new_o=None)
+                elif suffix == "vo":
+                    self.replace_attn_layers(i, new_q=None, new_k=None, new_v=linear_of(art["v_proj"]),
+                                             new_o=linear_of(art["o_proj"]))
+
+    # ---- shape properties (model_adapter.py:253-307) ----
+    @property
+    def arch(self) -> str:
+        return self.model_config.model_type
+
+    @property
+    def n_layers(self) -> int:
+        c = self.model_config
+        return getattr(c, "n_layer", None) or getattr(c, "num_hidden_layers", None) or getattr(c, "num_layers", None)
+
+    @property
+    def n_heads(self) -> int:
+        c = self.model_config
+        return getattr(c, "n_head", None) or getattr(c, "num_attention_heads", None)
+
+    @property
+    def d_model(self) -> int:
+        c = self.model_config
+        return getattr(c, "hidden_size", None) or getattr(c, "dim", None)
+
+    @property
+    def d_int(self) -> int:
+        return getattr(self.model_config, "intermediate_size", None)
+
+    @property
+    def head_dim(self) -> int:
+        hd = getattr(self.model_config, "head_dim", None)
+        return hd if hd else self.d_model // self.n_heads  # OPTConfig carries no head_dim
+
+    @property
+    def n_experts(self) -> int:
+        if self.arch == "deepseek":
+            return getattr(self.model_config, "n_routed_experts", 0)
+        return getattr(self.model_config, "num_local_experts", 0)
+
+    @property
+    def n_kv_heads(self) -> int:
+        return getattr(self.model_config, "num_key_value_heads", self.n_heads)
+
+    def get_n_inner(self) -> int:
+        return self.model_config.intermediate_size
+
+    # ---- what an adapter must provide (model_adapter.py:249-392) ----
+    @abstractmethod
+    def compute_layer_energy(self, layer_idx: int, Ca: Optional[Tensor] = None) -> MLPTensors: ...
+
+    @abstractmethod
+    def calibrate_model(self, n_samples: int, batch_size: int, target_layers: List[int], dataset="wikitext"): ...
+
+    @abstractmethod
+    def get_transformer_blocks(self) -> nn.ModuleList: ...
+
+    @abstractmethod
+    def register_hooks(self, layer_idx: int, block: nn.Module, cov_mlp_list: List[Tensor], cov_q_list: List[Tensor],
+                       cov_k_list: List[Tensor], cov_x_list: List[Tensor], handles: List[Any],
+                       logger: logging.Logger): ...
+
+    def on_batch_end_step(self, layer_idx: int, x_in: Tensor, cov_x_list: List[Tensor]):
+        pass
+
+    @abstractmethod
+    def get_mlp_components(self, layer_idx: int, expert_idx: Optional[int] = None) -> MLPComponents: ...
+
+    @abstractmethod
+    def get_mlp_tensors(self, layer_idx: int, expert_idx: Optional[int] = None) -> MLPTensors: ...
+
+    @abstractmethod
+    def get_vo_components(self, layer_idx: int, expert_idx: Optional[int] = None) -> VOComponents: ...
+
+    @abstractmethod
+    def get_vo_tensors(self, layer_idx: int, expert_idx: Optional[int] = None) -> VOTensors: ...
+
+    @abstractmethod
+    def get_qk_components(self, layer_idx: int, expert_idx: Optional[int] = None) -> QKComponents: ...
+
+    @abstractmethod
+    def get_qk_tensors(self, layer_idx: int, expert_idx: Optional[int] = None) -> QKTensors: ...
+
+    @abstractmethod
+    def replace_mlp_layers(self, layer_idx: int, new_up: nn.Module, new_down: nn.Module,
+                           new_gate: Optional[nn.Module] = None, expert_idx: Optional[int] = None) -> None: ...
+
+    @abstractmethod
+    def get_attn_components(self, layer_idx: int) -> AttentionComponents: ...
+
+    @abstractmethod
+    def replace_attn_layers(self, layer_idx: int, new_q: Optional[nn.Module], new_k: Optional[nn.Module],
+                            new_v: Optional[nn.Module], new_o: Optional[nn.Module]) -> None: ...
+
+    @abstractmethod
+    def get_qk_weights(self, layer_idx: int) -> Tuple[Tensor, Tensor]: ...
+
+    @abstractmethod
+    def get_vo_weights(self, layer_idx: int) -> Tuple[Tensor, Tensor]: ...
+
+    # ---- statistic hooks shared by adapters (model_adapter.py:546-567) ----
+    @staticmethod
+    def _make_fc_hook(layer_idx, cov_mlp_list):
+        """sigma_mlp += ReLU(fc1 out)^T ReLU(fc1 out) -- ReLU fused into the kernel's load."""
+        @torch.no_grad()
+        def hook(module, inp, out):
+            ops.cov_accum(cov_mlp_list[layer_idx], out, relu=True)
+        return hook
+
+    @staticmethod
+    def _make_proj_hook(layer_idx, cov_list, n_heads, head_dim, d_model=None):
+        """sigma[h] += P_h^T P_h for every head, read in place from the [tokens, n_heads*head_dim] output."""
+        @torch.no_grad()
+        def hook(module, inp, out):
+            ops.cov_accum(cov_list[layer_idx], out, n_heads=n_heads)
+        return hook

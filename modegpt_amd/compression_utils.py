@@ -1,0 +1,86 @@
+"""sqrt_M and allocate_global_sparsity (reference: src/compression_utils.py)."""
+from __future__ import annotations
+
+import logging
+
+import torch
+from torch import Tensor
+from torch.nn.functional import softmax
+
+from . import ops
+from .model_utils import dtype_p
+
+logger = logging.getLogger("MoDeGPT")
+
+_MAX_CLAMP_ITERS = 10_000
+
+
+@torch.no_grad()
+def sqrt_M(M: Tensor, ridge_lambda=1e-4, scaled=False, debug: str = "", inverse_sqrt=False):
+    """Symmetric square root with an eigenvalue ridge (compression_utils.py:15-55): eigh, lambda += ridge *
+    (max lambda if scaled else 1), sqrt(clamp >= 0), V diag V^T; optionally the inverse root with the 1e-12 clamp.
+    Runs the batched LDS Jacobi solver (mdg_sqrt_psd_small); M may be [n, n] or [batch, n, n], n <= 128 even.
+
+    The d_model-sized call the reference makes from compress_vo (compress_vo.py:44) does not exist in this
+    engine -- compress_vo works on the head-sized Gram matrix instead (DESIGN.md "Identities") -- so larger n is
+    rejected loudly rather than served by some other library."""
+    n = M.shape[-1]
+    if n > 128 or n % 2:
+        raise NotImplementedError(
+            f"sqrt_M: n={n} is outside the device solver's range (even n <= 128). The hot path never needs it: "
+            "compress_vo uses the Gram identity and compress_qk the diagonal identity.")
+    root, inv_root, lam = ops.sqrt_psd_small(M, ridge_lambda, scaled, inverse_sqrt)
+    if debug or bool((lam[..., -1] < 0).any()):
+        lam_h = lam.reshape(-1, n).cpu()
+        for row in lam_h:
+            mx, mn = row[0].item(), row[-1].item()
+            if debug:
+                print(f"{debug} Pre-reg: {mx:.1e} / {mn:.1e} = {mx / (mn + 1e-9):.1e}")
+                print(f"{debug} Pre-reg: eigen.mean() = {row.mean().item():.1e}")
+            if mn < 0:
+                print(f"Warning: Negative eigenvalues found ({mn}). Matrix is not PSD.")
+            if debug:
+                post = row + ridge_lambda * (mx if scaled else 1.0)
+                print(f"{debug} Post-reg: {post[0].item():.1e} / {post[-1].item():.1e} = "
+                      f"{post[0].item() / (post[-1].item() + 1e-9):.1e}")
+                print(f"{debug} Post-reg eigen.mean() = {post.mean().item():.1e}")
+    root = root.to(dtype=M.dtype)
+    if not inverse_sqrt:
+        return root
+    return root, inv_root.to(dtype=M.dtype)
+
+
+def allocate_global_sparsity(bi_scores, compression_ratio: float, smoothing: float = 0.015, max_sparsity: float = 0.8,
+                             adapter=None, invert=False):
+    """Block-Influence scores -> per-layer keep ratios (compression_utils.py:79-124).  Host arithmetic on purpose:
+    the result feeds int(dim * keep) and must be bit-identical, including the fp32 rounding of the scores by
+    torch.tensor(list) before the fp64 softmax.
+
+    One deliberate difference: the reference's clamp loop treats entries pinned AT the cap as free again and
+    does not terminate for peaked softmax weights (found while generating goldens, oracle/gen_golden.py).  The
+    arithmetic per iteration is identical; this version stops with a RuntimeError after 10 000 iterations."""
+    if adapter:
+        adapter.metrics["smoothing"] = smoothing
+    n_layers = len(bi_scores)
+    s = torch.tensor(bi_scores).to(dtype_p)
+    if invert:
+        s = -s
+    total_budget = n_layers * compression_ratio
+    softmax_weights = softmax(-s / smoothing, dim=0)
+    sparsities = softmax_weights * total_budget
+    logger.info(f"Max Layer Sparsity: {sparsities.max().item()}, Avg = {sparsities.mean().item()}")
+    if adapter:
+        adapter.metrics["max_layer_sparsity"] = sparsities.max().item()
+    for _ in range(_MAX_CLAMP_ITERS):
+        clamped = sparsities > max_sparsity
+        if not clamped.any():
+            return (1 - sparsities).tolist()
+        excess = (sparsities[clamped] - max_sparsity).sum()
+        sparsities[clamped] = max_sparsity
+        free = ~clamped
+        if free.any():
+            sparsities[free] += excess * (softmax_weights[free] / softmax_weights[free].sum())
+    raise RuntimeError(
+        "allocate_global_sparsity: the cap redistribution did not settle (the reference loops forever on this "
+        f"input: ratio={compression_ratio}, smoothing={smoothing}, max_sparsity={max_sparsity}); "
+        "use a larger smoothing or a lower ratio")

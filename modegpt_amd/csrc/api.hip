@@ -15,7 +15,7 @@ void set_error(const char* fmt, ...) {
 }
 
 // Each wave issues `iters` x 16 independent-accumulator v_mfma_f64_16x16x4_f64; operands never leave registers.
-__global__ __launch_bounds__(256) void probe_mfma_f64_kernel(int iters, double* sink) {
+__global__ __launch_bounds__(256, 2) void probe_mfma_f64_kernel(int iters, double* sink) {
   d4 acc[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) acc[i] = (d4){0., 0., 0., 0.};
@@ -38,6 +38,7 @@ extern "C" int mdg_abi_version(void) { return MDG_ABI_VERSION; }
 extern "C" const char* mdg_last_error(void) { return g_err; }
 
 extern "C" int mdg_device_info(int device, char* name, int cap, int* n_cu, int64_t* hbm_bytes) {
+  MDG_CLEAR();
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device >= count) {
     set_error("mdg_device_info: no HIP device %d (count %d)", device, count);
@@ -55,6 +56,7 @@ extern "C" int mdg_device_info(int device, char* name, int cap, int* n_cu, int64
 }
 
 extern "C" int mdg_probe_mfma_f64(int iters, double* tflops, void* stream) {
+  MDG_CLEAR();
   MDG_CHECK_ARG(iters > 0 && tflops, "mdg_probe_mfma_f64: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   int dev = 0, n_cu = 0;
@@ -66,13 +68,17 @@ extern "C" int mdg_probe_mfma_f64(int iters, double* tflops, void* stream) {
   MDG_HIP(hipEventCreate(&e0));
   MDG_HIP(hipEventCreate(&e1));
   const int blocks = n_cu * 2;  // 8 waves per CU = 2 per SIMD
-  hipLaunchKernelGGL(probe_mfma_f64_kernel, dim3(blocks), dim3(256), 0, st, iters / 8 + 1, sink);  // warm
-  MDG_HIP(hipEventRecord(e0, st));
-  hipLaunchKernelGGL(probe_mfma_f64_kernel, dim3(blocks), dim3(256), 0, st, iters, sink);
-  MDG_HIP(hipEventRecord(e1, st));
-  MDG_HIP(hipEventSynchronize(e1));
-  float ms = 0.f;
-  MDG_HIP(hipEventElapsedTime(&ms, e0, e1));
+  hipLaunchKernelGGL(probe_mfma_f64_kernel, dim3(blocks), dim3(256), 0, st, iters, sink);  // warm
+  float ms = 1e30f;
+  for (int rep = 0; rep < 3; rep++) {  // best of three: the clock ramps under load
+    MDG_HIP(hipEventRecord(e0, st));
+    hipLaunchKernelGGL(probe_mfma_f64_kernel, dim3(blocks), dim3(256), 0, st, iters, sink);
+    MDG_HIP(hipEventRecord(e1, st));
+    MDG_HIP(hipEventSynchronize(e1));
+    float t = 0.f;
+    MDG_HIP(hipEventElapsedTime(&t, e0, e1));
+    if (t < ms) ms = t;
+  }
   const double flop = (double)blocks * 4 /*waves*/ * (double)iters * 16 * (2.0 * 16 * 16 * 4);
   *tflops = flop / (ms * 1e-3) / 1e12;
   (void)hipEventDestroy(e0);

@@ -243,12 +243,14 @@ using namespace mdg;
 extern "C" size_t mdg_potrf_inv_diag_elems(int64_t n) { return (size_t)ceil_div(n, NB) * NB * NB + 16; }
 
 extern "C" int mdg_potrf_lower(double* A, int64_t n, int64_t lda, double* inv_diag, void* stream) {
+  MDG_CLEAR();
   MDG_CHECK_ARG(A && inv_diag && n > 0 && lda >= n, "mdg_potrf_lower: bad arguments");
   return potrf_lower(A, n, lda, inv_diag, (hipStream_t)stream);
 }
 
 extern "C" int mdg_potrs_lower(const double* L, int64_t n, int64_t ldl, const double* inv_diag, double* X,
                                int64_t nrhs, int64_t ldx, void* stream) {
+  MDG_CLEAR();
   MDG_CHECK_ARG(L && inv_diag && X && n > 0 && nrhs > 0 && ldl >= n && ldx >= nrhs, "mdg_potrs_lower: bad arguments");
   return potrs_lower(L, n, ldl, inv_diag, X, nrhs, ldx, (hipStream_t)stream);
 }
@@ -259,6 +261,7 @@ extern "C" size_t mdg_chol_inverse_diag_ws_bytes(int64_t n) {
 
 extern "C" int mdg_chol_inverse_diag(const double* L, int64_t n, int64_t ldl, const double* inv_diag, double* out,
                                      void* ws, size_t ws_bytes, void* stream) {
+  MDG_CLEAR();
   MDG_CHECK_ARG(L && inv_diag && out && n > 0 && ldl >= n, "mdg_chol_inverse_diag: bad arguments");
   MDG_CHECK_ARG(ws && ws_bytes >= mdg_chol_inverse_diag_ws_bytes(n), "mdg_chol_inverse_diag: workspace too small");
   double* X = (double*)ws;
@@ -273,6 +276,7 @@ extern "C" size_t mdg_ridge_scores_ws_bytes(int64_t n) {
 
 extern "C" int mdg_ridge_scores(const double* C, int64_t n, int64_t ldc, double ridge, double* scores, void* ws,
                                 size_t ws_bytes, void* stream) {
+  MDG_CLEAR();
   MDG_CHECK_ARG(C && scores && n > 0 && ldc >= n, "mdg_ridge_scores: bad arguments");
   MDG_CHECK_ARG(ws && ws_bytes >= mdg_ridge_scores_ws_bytes(n), "mdg_ridge_scores: workspace %zu < required %zu",
                 ws_bytes, mdg_ridge_scores_ws_bytes(n));

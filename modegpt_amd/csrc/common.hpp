@@ -35,6 +35,8 @@ void set_error(const char* fmt, ...);
     }                                                                        \
   } while (0)
 #define MDG_LAUNCH_CHECK() MDG_HIP(hipGetLastError())
+// hipGetLastError is sticky per thread: drop whatever an earlier, unrelated HIP call left behind
+#define MDG_CLEAR() (void)hipGetLastError()
 #define MDG_TRY(call)              \
   do {                             \
     int s_ = (call);               \

@@ -34,7 +34,10 @@ template <int DT> struct Stage {
   };
 };
 
-template <int DT, bool RELU>
+// FAST: every tile is full and 16-byte loads are legal, so the stage is one unconditional vector load per
+// chunk and its s_waitcnt can sink below the stage's MFMAs; the generic path (ragged n_feat, unaligned
+// views) goes element by element.
+template <int DT, bool FAST>
 __device__ __forceinline__ void load_panel(const CovArgs& a, int64_t tok0, int64_t tok_end, int64_t col0,
                                            int col_lim, int tid, typename Stage<DT>::Chunk* regs) {
   typedef Stage<DT> S;
@@ -48,7 +51,9 @@ __device__ __forceinline__ void load_panel(const CovArgs& a, int64_t tok0, int64
     int64_t tok = tok0 + row;
     typename S::Chunk ch;
     ch.q = make_uint4(0, 0, 0, 0);
-    if (tok < tok_end) {
+    if (FAST) {
+      if (tok < tok_end) ch.q = *(const uint4*)(x + tok * a.ld + col0 + col);
+    } else if (tok < tok_end) {
       const T* src = x + tok * a.ld + col0 + col;
       if (a.vec_ok && col + S::VEC <= col_lim) {
         ch.q = *(const uint4*)src;
@@ -83,7 +88,7 @@ __device__ __forceinline__ void store_panel(double* panel, int tid, const typena
   }
 }
 
-template <int DT, bool RELU>
+template <int DT, bool RELU, bool FAST>
 __global__ __launch_bounds__(256, 2) void cov_accum_kernel(CovArgs a) {
   typedef Stage<DT> S;
   __shared__ double lds[4 * PANEL];  // As[2], Bs[2]
@@ -107,8 +112,8 @@ __global__ __launch_bounds__(256, 2) void cov_accum_kernel(CovArgs a) {
   const int64_t n_stage = tok_end > tok_begin ? (tok_end - tok_begin + BK - 1) / BK : 0;
 
   if (n_stage > 0) {
-    load_panel<DT, RELU>(a, tok_begin, tok_end, colA, limA, tid, ra);
-    if (!diag) load_panel<DT, RELU>(a, tok_begin, tok_end, colB, limB, tid, rb);
+    load_panel<DT, FAST>(a, tok_begin, tok_end, colA, limA, tid, ra);
+    if (!diag) load_panel<DT, FAST>(a, tok_begin, tok_end, colB, limB, tid, rb);
     store_panel<DT, RELU>(lds, tid, ra);
     if (!diag) store_panel<DT, RELU>(lds + 2 * PANEL, tid, rb);
   }
@@ -118,8 +123,8 @@ __global__ __launch_bounds__(256, 2) void cov_accum_kernel(CovArgs a) {
     const bool more = s + 1 < n_stage;
     if (more) {
       int64_t tk = tok_begin + (s + 1) * BK;
-      load_panel<DT, RELU>(a, tk, tok_end, colA, limA, tid, ra);
-      if (!diag) load_panel<DT, RELU>(a, tk, tok_end, colB, limB, tid, rb);
+      load_panel<DT, FAST>(a, tk, tok_end, colA, limA, tid, ra);
+      if (!diag) load_panel<DT, FAST>(a, tk, tok_end, colB, limB, tid, rb);
     }
     const double* As = lds + cur * PANEL;
     const double* Bs = diag ? As : lds + (2 + cur) * PANEL;
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void cov_accum_kernel(CovArgs a) {
   }
 }
 
-// sigma tile += sum over splits (fixed order) of the partial tiles.
+// sigma tile += sum over splits (fixed order) of the partial tiles.  grid = (tiles, 64): 256 elements per block.
 __global__ __launch_bounds__(256) void cov_reduce_kernel(CovArgs a) {
   const int b = blockIdx.x / a.ntri, t = blockIdx.x % a.ntri;
   int bi, bj;
@@ -170,14 +175,13 @@ __global__ __launch_bounds__(256) void cov_reduce_kernel(CovArgs a) {
   double* sg = a.sigma + (int64_t)b * a.sigma_bs;
   const int64_t tile_stride = (int64_t)gridDim.x * (TILE * TILE);
   const double* pt = a.partial + (int64_t)blockIdx.x * (TILE * TILE);
-  for (int e = threadIdx.x; e < TILE * TILE; e += 256) {
-    int r = e / TILE, c = e % TILE;
-    int64_t gr = (int64_t)bi * TILE + r, gc = (int64_t)bj * TILE + c;
-    if (gr >= a.n_feat || gc >= a.n_feat) continue;
-    double s = 0.;
-    for (int k = 0; k < a.ksplit; k++) s += pt[k * tile_stride + e];
-    sg[gr * a.ld_sigma + gc] += s;
-  }
+  const int e = blockIdx.y * 256 + threadIdx.x;
+  const int r = e / TILE, c = e % TILE;
+  const int64_t gr = (int64_t)bi * TILE + r, gc = (int64_t)bj * TILE + c;
+  if (gr >= a.n_feat || gc >= a.n_feat) return;
+  double s = 0.;
+  for (int k = 0; k < a.ksplit; k++) s += pt[k * tile_stride + e];
+  sg[gr * a.ld_sigma + gc] += s;
 }
 
 // lower -> scaled lower + mirrored upper, 32x32 tiles through LDS.
@@ -245,27 +249,46 @@ __global__ void bi_final_kernel(const double* partial, int n, double* out) {
 }
 
 // ---------------------------------------------------------------- host side
+// Split-K factor from a two-term cost model: MFMA time of the rounded-up number of workgroup rounds (2 workgroups
+// per CU) plus the HBM round trip of the fp64 partial tiles.  Deterministic in its arguments (the _ws_bytes twin
+// must agree), so the CU count is fixed to the MI355X's 256.
 static int cov_ksplit(int64_t n_tokens, int64_t n_feat, int64_t batch, int64_t* tokens_per_split) {
-  int64_t T = ceil_div(n_feat, TILE);
-  int64_t blocks = batch * T * (T + 1) / 2;
-  int64_t want = blocks >= 768 ? 1 : ceil_div(1024, blocks);
-  int64_t max_split = n_tokens / (8 * BK);  // at least 128 tokens per split
+  const int64_t T = ceil_div(n_feat, TILE);
+  const int64_t blocks = batch * T * (T + 1) / 2;
+  const double slots = 512.0;
+  const double us_per_token = 2.0 * TILE * TILE / (78.6e12 / slots) * 1e6;  // one workgroup, one token
+  const double us_per_tile_rt = 2.0 * TILE * TILE * 8 / 4.0e12 * 1e6;       // write + read one partial tile
+  int64_t max_split = n_tokens / (8 * BK);                                  // >= 128 tokens per split
   if (max_split < 1) max_split = 1;
-  if (want > max_split) want = max_split;
-  int64_t tps = align_up((size_t)ceil_div(n_tokens, want), BK);
-  if (tps < BK) tps = BK;
-  int ks = (int)ceil_div(n_tokens > 0 ? n_tokens : 1, tps);
+  if (max_split > 256) max_split = 256;
+  int64_t best = 1;
+  double best_cost = 0.;
+  for (int64_t ks = 1; ks <= max_split; ks++) {
+    const int64_t tps = (int64_t)align_up((size_t)ceil_div(n_tokens, ks), BK);
+    const int64_t real = ceil_div(n_tokens, tps);
+    if (real != ks) continue;
+    double rounds = (double)ceil_div(blocks * ks, (int64_t)slots);
+    double cost = rounds * (double)tps * us_per_token + (ks > 1 ? (double)(blocks * ks) * us_per_tile_rt + 3.0 : 0.);
+    if (ks == 1 || cost < best_cost * 0.95) {  // 5 % hysteresis towards fewer splits
+      best = ks;
+      best_cost = cost;
+    }
+  }
+  int64_t tps = (int64_t)align_up((size_t)ceil_div(n_tokens > 0 ? n_tokens : 1, best), BK);
   *tokens_per_split = tps;
-  return ks < 1 ? 1 : ks;
+  return (int)ceil_div(n_tokens > 0 ? n_tokens : 1, tps);
 }
 
 template <int DT>
-static void launch_cov(const CovArgs& a, int relu, hipStream_t st) {
+static void launch_cov(const CovArgs& a, int relu, bool fast, hipStream_t st) {
   dim3 grid(a.batch * a.ntri, a.ksplit);
-  if (relu)
-    hipLaunchKernelGGL((cov_accum_kernel<DT, true>), grid, dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL((cov_accum_kernel<DT, false>), grid, dim3(256), 0, st, a);
+  if (fast) {
+    if (relu) hipLaunchKernelGGL((cov_accum_kernel<DT, true, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((cov_accum_kernel<DT, false, true>), grid, dim3(256), 0, st, a);
+  } else {
+    if (relu) hipLaunchKernelGGL((cov_accum_kernel<DT, true, false>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((cov_accum_kernel<DT, false, false>), grid, dim3(256), 0, st, a);
+  }
 }
 
 }  // namespace mdg
@@ -284,6 +307,7 @@ extern "C" size_t mdg_cov_accum_ws_bytes(int64_t n_tokens, int64_t n_feat, int64
 extern "C" int mdg_cov_accum(const void* x, int dtype, int64_t n_tokens, int64_t n_feat, int64_t batch,
                              int64_t ld, int relu, double* sigma, int64_t ld_sigma, int64_t sigma_bs, void* ws,
                              size_t ws_bytes, void* stream) {
+  MDG_CLEAR();
   MDG_CHECK_ARG(n_tokens >= 0 && n_feat > 0 && batch > 0, "mdg_cov_accum: bad sizes (tokens=%lld feat=%lld batch=%lld)",
                 (long long)n_tokens, (long long)n_feat, (long long)batch);
   MDG_CHECK_ARG(dtype >= MDG_BF16 && dtype <= MDG_F64, "mdg_cov_accum: unknown dtype %d", dtype);
@@ -316,15 +340,16 @@ extern "C" int mdg_cov_accum(const void* x, int dtype, int64_t n_tokens, int64_t
     MDG_CHECK_ARG(ws && ws_bytes >= need, "mdg_cov_accum: workspace %zu < required %zu", ws_bytes, need);
   }
   MDG_CHECK_ARG((int64_t)a.batch * a.ntri < (1ll << 31) && a.ksplit < 65536, "mdg_cov_accum: grid too large");
+  const bool fast = a.vec_ok && (n_feat % TILE == 0);
   switch (dtype) {
-    case MDG_BF16: launch_cov<MDG_BF16>(a, relu, st); break;
-    case MDG_F16: launch_cov<MDG_F16>(a, relu, st); break;
-    case MDG_F32: launch_cov<MDG_F32>(a, relu, st); break;
-    default: launch_cov<MDG_F64>(a, relu, st); break;
+    case MDG_BF16: launch_cov<MDG_BF16>(a, relu, fast, st); break;
+    case MDG_F16: launch_cov<MDG_F16>(a, relu, fast, st); break;
+    case MDG_F32: launch_cov<MDG_F32>(a, relu, fast, st); break;
+    default: launch_cov<MDG_F64>(a, relu, fast, st); break;
   }
   MDG_LAUNCH_CHECK();
   if (a.ksplit > 1) {
-    hipLaunchKernelGGL(cov_reduce_kernel, dim3(a.batch * a.ntri), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(cov_reduce_kernel, dim3(a.batch * a.ntri, TILE * TILE / 256), dim3(256), 0, st, a);
     MDG_LAUNCH_CHECK();
   }
   return MDG_OK;
@@ -332,6 +357,7 @@ extern "C" int mdg_cov_accum(const void* x, int dtype, int64_t n_tokens, int64_t
 
 extern "C" int mdg_cov_finalize(double* sigma, int64_t n, int64_t batch, int64_t ld_sigma, int64_t sigma_bs,
                                 double scale, void* stream) {
+  MDG_CLEAR();
   MDG_CHECK_ARG(sigma && n > 0 && batch > 0 && ld_sigma >= n, "mdg_cov_finalize: bad arguments");
   int tiles = (int)ceil_div(n, 32);
   int64_t ntri = (int64_t)tiles * (tiles + 1) / 2;
@@ -347,6 +373,7 @@ extern "C" size_t mdg_bi_ws_bytes(int64_t n_tokens) { return (size_t)BI_MAX_BLOC
 
 extern "C" int mdg_bi_accum(const void* x_in, const void* x_out, int dtype, int64_t n_tokens, int64_t d, int64_t ld,
                             double* out, void* ws, size_t ws_bytes, void* stream) {
+  MDG_CLEAR();
   MDG_CHECK_ARG(x_in && x_out && out && n_tokens >= 0 && d > 0 && ld >= d, "mdg_bi_accum: bad arguments");
   MDG_CHECK_ARG(ws && ws_bytes >= mdg_bi_ws_bytes(n_tokens), "mdg_bi_accum: workspace too small");
   if (n_tokens == 0) return MDG_OK;

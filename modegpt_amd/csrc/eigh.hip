@@ -178,6 +178,7 @@ int check_flag(int* dflag, hipStream_t st, const char* what) {
 using namespace mdg;
 
 extern "C" int mdg_syevj_batched(double* A, int64_t n, int64_t batch, double* evals, double* evecs, void* stream) {
+  MDG_CLEAR();
   MDG_CHECK_ARG(A && evals && evecs, "mdg_syevj_batched: null pointer");
   hipStream_t st = (hipStream_t)stream;
   // standalone entry: a 4-byte stream-ordered scratch for the convergence flag (internal callers pass workspace)
@@ -195,6 +196,7 @@ extern "C" size_t mdg_sqrt_psd_small_ws_bytes(int64_t n, int64_t batch) {
 
 extern "C" int mdg_sqrt_psd_small(const double* M, int64_t n, int64_t batch, double ridge, int scaled, double* root,
                                   double* inv_root, double* evals_out, void* ws, size_t ws_bytes, void* stream) {
+  MDG_CLEAR();
   MDG_CHECK_ARG(M && root && n > 0 && batch > 0, "mdg_sqrt_psd_small: bad arguments");
   MDG_CHECK_ARG(ws && ws_bytes >= mdg_sqrt_psd_small_ws_bytes(n, batch), "mdg_sqrt_psd_small: workspace too small");
   hipStream_t st = (hipStream_t)stream;

@@ -184,6 +184,7 @@ extern "C" int mdg_gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const
                             int64_t sa_k, const int64_t* a_rows, const void* B, int b_dtype, int64_t sb_k,
                             int64_t sb_j, double beta, void* C, int c_dtype, int64_t ldc, int64_t batch,
                             int64_t a_bs, int64_t b_bs, int64_t c_bs, int flags, void* stream) {
+  MDG_CLEAR();
   return mdg::gemm_f64(M, N, K, alpha, A, a_dtype, sa_i, sa_k, a_rows, B, b_dtype, sb_k, sb_j, beta, C, c_dtype, ldc,
                        batch, a_bs, b_bs, c_bs, flags, (hipStream_t)stream);
 }

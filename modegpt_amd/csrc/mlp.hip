@@ -24,6 +24,7 @@ extern "C" size_t mdg_nystrom_down_ws_bytes(int64_t n, int64_t r, int64_t d) {
 extern "C" int mdg_nystrom_down(const double* C, int64_t n, int64_t ldc, const int64_t* idx, int64_t r, const void* Wd,
                                 int64_t d, int64_t ld_wd, double eps, void* down_out, int64_t ld_out,
                                 double* down_f64, void* ws, size_t ws_bytes, void* stream) {
+  MDG_CLEAR();
   MDG_CHECK_ARG(C && idx && Wd && down_out, "mdg_nystrom_down: null pointer");
   MDG_CHECK_ARG(n > 0 && r > 0 && r <= n && d > 0 && ldc >= n && ld_wd >= n && ld_out >= r,
                 "mdg_nystrom_down: bad sizes (n=%lld r=%lld d=%lld)", (long long)n, (long long)r, (long long)d);

@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const double* in, i
 using namespace mdg;
 
 extern "C" int mdg_select_smallest_sorted(const double* scores, int64_t n, int64_t k, int64_t* idx, void* stream) {
+  MDG_CLEAR();
   MDG_CHECK_ARG(scores && idx && n > 0 && k >= 0 && k <= n, "mdg_select_smallest_sorted: bad arguments (n=%lld k=%lld)",
                 (long long)n, (long long)k);
   if (k == 0) return MDG_OK;
@@ -164,6 +165,7 @@ extern "C" int mdg_select_smallest_sorted(const double* scores, int64_t n, int64
 
 extern "C" int mdg_gather_rows_16(const void* src, int64_t ld_src, const int64_t* rows, int64_t n_rows, int64_t n_cols,
                                   void* out, int64_t ld_out, void* stream) {
+  MDG_CLEAR();
   MDG_CHECK_ARG(n_rows >= 0 && n_cols > 0 && ld_src >= n_cols && ld_out >= n_cols, "mdg_gather_rows_16: bad sizes");
   if (n_rows == 0) return MDG_OK;
   MDG_CHECK_ARG(src && rows && out, "mdg_gather_rows_16: null pointer");
@@ -179,6 +181,7 @@ extern "C" int mdg_gather_rows_16(const void* src, int64_t ld_src, const int64_t
 extern "C" int mdg_qk_select(const double* cov_q, const double* cov_k, int n_heads, int n_kv, int hd, double ridge_q,
                              double ridge_k, int rank, int mode, int64_t* mask, int64_t* q_rows, int64_t* k_rows,
                              void* stream) {
+  MDG_CLEAR();
   MDG_CHECK_ARG(cov_q && cov_k && mask && q_rows && k_rows, "mdg_qk_select: null pointer");
   MDG_CHECK_ARG(n_kv > 0 && n_heads >= n_kv && n_heads % n_kv == 0, "mdg_qk_select: n_heads %d not a multiple of n_kv %d",
                 n_heads, n_kv);
@@ -199,6 +202,7 @@ extern "C" int mdg_qk_select(const double* cov_q, const double* cov_k, int n_hea
 
 extern "C" int mdg_cast_transpose_f64_bf16(const double* in, int64_t rows, int64_t cols, int64_t ld_in, void* out,
                                            int64_t ld_out, void* stream) {
+  MDG_CLEAR();
   MDG_CHECK_ARG(in && out && rows > 0 && cols > 0 && ld_in >= cols && ld_out >= rows, "mdg_cast_transpose: bad arguments");
   dim3 grid((unsigned)ceil_div(cols, 32), (unsigned)ceil_div(rows, 32));
   MDG_CHECK_ARG(grid.y < 65536, "mdg_cast_transpose: too many rows");

@@ -119,6 +119,7 @@ extern "C" int mdg_vo_compress(const double* cov_x, int64_t d, int64_t ldc, cons
                                int64_t ld_wo, int n_heads, int n_kv, int hd, int rank, double ridge, void* v_out,
                                int64_t ld_v, void* o_out, int64_t ld_o, double* v_f64, double* o_f64, void* ws,
                                size_t ws_bytes, void* stream) {
+  MDG_CLEAR();
   MDG_CHECK_ARG(cov_x && Wv && Wo && v_out && o_out, "mdg_vo_compress: null pointer");
   MDG_CHECK_ARG(n_kv > 0 && n_heads % n_kv == 0 && hd >= 2 && hd <= 128 && hd % 2 == 0,
                 "mdg_vo_compress: unsupported head layout (n_heads=%d n_kv=%d hd=%d)", n_heads, n_kv, hd);

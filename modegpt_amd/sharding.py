@@ -1,0 +1,156 @@
+"""Layer sharding across the GPUs of one node (new: the reference is single-process).
+
+Given the sigma matrices, every layer's MLP / QK / VO compression is independent, so rank g of G owns a
+contiguous block of ceil(L/G) layers and no data-path collective is needed until the end, when ONE all-gather
+(RCCL over xGMI under backend "nccl", gloo on CPU in tests) of a fixed-stride packed buffer reassembles the
+compressed checkpoint on every rank.
+
+Packed record per layer (all 2-byte words, bf16 bit patterns or int16 quarters of int64s):
+    header  : 16 x int64  = [layer_idx, n_tensors, (rows, cols) x 7 tensors]   (up, gate, down, q, k, v, o)
+    mask hdr:  2 x int64  = [n_kv, rank]  followed by the int64 rotary mask
+    payload : the tensors' bf16 words back to back
+Records are padded to the largest record of the call (per-layer ranks differ with the keep ratios).
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+TENSOR_ORDER = ("up", "gate", "down", "q_proj", "k_proj", "v_proj", "o_proj")
+_HDR_I64 = 16
+
+
+def init_from_env() -> Tuple[int, int]:
+    """(rank, world).  Initialises torch.distributed when launched by torchrun; backend nccl (= RCCL) on GPU."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return 0, 1
+    if not dist.is_initialized():
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend=backend)
+    return dist.get_rank(), dist.get_world_size()
+
+
+def finalize() -> None:
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def my_layers(layers: Sequence[int], rank: int, world: int) -> List[int]:
+    """Contiguous block partition: rank g gets layers[g*ceil(L/G) : (g+1)*ceil(L/G)]."""
+    layers = list(layers)
+    if world == 1:
+        return layers
+    per = -(-len(layers) // world)
+    return layers[rank * per:(rank + 1) * per]
+
+
+def owner_of(pos: int, n: int, world: int) -> int:
+    per = -(-n // world)
+    return pos // per
+
+
+# ------------------------------------------------------------------ pack / unpack
+def pack_layer(layer_idx: int, tensors: Dict[str, Optional[torch.Tensor]], mask: Optional[torch.Tensor]) -> torch.Tensor:
+    """One layer's compressed tensors (+ rotary mask) -> flat int16 record on the tensors' device."""
+    dev = next(t.device for t in tensors.values() if t is not None)
+    hdr = torch.zeros(_HDR_I64, dtype=torch.int64)
+    hdr[0] = layer_idx
+    parts = []
+    n = 0
+    for slot, name in enumerate(TENSOR_ORDER):
+        t = tensors.get(name)
+        if t is None:
+            continue
+        if t.dtype != torch.bfloat16 or t.dim() != 2:
+            raise ValueError(f"{name}: expected a 2-D bf16 tensor")
+        hdr[2 + 2 * slot], hdr[3 + 2 * slot] = t.shape[0], t.shape[1]
+        parts.append(t.contiguous().view(torch.int16).reshape(-1))
+        n += 1
+    hdr[1] = n
+    if mask is None:
+        mh = torch.zeros(2, dtype=torch.int64)
+        mparts = []
+    else:
+        mh = torch.tensor(list(mask.shape), dtype=torch.int64)
+        mparts = [mask.to(torch.int64).contiguous().view(torch.int16).reshape(-1)]
+    head = torch.cat([hdr, mh]).view(torch.int16).to(dev)
+    return torch.cat([head] + [p.to(dev) for p in mparts] + parts)
+
+
+def unpack_layer(rec: torch.Tensor) -> Tuple[int, Dict[str, torch.Tensor], Optional[torch.Tensor]]:
+    words_hdr = (_HDR_I64 + 2) * 4
+    head = rec[:words_hdr].cpu().view(torch.int64)
+    layer_idx, off = int(head[0]), words_hdr
+    n_kv, r = int(head[_HDR_I64]), int(head[_HDR_I64 + 1])
+    mask = None
+    if n_kv * r > 0:
+        mask = rec[off:off + n_kv * r * 4].contiguous().view(torch.int64).reshape(n_kv, r)
+        off += n_kv * r * 4
+    out = {}
+    for slot, name in enumerate(TENSOR_ORDER):
+        rows, cols = int(head[2 + 2 * slot]), int(head[3 + 2 * slot])
+        if rows * cols == 0:
+            continue
+        out[name] = rec[off:off + rows * cols].contiguous().view(torch.bfloat16).reshape(rows, cols)
+        off += rows * cols
+    return layer_idx, out, mask
+
+
+def allgather_records(records: List[torch.Tensor], per_rank: int, world: int) -> List[torch.Tensor]:
+    """The single data-path collective: every rank contributes `per_rank` records padded to a common stride."""
+    dev = records[0].device if records else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    longest = torch.tensor([max([r.numel() for r in records] + [0])], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(longest, op=dist.ReduceOp.MAX)  # 8-byte size agreement, not a data-path exchange
+    stride = (int(longest.item()) + 3) // 4 * 4          # rows stay 8-byte aligned for the int64 header views
+    PRE = 4                                                 # words 0..3: slot-in-use flag (+ alignment pad)
+    send = torch.zeros(per_rank, PRE + stride, dtype=torch.int16, device=dev)
+    for i, r in enumerate(records):
+        send[i, 0] = 1
+        send[i, PRE:PRE + r.numel()] = r
+    if world == 1:
+        return [send[i, PRE:] for i in range(per_rank) if send[i, 0] == 1]
+    recv = torch.empty(world * per_rank, PRE + stride, dtype=torch.int16, device=dev)
+    # byte views: every backend moves uint8 (gloo has no int16)
+    dist.all_gather_into_tensor(recv.view(torch.uint8), send.view(torch.uint8))
+    used = recv[:, 0].cpu()
+    return [recv[i, PRE:] for i in range(world * per_rank) if used[i] == 1]
+
+
+def gather_layer_artifacts(adapter, chunk: Sequence[int], mine: Sequence[int], rotary_masks, rank: int, world: int):
+    """After this rank compressed `mine`: all-gather everybody's layers of `chunk`, write the artefacts this rank
+    did not produce into temp_storage_dir (so convert_model finds layer_<i>_{mlp,qk,vo} for every i), and return
+    the chunk's rotary masks in layer order."""
+    rms = list(rotary_masks or [])
+    if world == 1:
+        return rms
+    d = os.path.expandvars(adapter.config.temp_storage_dir)
+    dev = "cuda" if torch.cuda.is_available() else "cpu"
+    records = []
+    for pos, layer in enumerate(mine):
+        tensors = {}
+        for suffix in ("mlp", "qk", "vo"):
+            p = os.path.join(d, f"layer_{layer}_{suffix}")
+            if os.path.exists(p):
+                tensors.update(torch.load(p, map_location=dev))
+        records.append(pack_layer(layer, tensors, rms[pos] if pos < len(rms) else None))
+    per = -(-len(chunk) // world)
+    masks = {}
+    for rec in allgather_records(records, per, world):
+        layer, tensors, mask = unpack_layer(rec)
+        masks[layer] = mask
+        if layer in mine:
+            continue
+        groups = {"mlp": ("up", "gate", "down"), "qk": ("q_proj", "k_proj"), "vo": ("v_proj", "o_proj")}
+        for suffix, names in groups.items():
+            w = {k: tensors[k].clone() for k in names if k in tensors}
+            if w:
+                adapter.save_layer(output_dir=adapter.config.temp_storage_dir, suffix=suffix, weights=w, layer_idx=layer)
+    return [masks[l] for l in chunk if masks.get(l) is not None]

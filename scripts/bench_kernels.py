@@ -1,0 +1,62 @@
+"""Per-kernel timing at Llama-3-8B shapes (dev tool; the judged numbers come from bench.py)."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from modegpt_amd import ops, _lib
+
+dev = torch.device("cuda:0")
+F64 = torch.float64
+
+def timeit(fn, n=3, warm=1):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e-3
+
+print("device", ops.device_info(0))
+print("fp64 MFMA probe TFLOP/s:", ops.probe_mfma_f64(8192))
+which = sys.argv[1:] or ["cov", "mlp", "vo", "qk"]
+T, d_ff, d, nh, nkv, hd = 32768, 14336, 4096, 32, 8, 128
+g = torch.Generator(device=dev).manual_seed(0)
+def acts(t, f):
+    c = torch.exp(torch.empty(f, device=dev).uniform_(-3.0, 0.7, generator=g))
+    return (torch.randn(t, f, device=dev, generator=g) * c).to(torch.bfloat16)
+if "cov" in which:
+    H = acts(T, d_ff); S = torch.zeros(d_ff, d_ff, dtype=F64, device=dev)
+    t = timeit(lambda: ops.cov_accum(S, H), n=2)
+    fl = T * d_ff * (d_ff + 1)
+    print(f"cov mlp  {T}x{d_ff}: {t*1e3:.1f} ms  {fl/t/1e12:.1f} TF (syrk count)")
+    X = acts(T, d); Sx = torch.zeros(d, d, dtype=F64, device=dev)
+    t = timeit(lambda: ops.cov_accum(Sx, X), n=3)
+    print(f"cov x    {T}x{d}: {t*1e3:.1f} ms  {T*d*(d+1)/t/1e12:.1f} TF")
+    Q = acts(T, nh * hd); Sq = torch.zeros(nh, hd, hd, dtype=F64, device=dev)
+    t = timeit(lambda: ops.cov_accum(Sq, Q, n_heads=nh), n=3)
+    print(f"cov q    {T}x{nh}x{hd}: {t*1e3:.1f} ms  {T*nh*hd*(hd+1)/t/1e12:.1f} TF")
+    K = acts(T, nkv * hd); Sk = torch.zeros(nkv, hd, hd, dtype=F64, device=dev)
+    t = timeit(lambda: ops.cov_accum(Sk, K, n_heads=nkv), n=3)
+    print(f"cov k    {T}x{nkv}x{hd}: {t*1e3:.1f} ms  {T*nkv*hd*(hd+1)/t/1e12:.1f} TF")
+    t = timeit(lambda: ops.cov_finalize(S, 1.0 / T), n=2)
+    print(f"finalize {d_ff}: {t*1e3:.2f} ms")
+    if "mlp" in which:
+        ops.cov_finalize(Sx, 1.0 / T); ops.cov_finalize(Sq, 1.0 / T); ops.cov_finalize(Sk, 1.0 / T)
+        lam = float(torch.tensor(1e-4, dtype=torch.float32).double())
+        t0 = time.time(); sc = ops.ridge_scores(S, lam); torch.cuda.synchronize(); print(f"ridge_scores first {time.time()-t0:.3f}s")
+        t = timeit(lambda: ops.ridge_scores(S, lam), n=2, warm=0); print(f"ridge_scores {d_ff}: {t*1e3:.1f} ms")
+        r = int(d_ff * 0.7)
+        t = timeit(lambda: ops.select_smallest_sorted(sc, r), n=3); print(f"select: {t*1e3:.2f} ms")
+        idx = ops.select_smallest_sorted(sc, r)
+        Wd = (torch.randn(d, d_ff, device=dev, generator=g) * 0.02).to(torch.bfloat16)
+        Wu = (torch.randn(d_ff, d, device=dev, generator=g) * 0.02).to(torch.bfloat16)
+        t = timeit(lambda: ops.nystrom_down(S, idx, Wd), n=2); print(f"nystrom_down r={r}: {t*1e3:.1f} ms")
+        t = timeit(lambda: ops.gather_rows(Wu, idx), n=3); print(f"gather up: {t*1e3:.2f} ms")
+    if "vo" in which:
+        Wv = (torch.randn(nkv * hd, d, device=dev, generator=g) * 0.02).to(torch.bfloat16)
+        Wo = (torch.randn(d, nh * hd, device=dev, generator=g) * 0.02).to(torch.bfloat16)
+        t = timeit(lambda: ops.vo_compress(Sx, Wv, Wo, nh, nkv, hd, 88, 1e-5), n=2); print(f"vo_compress gqa: {t*1e3:.1f} ms")
+        Wv2 = (torch.randn(nh * hd, d, device=dev, generator=g) * 0.02).to(torch.bfloat16)
+        t = timeit(lambda: ops.vo_compress(Sx, Wv2, Wo, nh, nh, hd, 88, 1e-5), n=2); print(f"vo_compress mha: {t*1e3:.1f} ms")
+    if "qk" in which:
+        t = timeit(lambda: ops.qk_select(Sq, Sk, 88, _lib.MDG_QK_ROPE_GROUPED, 1e-4, 1e-2), n=3); print(f"qk_select: {t*1e3:.3f} ms")

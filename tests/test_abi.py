@@ -1,0 +1,44 @@
+"""CPU: the C-ABI library loads without a GPU and exports exactly the symbols include/modegpt_hip.h declares."""
+import os
+import re
+import subprocess
+
+from modegpt_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "modegpt_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return set(re.findall(r"\b(mdg_[a-z0-9_]+)\s*\(", src))
+
+
+def test_header_matches_binding_table():
+    assert header_symbols() == set(_lib.SIGNATURES)
+
+
+def test_library_loads_and_exports_everything():
+    lib = _lib.load()  # no GPU needed to dlopen and bind
+    assert lib.mdg_abi_version() == 1
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (mdg_[a-z0-9_]+)", out))
+    assert header_symbols() <= exported
+    assert exported == header_symbols(), f"undeclared exports: {exported - header_symbols()}"
+
+
+def test_pure_size_queries_need_no_gpu():
+    lib = _lib.load()
+    assert lib.mdg_cov_accum_ws_bytes(32768, 14336, 1) == 0          # enough tiles: no split-K
+    assert lib.mdg_cov_accum_ws_bytes(32768, 128, 8) > 0             # head Grams split over tokens
+    n = 14336
+    assert lib.mdg_ridge_scores_ws_bytes(n) >= (2 * n * n + n * n // 4) * 8
+    assert lib.mdg_potrf_inv_diag_elems(300) == 3 * 128 * 128 + 16
+
+
+def test_bad_arguments_return_status_not_abort():
+    lib = _lib.load()
+    rc = lib.mdg_cov_accum(None, 99, 10, 10, 1, 10, 0, None, 10, 100, None, 0, None)
+    assert rc == _lib.MDG_ERR_BAD_ARG and b"dtype" in lib.mdg_last_error()
+    rc = lib.mdg_qk_select(None, None, 4, 2, 16, 0.0, 0.0, 8, 0, None, None, None, None)
+    assert rc == _lib.MDG_ERR_BAD_ARG

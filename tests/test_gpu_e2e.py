@@ -1,0 +1,290 @@
+"""GPU: the drop-in functions end to end (load_calibs hooks -> compress_nystrom / compress_qk / compress_vo ->
+convert_model), against the golden vectors, against the oracle on a random-init HF model, and at BASELINE.json's
+full sizes through size-independent properties."""
+import os
+
+import pytest
+import torch
+
+from oracle import modegpt_oracle as O
+from tests.golden_util import CASES, Case, vo_products
+
+pytestmark = pytest.mark.gpu
+F64 = torch.float64
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-300)).item()
+
+
+def bf16_mismatch(a, b):
+    return (a.cpu().view(torch.int16) != b.cpu().view(torch.int16)).float().mean().item()
+
+
+# ---------------------------------------------------------------- golden cases through the drop-in functions
+@pytest.mark.parametrize("name", CASES)
+def test_dropin_functions_on_golden(dev, name):
+    from modegpt_amd import engine
+    from modegpt_amd.adapters.CompressionConfig import CompressionConfig
+    c = Case(name)
+    shape = dict(arch=c.arch, n_layers=1, d=c.d, d_ff=c.d_ff, n_heads=c.n_h, n_kv_heads=c.n_kv, head_dim=c.hd)
+    w = {k: v.to(dev) for k, v in c.W.items()}
+    if c.arch == "opt":
+        w.pop("gate")
+    ad = engine.TensorAdapter(shape, {0: w}, CompressionConfig(**c.ridges))
+    covs = engine.new_covs(shape, dev)
+    half = c.tokens // 2
+    for sl in (slice(0, half), slice(half, c.tokens)):
+        engine.accumulate(covs, {k: v[sl].to(dev) for k, v in c.act.items()}, shape)
+    engine.finalize(covs, c.n_texts)
+    for k in covs:
+        assert rel(covs[k], c.f64["sigma_" + k]) < 1e-13
+    out, mask = engine.compress_layer(ad, 0, covs, c.keep)
+    assert torch.equal(out["up"].cpu(), c.bf["mlp_up"])                      # selection bit-identical
+    if c.arch != "opt":
+        assert torch.equal(out["gate"].cpu(), c.bf["mlp_gate"])
+        assert torch.equal(mask.cpu(), c.qk_mask)
+    assert bf16_mismatch(out["down"], c.bf["mlp_down"]) < 1e-3 and rel(out["down"], c.bf["mlp_down"]) < 2 ** -7
+    assert torch.equal(out["q_proj"].cpu(), c.bf["qk_q"]) and torch.equal(out["k_proj"].cpu(), c.bf["qk_k"])
+    r = c.vo_rank
+    assert out["v_proj"].shape == (c.n_kv * r, c.d) and out["o_proj"].shape == (c.d, c.n_h * r)
+    P = vo_products(out["v_proj"].cpu(), out["o_proj"].cpu(), c.n_h, c.n_kv, r)
+    Pr = vo_products(c.bf["vo_v"], c.bf["vo_o"], c.n_h, c.n_kv, r)
+    assert rel(P, Pr) < 3e-2  # products of bf16-rounded factors: two 2^-9 roundings on each side
+
+
+# ---------------------------------------------------------------- random-init HF model through load_calibs
+def _tiny_model(kind, dev):
+    transformers = pytest.importorskip("transformers")
+    torch.manual_seed(0)
+    if kind == "opt":
+        cfg = transformers.OPTConfig(hidden_size=128, ffn_dim=320, num_hidden_layers=2, num_attention_heads=4,
+                                     vocab_size=211, max_position_embeddings=64, word_embed_proj_dim=128)
+        m = transformers.OPTForCausalLM(cfg)
+    elif kind == "qwen3":
+        cfg = transformers.Qwen3Config(hidden_size=128, intermediate_size=320, num_hidden_layers=2, num_attention_heads=4,
+                                       num_key_value_heads=2, head_dim=32, vocab_size=211, max_position_embeddings=64)
+        m = transformers.Qwen3ForCausalLM(cfg)
+    else:
+        kv = 2 if kind == "llama_gqa" else 4
+        cfg = transformers.LlamaConfig(hidden_size=128, intermediate_size=320, num_hidden_layers=2, num_attention_heads=4,
+                                       num_key_value_heads=kv, head_dim=32, vocab_size=211, max_position_embeddings=64)
+        m = transformers.LlamaForCausalLM(cfg)
+    return m.to(dev).to(torch.bfloat16).eval()
+
+
+def _capture(adapter, batches):
+    """Independent capture of the hook inputs with plain torch hooks -> oracle sigma on the CPU."""
+    arch = adapter.arch
+    blocks = adapter.get_transformer_blocks()
+    store = {i: {"h": [], "x": [], "q": [], "k": []} for i in range(adapter.n_layers)}
+    hs = []
+    for i, b in enumerate(blocks):
+        if arch == "opt":
+            hs.append(b.fc1.register_forward_hook(lambda m, a, o, i=i: store[i]["h"].append(o.detach().cpu())))
+            hs.append(b.self_attn_layer_norm.register_forward_hook(lambda m, a, o, i=i: store[i]["x"].append(o.detach().cpu())))
+        else:
+            hs.append(b.mlp.down_proj.register_forward_pre_hook(lambda m, a, i=i: store[i]["h"].append(a[0].detach().cpu())))
+            hs.append(b.input_layernorm.register_forward_hook(lambda m, a, o, i=i: store[i]["x"].append(o.detach().cpu())))
+        hs.append(b.self_attn.q_proj.register_forward_hook(lambda m, a, o, i=i: store[i]["q"].append(o.detach().cpu())))
+        hs.append(b.self_attn.k_proj.register_forward_hook(lambda m, a, o, i=i: store[i]["k"].append(o.detach().cpu())))
+    bi = [0.0] * adapter.n_layers
+    n_texts = 0
+    with torch.no_grad():
+        for batch in batches:
+            n_texts += len(batch)
+            out = adapter.model(batch, output_hidden_states=True)
+            for l in range(adapter.n_layers):
+                bi[l] += O.bi_score_batch(out.hidden_states[l].cpu(), out.hidden_states[l + 1].cpu())
+    for h in hs:
+        h.remove()
+    return store, [b / n_texts for b in bi], n_texts
+
+
+@pytest.mark.parametrize("kind", ["llama_gqa", "llama_mha", "qwen3", "opt"])
+def test_model_end_to_end(dev, kind, tmp_path):
+    from modegpt_amd.adapters.CompressionConfig import CompressionConfig
+    from modegpt_amd.adapters.model_adapter import ModelAdapter
+    from modegpt_amd.calibration import load_calibs
+    from modegpt_amd.compression.compress_mlp import compress_nystrom
+    from modegpt_amd.compression.compress_qk import compress_qk
+    from modegpt_amd.compression.compress_vo import compress_vo
+    from modegpt_amd.compression_utils import allocate_global_sparsity
+
+    model = _tiny_model(kind, dev)
+    ad = ModelAdapter.from_model(model, None)
+    ad.config = CompressionConfig(temp_storage_dir=str(tmp_path / "layers"), nystrom_ridge=1e-4, ridge_qk=1e-2, ridge_vo=1e-5,
+                                  dataset="synthetic", calib_size=6, calibs_batch_size=4, compression_ratio=0.3,
+                                  order="mlp,qk,vo")
+    weights0 = {i: {"up": ad.get_mlp_tensors(i).up_proj.detach().cpu().clone(),
+                    "gate": None if ad.get_mlp_tensors(i).gate_proj is None else ad.get_mlp_tensors(i).gate_proj.detach().cpu().clone(),
+                    "down": ad.get_mlp_tensors(i).down_proj.detach().cpu().clone(),
+                    "q": ad.get_qk_tensors(i).query_proj.detach().cpu().clone(),
+                    "k": ad.get_qk_tensors(i).key_proj.detach().cpu().clone(),
+                    "v": ad.get_vo_tensors(i).v_proj.detach().cpu().clone(),
+                    "o": ad.get_vo_tensors(i).o_proj.detach().cpu().clone()} for i in range(ad.n_layers)}
+    d_int0 = ad.get_n_inner()
+    cov_mlp, cov_q, cov_k, cov_x, bi = load_calibs(ad, n_samples=6, batch_size=4, dataset="synthetic", target_layers=[])
+    store, bi_ref, n_texts = _capture(ad, ad.calibs)
+    assert n_texts == 6
+    for l in range(ad.n_layers):
+        assert abs(bi[l] - bi_ref[l]) <= 1e-9 * max(1.0, abs(bi_ref[l]))
+    shape = dict(arch=ad.arch, n_heads=ad.n_heads, n_kv_heads=ad.n_kv_heads, head_dim=ad.head_dim)
+    ref_cov = {}
+    for l in range(ad.n_layers):
+        s = {"mlp": torch.zeros(ad.get_n_inner(), ad.get_n_inner(), dtype=F64), "x": torch.zeros(ad.d_model, ad.d_model, dtype=F64),
+             "q": torch.zeros(ad.n_heads, ad.head_dim, ad.head_dim, dtype=F64),
+             "k": torch.zeros(ad.n_kv_heads, ad.head_dim, ad.head_dim, dtype=F64)}
+        for t in store[l]["h"]:
+            (O.cov_accum_tokens_relu if ad.arch == "opt" else O.cov_accum_tokens)(s["mlp"], t)
+        for t in store[l]["x"]:
+            O.cov_accum_tokens(s["x"], t)
+        for t in store[l]["q"]:
+            O.cov_accum_heads(s["q"], t, ad.n_heads, ad.head_dim)
+        for t in store[l]["k"]:
+            O.cov_accum_heads(s["k"], t, ad.n_kv_heads, ad.head_dim)
+        for v in s.values():
+            O.cov_finalize(v, n_texts)
+        ref_cov[l] = s
+        assert rel(cov_mlp[l], s["mlp"]) < 1e-12 and rel(cov_x[l], s["x"]) < 1e-12
+        assert rel(cov_q[l], s["q"]) < 1e-12 and rel(cov_k[l], s["k"]) < 1e-12
+
+    keep = allocate_global_sparsity(bi, 0.3, smoothing=0.15, max_sparsity=0.8, adapter=ad)
+    assert keep == O.allocate_global_sparsity(bi, 0.3, smoothing=0.15, max_sparsity=0.8)
+    layers = list(range(ad.n_layers))
+    compress_nystrom(ad, cov_mlp, keep, layers)
+    masks = compress_qk(ad, (cov_q, cov_k), keep, target_layers=layers)
+    compress_vo(ad, cov_x, keep, target_layers=layers)
+    ridges = dict(nystrom_ridge=1e-4, ridge_qk=1e-2, ridge_vo=1e-5)
+    for l in layers:
+        art = {}
+        for suffix in ("mlp", "qk", "vo"):
+            art.update(torch.load(os.path.join(ad.config.temp_storage_dir, f"layer_{l}_{suffix}"), map_location="cpu"))
+        ref = O.compress_layer_all(weights0[l], ref_cov[l], shape, keep[l], ridges)
+        assert torch.equal(art["up"], ref["mlp"]["up"])
+        assert bf16_mismatch(art["down"], ref["mlp"]["down"]) < 2e-3
+        assert torch.equal(art["q_proj"], ref["qk"]["q_proj"]) and torch.equal(art["k_proj"], ref["qk"]["k_proj"])
+        if ad.arch != "opt":
+            assert torch.equal(masks[l].cpu(), ref["mask"])
+        r = art["v_proj"].shape[0] // ad.n_kv_heads
+        P = vo_products(art["v_proj"], art["o_proj"], ad.n_heads, ad.n_kv_heads, r)
+        Pr = vo_products(ref["vo"]["v_proj"], ref["vo"]["o_proj"], ad.n_heads, ad.n_kv_heads, r)
+        assert rel(P, Pr) < 3e-2
+    ad.convert_model(saved_layers_dir=ad.config.temp_storage_dir)
+    ad.patch_config()
+    cfg = model.config
+    mlp0 = ad.get_mlp_tensors(0)
+    assert mlp0.up_proj.shape[0] == int(d_int0 * keep[0]) == mlp0.down_proj.shape[1]
+    if ad.arch != "opt":
+        assert cfg.gate_ranks[0] == mlp0.up_proj.shape[0] and len(cfg.q_ranks) == ad.n_layers
+        assert cfg.q_ranks[0] == ad.get_qk_tensors(0).query_proj.shape[0] and cfg.ffn_dim == -1
+        assert "Rebuild" in cfg.auto_map["AutoModelForCausalLM"]
+
+
+# ---------------------------------------------------------------- BASELINE sizes: size-independent properties
+def _acts(dev, tokens, feat, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    c = torch.exp(torch.empty(feat, device=dev).uniform_(-3.0, 0.7, generator=g))
+    return (torch.randn(tokens, feat, device=dev, generator=g) * c).to(torch.bfloat16)
+
+
+def test_full_size_cov_properties(dev):
+    """d_ff = 14336, 16384 tokens: linearity in the token dimension, symmetry, trace checksum, PSD."""
+    from modegpt_amd import ops
+    n, t = 14336, 16384
+    X = _acts(dev, t, n, 1)
+    A = torch.zeros(n, n, dtype=F64, device=dev)
+    ops.cov_accum(A, X)
+    B = torch.zeros(n, n, dtype=F64, device=dev)
+    ops.cov_accum(B, X[: t // 2])
+    ops.cov_accum(B, X[t // 2:])
+    ops.cov_finalize(A, 1.0)
+    ops.cov_finalize(B, 1.0)
+    assert rel(A, B) < 1e-14                                   # sum over batches == one batch
+    assert torch.equal(A, A.T)
+    tr = (X.double() ** 2).sum().item()
+    assert abs(torch.diagonal(A).sum().item() - tr) / tr < 1e-13  # trace = sum of squared entries
+    cols = torch.tensor([0, 1, 127, 128, 5000, 14335], device=dev)
+    sub = X[:, cols].double()
+    assert rel(A[cols][:, cols], sub.T @ sub) < 1e-13          # spot block against a torch fp64 product
+    del A, B, X
+
+
+def test_full_size_mlp_properties(dev):
+    """Llama-3-8B MLP sizes: scores satisfy the defining identity on sampled columns, selection is sorted/unique,
+    and the Nystrom solve leaves a tiny residual."""
+    from modegpt_amd import ops
+    n, d, t, keep = 14336, 4096, 32768, 0.7
+    X = _acts(dev, t, n, 2)
+    Cm = torch.zeros(n, n, dtype=F64, device=dev)
+    ops.cov_accum(Cm, X)
+    ops.cov_finalize(Cm, 1.0 / t)
+    del X
+    lam = float(torch.tensor(1e-4, dtype=torch.float32).double())
+    scores = ops.ridge_scores(Cm, lam)
+    # defining identity: (C + lam I) z = e_j  =>  z_j = score_j ; check a few columns with the library's own solver
+    A = Cm.clone()
+    A.diagonal().add_(lam)
+    inv = ops.potrf_lower(A)
+    cols = [0, 777, 8191, 14335]
+    E = torch.zeros(n, len(cols), dtype=F64, device=dev)
+    for k, j in enumerate(cols):
+        E[j, k] = 1.0
+    Z = E.clone()
+    ops.potrs_lower(A, inv, Z)
+    for k, j in enumerate(cols):
+        assert abs(Z[j, k].item() - scores[j].item()) / scores[j].item() < 1e-9
+    A2 = Cm.clone()
+    A2.diagonal().add_(lam)
+    assert rel(A2 @ Z, E) < 1e-8                               # and the solve itself is a solve
+    r = int(n * keep)
+    idx = ops.select_smallest_sorted(scores, r)
+    assert idx.numel() == r and bool((idx[1:] > idx[:-1]).all())
+    thr = scores[idx].max()
+    notsel = torch.ones(n, dtype=torch.bool, device=dev)
+    notsel[idx] = False
+    assert bool((scores[notsel] >= thr).all())
+    g = torch.Generator(device=dev).manual_seed(3)
+    Wd = (torch.randn(d, n, device=dev, generator=g) * 0.02).to(torch.bfloat16)
+    down, down64 = ops.nystrom_down(Cm, idx, Wd, want_f64=True)
+    Ckk = Cm[idx][:, idx]
+    Ckk.diagonal().add_(1e-6)
+    rhs = Cm[idx] @ Wd.double().T
+    assert rel(Ckk @ down64, rhs) < 1e-9                       # (C_kk + eps I) W_d' = C_k: W_d^T
+    assert torch.equal(down.cpu(), down64.T.cpu().to(torch.bfloat16))
+
+
+def test_full_size_vo_properties(dev):
+    """d = 4096, 8 kv / 32 q heads of 128: W_v' C W_v'^T = I_r and W_o' W_v' = W_o,h P W_v with P a C-orthogonal
+    projector of rank r (the invariants of compress_vo.py:112-159)."""
+    from modegpt_amd import ops
+    d, nh, nkv, hd, r, rho = 4096, 32, 8, 128, 88, 1e-5
+    X = _acts(dev, 16384, d, 4)
+    Cx = torch.zeros(d, d, dtype=F64, device=dev)
+    ops.cov_accum(Cx, X)
+    ops.cov_finalize(Cx, 1.0 / 16384)
+    g = torch.Generator(device=dev).manual_seed(5)
+    Wv = (torch.randn(nkv * hd, d, device=dev, generator=g) * 0.02).to(torch.bfloat16)
+    Wo = (torch.randn(d, nh * hd, device=dev, generator=g) * 0.02).to(torch.bfloat16)
+    v, o, v64, o64 = ops.vo_compress(Cx, Wv, Wo, nh, nkv, hd, r, rho, want_f64=True)
+    Cr = Cx.clone()
+    Cr.diagonal().add_(rho)
+    eye = torch.eye(r, dtype=F64, device=dev)
+    for h in range(nkv):
+        vh = v64[h * r:(h + 1) * r]
+        assert (vh @ Cr @ vh.T - eye).abs().max().item() < 1e-8
+        Wvh = Wv[h * hd:(h + 1) * hd].double()
+        G = Wvh @ Cr @ Wvh.T
+        lam = torch.linalg.eigvalsh(G.cpu()).flip(0)[:r].to(dev)      # singular values^2 of sqrt(C) W_v^T
+        got = torch.linalg.eigvalsh((o64[:, h * 4 * r:(h * 4 + 1) * r].T @ o64[:, h * 4 * r:(h * 4 + 1) * r]).cpu())
+        # o'_j = W_o,j V_r S_r: energy check through the Gram spectrum of S_r V_r^T (independent of W_o)
+        P = vh.T @ (vh @ Cr)                                          # C-orthogonal projector onto the kept subspace
+        assert rel(P @ P, P) < 1e-8 and abs(torch.trace(P).item() - r) < 1e-6
+        for j in range(4):
+            qh = h * 4 + j
+            Woj = Wo[:, qh * hd:(qh + 1) * hd].double()
+            full = Woj @ Wvh                                           # uncompressed per-head map
+            assert rel(o64[:, qh * r:(qh + 1) * r] @ vh, full @ P.T) < 1e-7
+        assert lam.min().item() > 0 and got.min().item() >= -1e-12
+    assert torch.equal(v.cpu(), v64.cpu().to(torch.bfloat16)) and torch.equal(o.cpu(), o64.cpu().to(torch.bfloat16))
