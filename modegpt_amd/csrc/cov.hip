@@ -88,6 +88,65 @@ __device__ __forceinline__ void store_panel(double* panel, int tid, const typena
   }
 }
 
+// One quarter of store_panel: elements [2q .. 2q+2) x (VEC/8 ... ) -- every dtype stages a panel in 4 pieces of
+// 2*CPT*VEC/8 fp64 values, so the conversion + LDS write can be dealt out between MFMAs.
+template <int DT, bool RELU>
+__device__ __forceinline__ void store_piece(double* panel, int tid, const typename Stage<DT>::Chunk* regs, int piece) {
+  typedef Stage<DT> S;
+  constexpr int PAIRS = S::CPT * S::VEC / 2;  // d2 writes per thread per panel
+  constexpr int PER = PAIRS / 4;
+#pragma unroll
+  for (int u = 0; u < PER; u++) {
+    const int w = piece * PER + u;          // which d2 of this thread
+    const int p = w / (S::VEC / 2), e = (w % (S::VEC / 2)) * 2;
+    const int c = tid + 256 * p;
+    const int row = c / S::CPR, col = (c % S::CPR) * S::VEC;
+    double v0 = load_f64<DT>(regs[p].e, e), v1 = load_f64<DT>(regs[p].e, e + 1);
+    if (RELU) {
+      v0 = v0 > 0. ? v0 : 0.;
+      v1 = v1 > 0. ? v1 : 0.;
+    }
+    *(d2*)(panel + row * PITCH + col + e) = (d2){v0, v1};
+  }
+}
+
+// Second half of a stage (k4-steps 2 and 3, 32 MFMAs) with the next stage's staging dealt out in 8 pieces, one
+// after every 4 MFMAs; sched_barrier pins the interleave so the conversions and ds_writes retire in the MFMAs'
+// shadow instead of in a block in front of the s_barrier.
+template <int DT, bool RELU>
+__device__ __forceinline__ void mma_half_with_staging(const double* __restrict__ As, const double* __restrict__ Bs,
+                                                      int wr, int wc, int lane, Acc& acc, bool stage_next, bool diag,
+                                                      double* nextA, double* nextB, int tid,
+                                                      const typename Stage<DT>::Chunk* ra,
+                                                      const typename Stage<DT>::Chunk* rb) {
+  const int m = lane & 15, kq = lane >> 4;
+  double a[2][4], b[2][4];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int k4 = BK / 8 + h;
+    const double* ap = As + (k4 * 4 + kq) * PITCH + wr * WTILE + 4 * m;
+    const double* bp = Bs + (k4 * 4 + kq) * PITCH + wc * WTILE + 4 * m;
+    d2 a01 = *(const d2*)ap, a23 = *(const d2*)(ap + 2);
+    d2 b01 = *(const d2*)bp, b23 = *(const d2*)(bp + 2);
+    a[h][0] = a01.x; a[h][1] = a01.y; a[h][2] = a23.x; a[h][3] = a23.y;
+    b[h][0] = b01.x; b[h][1] = b01.y; b[h][2] = b23.x; b[h][3] = b23.y;
+  }
+#pragma unroll
+  for (int h = 0; h < 2; h++)
+#pragma unroll
+    for (int sa = 0; sa < 4; sa++) {
+#pragma unroll
+      for (int sb = 0; sb < 4; sb++)
+        acc.v[sa][sb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[h][sa], b[h][sb], acc.v[sa][sb], 0, 0, 0);
+      if (stage_next) {
+        const int piece = h * 4 + sa;
+        if (piece < 4) store_piece<DT, RELU>(nextA, tid, ra, piece);
+        else if (!diag) store_piece<DT, RELU>(nextB, tid, rb, piece - 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int DT, bool RELU, bool FAST>
 __global__ __launch_bounds__(256, 2) void cov_accum_kernel(CovArgs a) {
   typedef Stage<DT> S;
@@ -108,30 +167,40 @@ __global__ __launch_bounds__(256, 2) void cov_accum_kernel(CovArgs a) {
 
   Acc acc;
   acc_zero(acc);
-  typename S::Chunk ra[S::CPT], rb[S::CPT];
+  // Software pipeline, prefetch distance 2: while stage s is multiplied, stage s+1 sits in registers (loaded
+  // during stage s-1) and is converted + written to the other LDS buffer in the SHADOW of this stage's MFMAs
+  // (between its two halves), and the global loads of stage s+2 are in flight.  What is left between the last
+  // MFMA of a stage and the first of the next is one s_barrier and one LDS read latency.
+  typename S::Chunk ra1[S::CPT], rb1[S::CPT], ra2[S::CPT], rb2[S::CPT];
   const int64_t n_stage = tok_end > tok_begin ? (tok_end - tok_begin + BK - 1) / BK : 0;
 
   if (n_stage > 0) {
-    load_panel<DT, FAST>(a, tok_begin, tok_end, colA, limA, tid, ra);
-    if (!diag) load_panel<DT, FAST>(a, tok_begin, tok_end, colB, limB, tid, rb);
-    store_panel<DT, RELU>(lds, tid, ra);
-    if (!diag) store_panel<DT, RELU>(lds + 2 * PANEL, tid, rb);
+    load_panel<DT, FAST>(a, tok_begin, tok_end, colA, limA, tid, ra1);
+    if (!diag) load_panel<DT, FAST>(a, tok_begin, tok_end, colB, limB, tid, rb1);
+    store_panel<DT, RELU>(lds, tid, ra1);
+    if (!diag) store_panel<DT, RELU>(lds + 2 * PANEL, tid, rb1);
+    if (n_stage > 1) {
+      load_panel<DT, FAST>(a, tok_begin + BK, tok_end, colA, limA, tid, ra1);
+      if (!diag) load_panel<DT, FAST>(a, tok_begin + BK, tok_end, colB, limB, tid, rb1);
+    }
   }
   __syncthreads();
   for (int64_t s = 0; s < n_stage; s++) {
     const int cur = (int)(s & 1);
-    const bool more = s + 1 < n_stage;
-    if (more) {
-      int64_t tk = tok_begin + (s + 1) * BK;
-      load_panel<DT, FAST>(a, tk, tok_end, colA, limA, tid, ra);
-      if (!diag) load_panel<DT, FAST>(a, tk, tok_end, colB, limB, tid, rb);
+    if (s + 2 < n_stage) {
+      const int64_t tk = tok_begin + (s + 2) * BK;
+      load_panel<DT, FAST>(a, tk, tok_end, colA, limA, tid, ra2);
+      if (!diag) load_panel<DT, FAST>(a, tk, tok_end, colB, limB, tid, rb2);
     }
     const double* As = lds + cur * PANEL;
     const double* Bs = diag ? As : lds + (2 + cur) * PANEL;
-    mma_stage(As, Bs, wr, wc, lane, acc);
-    if (more) {
-      store_panel<DT, RELU>(lds + (cur ^ 1) * PANEL, tid, ra);
-      if (!diag) store_panel<DT, RELU>(lds + (2 + (cur ^ 1)) * PANEL, tid, rb);
+    mma_steps<0, BK / 8>(As, Bs, wr, wc, lane, acc);
+    mma_half_with_staging<DT, RELU>(As, Bs, wr, wc, lane, acc, s + 1 < n_stage, diag, lds + (cur ^ 1) * PANEL,
+                                    lds + (2 + (cur ^ 1)) * PANEL, tid, ra1, rb1);
+#pragma unroll
+    for (int p = 0; p < S::CPT; p++) {
+      ra1[p] = ra2[p];
+      rb1[p] = rb2[p];
     }
     __syncthreads();
   }
@@ -269,7 +338,7 @@ static int cov_ksplit(int64_t n_tokens, int64_t n_feat, int64_t batch, int64_t* 
     if (real != ks) continue;
     double rounds = (double)ceil_div(blocks * ks, (int64_t)slots);
     double cost = rounds * (double)tps * us_per_token + (ks > 1 ? (double)(blocks * ks) * us_per_tile_rt + 3.0 : 0.);
-    if (ks == 1 || cost < best_cost * 0.95) {  // 5 % hysteresis towards fewer splits
+    if (ks == 1 || cost < best_cost * 0.95) {  // 5 % hysteresis towards fewer splits (the tail round runs 1 workgroup per CU and is faster than the model says)
       best = ks;
       best_cost = cost;
     }

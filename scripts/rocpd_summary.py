@@ -1,0 +1,24 @@
+"""Summarise a rocprofv3 rocpd .db: per-kernel dispatch stats (and PMC counter sums if present) as CSV on stdout."""
+import sqlite3
+import sys
+
+db = sqlite3.connect(sys.argv[1])
+cur = db.cursor()
+tot = cur.execute("select sum(end-start) from rocpd_kernel_dispatch").fetchone()[0]
+print("kernel,calls,total_ms,avg_ms,min_ms,max_ms,pct")
+q = """select s.kernel_name, count(*), sum(d.end-d.start)/1e6, avg(d.end-d.start)/1e6, min(d.end-d.start)/1e6,
+       max(d.end-d.start)/1e6 from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id=s.id
+       group by s.kernel_name order by 3 desc"""
+for r in cur.execute(q):
+    print('"%s",%d,%.3f,%.4f,%.4f,%.4f,%.2f' % (r[0], r[1], r[2], r[3], r[4], r[5], 100.0 * r[2] * 1e6 / tot))
+try:
+    rows = list(cur.execute("""select s.kernel_name, p.name, count(*), sum(e.value), avg(e.value)
+        from rocpd_pmc_event e join rocpd_info_pmc p on e.pmc_id=p.id
+        join rocpd_kernel_dispatch d on e.event_id=d.event_id
+        join rocpd_info_kernel_symbol s on d.kernel_id=s.id group by s.kernel_name, p.name order by 1, 2"""))
+    if rows:
+        print("\nkernel,counter,dispatches,sum,avg_per_dispatch")
+        for r in rows:
+            print('"%s",%s,%d,%.6g,%.6g' % r)
+except sqlite3.Error as e:
+    print("# no pmc tables:", e)
