@@ -60,3 +60,10 @@ if "cov" in which:
         t = timeit(lambda: ops.vo_compress(Sx, Wv2, Wo, nh, nh, hd, 88, 1e-5), n=2); print(f"vo_compress mha: {t*1e3:.1f} ms")
     if "qk" in which:
         t = timeit(lambda: ops.qk_select(Sq, Sk, 88, _lib.MDG_QK_ROPE_GROUPED, 1e-4, 1e-2), n=3); print(f"qk_select: {t*1e3:.3f} ms")
+if "cov1r" in which:
+    # one exactly-resident round: T=31 -> 496 tiles on 512 slots; isolates in-loop efficiency from tail effects
+    n = 128 * 31
+    X = acts(131072, n); S1 = torch.zeros(n, n, dtype=F64, device=dev)
+    t = timeit(lambda: ops.cov_accum(S1, X), n=3)
+    ex = 496 * 128 * 128 * 2 * 131072
+    print(f"cov 1-round {131072}x{n}: {t*1e3:.1f} ms  {131072*n*(n+1)/t/1e12:.1f} TF syrk, executed {ex/t/1e12:.1f} TF on 496/512 slots -> {ex/t/1e12*512/496:.1f} TF-equivalent")
