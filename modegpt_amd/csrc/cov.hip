@@ -32,6 +32,17 @@ template <int DT> struct Stage {
     uint4 q;
     T e[VEC];
   };
+  // Which (token row, first column) staging chunk c of a BK x 128 panel is.  NOT the obvious c/CPR, c%CPR: a chunk
+  // widens to VEC*8 bytes of fp64, so neighbouring chunks of one row sit 64 B (bf16) apart and the 8 lanes of a
+  // ds_write_b128 group would share 2 of the 8 bank quads (4-way conflict, measured: it starves the fragment
+  // reads).  Rows are 1040 B apart = 1 bank quad (mod 8), so a group of RG rows x 8/RG chunks covers all 8 quads.
+  static constexpr int RG = VEC >= 8 ? 4 : (VEC == 4 ? 2 : 1);
+  static constexpr int CG = 8 / RG;
+  __device__ static __forceinline__ void chunk_rc(int c, int& row, int& col) {
+    const int g = c >> 3, i = c & 7;
+    row = (g % (BK / RG)) * RG + (i % RG);
+    col = ((g / (BK / RG)) * CG + i / RG) * VEC;
+  }
 };
 
 // FAST: every tile is full and 16-byte loads are legal, so the stage is one unconditional vector load per
@@ -45,9 +56,8 @@ __device__ __forceinline__ void load_panel(const CovArgs& a, int64_t tok0, int64
   const T* x = (const T*)a.x;
 #pragma unroll
   for (int p = 0; p < S::CPT; p++) {
-    int c = tid + 256 * p;
-    int row = c / S::CPR;
-    int col = (c % S::CPR) * S::VEC;
+    int row, col;
+    S::chunk_rc(tid + 256 * p, row, col);
     int64_t tok = tok0 + row;
     typename S::Chunk ch;
     ch.q = make_uint4(0, 0, 0, 0);
@@ -72,9 +82,8 @@ __device__ __forceinline__ void store_panel(double* panel, int tid, const typena
   typedef Stage<DT> S;
 #pragma unroll
   for (int p = 0; p < S::CPT; p++) {
-    int c = tid + 256 * p;
-    int row = c / S::CPR;
-    int col = (c % S::CPR) * S::VEC;
+    int row, col;
+    S::chunk_rc(tid + 256 * p, row, col);
     double* dst = panel + row * PITCH + col;
 #pragma unroll
     for (int e = 0; e < S::VEC; e += 2) {
@@ -99,8 +108,8 @@ __device__ __forceinline__ void store_piece(double* panel, int tid, const typena
   for (int u = 0; u < PER; u++) {
     const int w = piece * PER + u;          // which d2 of this thread
     const int p = w / (S::VEC / 2), e = (w % (S::VEC / 2)) * 2;
-    const int c = tid + 256 * p;
-    const int row = c / S::CPR, col = (c % S::CPR) * S::VEC;
+    int row, col;
+    S::chunk_rc(tid + 256 * p, row, col);
     double v0 = load_f64<DT>(regs[p].e, e), v1 = load_f64<DT>(regs[p].e, e + 1);
     if (RELU) {
       v0 = v0 > 0. ? v0 : 0.;
