@@ -16,19 +16,20 @@ constexpr int DP = NB + 1;  // LDS pitch (fp64) of the diagonal block: odd pitch
 
 // Factorise the nb x nb diagonal block at A (lower), write L back, write inv(L) (identity padded to 128x128)
 // to inv.  info: first failing global pivot index + 1 (atomicMin-style, 0 = ok).
-__global__ __launch_bounds__(256) void potrf_diag_kernel(double* A, int64_t lda, int nb, int64_t k0, double* inv,
+__global__ __launch_bounds__(1024) void potrf_diag_kernel(double* A, int64_t lda, int nb, int64_t k0, double* inv,
                                                          int* info) {
   __shared__ double a[NB * DP];
   __shared__ double piv[NB];   // pivots d_j, later 1/L_jj
   __shared__ double xd[NB];    // diagonal of inv(L)
+  constexpr int PT = 1024;  // 16 waves: the column updates are LDS-latency bound, so more waves in flight = faster
   const int tid = threadIdx.x;
-  for (int e = tid; e < nb * nb; e += 256) {
+  for (int e = tid; e < nb * nb; e += PT) {
     int i = e / nb, j = e % nb;
     a[i * DP + j] = (j <= i) ? A[(int64_t)i * lda + j] : 0.;
   }
   __syncthreads();
   // right-looking, scaling deferred: after step j column j holds the unscaled L column, a[j][j] the pivot.
-  const int tr = tid >> 4, tc = tid & 15;
+  const int tr = tid >> 5, tc = tid & 31;
   for (int j = 0; j < nb; j++) {
     double d = a[j * DP + j];
     if (!(d > 0.)) {  // also catches NaN
@@ -42,15 +43,15 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* A, int64_t lda,
       if (tid == 0) a[j * DP + j] = 1.;
     }
     const double rd = 1. / d;
-    for (int i = j + 1 + tr; i < nb; i += 16) {
+    for (int i = j + 1 + tr; i < nb; i += 32) {
       const double lij = a[i * DP + j] * rd;
-      for (int k = j + 1 + tc; k <= i; k += 16) a[i * DP + k] -= lij * a[k * DP + j];
+      for (int k = j + 1 + tc; k <= i; k += 32) a[i * DP + k] -= lij * a[k * DP + j];
     }
     __syncthreads();
   }
   if (tid < nb) piv[tid] = 1. / sqrt(a[tid * DP + tid]);
   __syncthreads();
-  for (int e = tid; e < nb * nb; e += 256) {
+  for (int e = tid; e < nb * nb; e += PT) {
     int i = e / nb, j = e % nb;
     if (j < i) a[i * DP + j] *= piv[j];
   }
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* A, int64_t lda,
     xd[tid] = piv[tid];                 // X_jj = 1 / L_jj
   }
   __syncthreads();
-  for (int e = tid; e < nb * nb; e += 256) {
+  for (int e = tid; e < nb * nb; e += PT) {
     int i = e / nb, j = e % nb;
     if (j <= i) A[(int64_t)i * lda + j] = a[i * DP + j];
   }
@@ -69,17 +70,17 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* A, int64_t lda,
   for (int k = 0; k < nb; k++) {
     // scale row k: X[k][j] for j < k  (X[k][k] = xd[k] already holds 1/L_kk)
     // combined with the update below by carrying the scale: process row k scaling first.
-    for (int j = tid; j < k; j += 256) a[j * DP + k] *= xd[k];
+    for (int j = tid; j < k; j += PT) a[j * DP + k] *= xd[k];
     __syncthreads();
     const int rows = nb - 1 - k;
-    for (int e = tid; e < rows * (k + 1); e += 256) {
+    for (int e = tid; e < rows * (k + 1); e += PT) {
       int i = k + 1 + e % rows, j = e / rows;
       double xkj = (j == k) ? xd[k] : a[j * DP + k];
       a[j * DP + i] -= a[i * DP + k] * xkj;
     }
     __syncthreads();
   }
-  for (int e = tid; e < NB * NB; e += 256) {
+  for (int e = tid; e < NB * NB; e += PT) {
     int i = e / NB, j = e % NB;
     double v;
     if (i >= nb || j >= nb) v = (i == j) ? 1. : 0.;
@@ -145,7 +146,7 @@ int potrf_lower(double* A, int64_t n, int64_t lda, double* inv_diag, hipStream_t
     const int nb = (int)(n - k0 < NB ? n - k0 : NB);
     double* Akk = A + k0 * lda + k0;
     double* inv = inv_diag + b * NB * NB;
-    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, st, Akk, lda, nb, k0, inv, dflag);
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(1024), 0, st, Akk, lda, nb, k0, inv, dflag);
     MDG_LAUNCH_CHECK();
     const int64_t rest = n - k0 - nb;
     if (rest <= 0) break;

@@ -7,6 +7,8 @@
 // the token dimension is streamed through LDS in 16-token stages, converted to fp64 once while staging, so
 // the inner loop is LDS reads + 16 MFMAs per 4 tokens.  The kernel is fp64-MFMA bound: at 128x128 tiles the
 // operand traffic is 2 B/cycle/CU (DESIGN.md "cov_accum").
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace mdg {
@@ -48,7 +50,7 @@ template <int DT> struct Stage {
 // FAST: every tile is full and 16-byte loads are legal, so the stage is one unconditional vector load per
 // chunk and its s_waitcnt can sink below the stage's MFMAs; the generic path (ragged n_feat, unaligned
 // views) goes element by element.
-template <int DT, bool FAST>
+template <int DT, bool FAST, bool INB = false>
 __device__ __forceinline__ void load_panel(const CovArgs& a, int64_t tok0, int64_t tok_end, int64_t col0,
                                            int col_lim, int tid, typename Stage<DT>::Chunk* regs) {
   typedef Stage<DT> S;
@@ -61,7 +63,9 @@ __device__ __forceinline__ void load_panel(const CovArgs& a, int64_t tok0, int64
     int64_t tok = tok0 + row;
     typename S::Chunk ch;
     ch.q = make_uint4(0, 0, 0, 0);
-    if (FAST) {
+    if (FAST && INB) {
+      ch.q = *(const uint4*)(x + tok * a.ld + col0 + col);  // whole stage in range: no exec masking, no branch
+    } else if (FAST) {
       if (tok < tok_end) ch.q = *(const uint4*)(x + tok * a.ld + col0 + col);
     } else if (tok < tok_end) {
       const T* src = x + tok * a.ld + col0 + col;
@@ -122,9 +126,9 @@ __device__ __forceinline__ void store_piece(double* panel, int tid, const typena
 // Second half of a stage (k4-steps 2 and 3, 32 MFMAs) with the next stage's staging dealt out in 8 pieces, one
 // after every 4 MFMAs; sched_barrier pins the interleave so the conversions and ds_writes retire in the MFMAs'
 // shadow instead of in a block in front of the s_barrier.
-template <int DT, bool RELU>
+template <int DT, bool RELU, bool DIAG>
 __device__ __forceinline__ void mma_half_with_staging(const double* __restrict__ As, const double* __restrict__ Bs,
-                                                      int wr, int wc, int lane, Acc& acc, bool stage_next, bool diag,
+                                                      int wr, int wc, int lane, Acc& acc, bool stage_next,
                                                       double* nextA, double* nextB, int tid,
                                                       const typename Stage<DT>::Chunk* ra,
                                                       const typename Stage<DT>::Chunk* rb) {
@@ -150,22 +154,17 @@ __device__ __forceinline__ void mma_half_with_staging(const double* __restrict__
       if (stage_next) {
         const int piece = h * 4 + sa;
         if (piece < 4) store_piece<DT, RELU>(nextA, tid, ra, piece);
-        else if (!diag) store_piece<DT, RELU>(nextB, tid, rb, piece - 4);
+        else if (!DIAG) store_piece<DT, RELU>(nextB, tid, rb, piece - 4);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-template <int DT, bool RELU, bool FAST>
-__global__ __launch_bounds__(256, 2) void cov_accum_kernel(CovArgs a) {
+template <int DT, bool RELU, bool FAST, bool DIAG>
+__device__ __forceinline__ void cov_tile(const CovArgs& a, double* lds, int b, int bi, int bj) {
   typedef Stage<DT> S;
-  __shared__ double lds[4 * PANEL];  // As[2], Bs[2]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int b = blockIdx.x / a.ntri, t = blockIdx.x % a.ntri;
-  int bi, bj;
-  tri_decode(t, bi, bj);
-  const bool diag = (bi == bj);
   const int split = blockIdx.y;
   const int64_t tok_begin = (int64_t)split * a.tokens_per_split;
   int64_t tok_end = tok_begin + a.tokens_per_split;
@@ -185,34 +184,49 @@ __global__ __launch_bounds__(256, 2) void cov_accum_kernel(CovArgs a) {
 
   if (n_stage > 0) {
     load_panel<DT, FAST>(a, tok_begin, tok_end, colA, limA, tid, ra1);
-    if (!diag) load_panel<DT, FAST>(a, tok_begin, tok_end, colB, limB, tid, rb1);
+    if (!DIAG) load_panel<DT, FAST>(a, tok_begin, tok_end, colB, limB, tid, rb1);
     store_panel<DT, RELU>(lds, tid, ra1);
-    if (!diag) store_panel<DT, RELU>(lds + 2 * PANEL, tid, rb1);
+    if (!DIAG) store_panel<DT, RELU>(lds + 2 * PANEL, tid, rb1);
     if (n_stage > 1) {
       load_panel<DT, FAST>(a, tok_begin + BK, tok_end, colA, limA, tid, ra1);
-      if (!diag) load_panel<DT, FAST>(a, tok_begin + BK, tok_end, colB, limB, tid, rb1);
+      if (!DIAG) load_panel<DT, FAST>(a, tok_begin + BK, tok_end, colB, limB, tid, rb1);
     }
   }
   __syncthreads();
-  for (int64_t s = 0; s < n_stage; s++) {
-    const int cur = (int)(s & 1);
-    if (s + 2 < n_stage) {
+  // One stage: issue the loads of stage s+2 into `ld`, multiply LDS buffer CUR, deal stage s+1 (registers `st`) out to
+  // buffer CUR^1 between the MFMAs, barrier.  Unrolled by two so buffer parity and the two register sets are
+  // compile-time; STEADY = stages s+1 and s+2 exist and lie wholly inside the token range, so the steady-state loop
+  // carries no branches and no exec masking (every non-MFMA instruction costs MFMA issue slots on the SIMD).
+  auto stage = [&](int64_t s, auto cur_c, auto steady_c, typename S::Chunk* st_a, typename S::Chunk* st_b,
+                   typename S::Chunk* ld_a, typename S::Chunk* ld_b) {
+    constexpr int CUR = decltype(cur_c)::value;
+    constexpr bool STEADY = decltype(steady_c)::value;
+    if (STEADY || s + 2 < n_stage) {
       const int64_t tk = tok_begin + (s + 2) * BK;
-      load_panel<DT, FAST>(a, tk, tok_end, colA, limA, tid, ra2);
-      if (!diag) load_panel<DT, FAST>(a, tk, tok_end, colB, limB, tid, rb2);
+      load_panel<DT, FAST, STEADY>(a, tk, tok_end, colA, limA, tid, ld_a);
+      if (!DIAG) load_panel<DT, FAST, STEADY>(a, tk, tok_end, colB, limB, tid, ld_b);
     }
-    const double* As = lds + cur * PANEL;
-    const double* Bs = diag ? As : lds + (2 + cur) * PANEL;
+    const double* As = lds + CUR * PANEL;
+    const double* Bs = DIAG ? As : lds + (2 + CUR) * PANEL;
     mma_steps<0, BK / 8>(As, Bs, wr, wc, lane, acc);
-    mma_half_with_staging<DT, RELU>(As, Bs, wr, wc, lane, acc, s + 1 < n_stage, diag, lds + (cur ^ 1) * PANEL,
-                                    lds + (2 + (cur ^ 1)) * PANEL, tid, ra1, rb1);
-#pragma unroll
-    for (int p = 0; p < S::CPT; p++) {
-      ra1[p] = ra2[p];
-      rb1[p] = rb2[p];
-    }
+    mma_half_with_staging<DT, RELU, DIAG>(As, Bs, wr, wc, lane, acc, STEADY || s + 1 < n_stage, lds + (CUR ^ 1) * PANEL,
+                                          lds + (2 + (CUR ^ 1)) * PANEL, tid, st_a, st_b);
     __syncthreads();
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  int64_t s = 0;
+  // steady state: stage s+3 must be complete too, since the unrolled pair loads stages s+2 and s+3
+  const int64_t n_full = (tok_end - tok_begin) / BK;  // stages wholly inside the token range
+  for (; s + 3 < n_full; s += 2) {
+    stage(s, I0{}, std::true_type{}, ra1, rb1, ra2, rb2);
+    stage(s + 1, I1{}, std::true_type{}, ra2, rb2, ra1, rb1);
   }
+  for (; s + 1 < n_stage; s += 2) {
+    stage(s, I0{}, std::false_type{}, ra1, rb1, ra2, rb2);
+    stage(s + 1, I1{}, std::false_type{}, ra2, rb2, ra1, rb1);
+  }
+  if (s < n_stage) stage(s, I0{}, std::false_type{}, ra1, rb1, ra2, rb2);
 
   // epilogue
   if (a.ksplit == 1) {
@@ -243,6 +257,16 @@ __global__ __launch_bounds__(256, 2) void cov_accum_kernel(CovArgs a) {
         *(d4*)(pt + r * TILE + c0) = v;
       }
   }
+}
+
+template <int DT, bool RELU, bool FAST>
+__global__ __launch_bounds__(256, 2) void cov_accum_kernel(CovArgs a) {
+  __shared__ double lds[4 * PANEL];  // As[2], Bs[2]
+  const int b = blockIdx.x / a.ntri, t = blockIdx.x % a.ntri;
+  int bi, bj;
+  tri_decode(t, bi, bj);
+  if (bi == bj) cov_tile<DT, RELU, FAST, true>(a, lds, b, bi, bj);
+  else cov_tile<DT, RELU, FAST, false>(a, lds, b, bi, bj);
 }
 
 // sigma tile += sum over splits (fixed order) of the partial tiles.  grid = (tiles, 64): 256 elements per block.
