@@ -8,12 +8,9 @@ once at the end (mdg_cov_finalize).
 """
 from __future__ import annotations
 
-import json
 import logging
 import os
 from abc import ABC, abstractmethod
-from dataclasses import dataclass
-from datetime import datetime
 from typing import Any, List, Optional, Tuple
 
 import torch
@@ -21,81 +18,16 @@ import torch.nn as nn
 from torch import Tensor
 
 from .. import ops
+from . import metrics as _metrics
 from .CompressionConfig import CompressionConfig
-
-
-# ---- carriers between adapters and compressors (model_adapter.py:19-82) ----
-@dataclass
-class MLPTensors:
-    up_proj: Tensor
-    down_proj: Tensor
-    gate_proj: Optional[Tensor]
-
-    def to(self, dtype):
-        self.up_proj = self.up_proj.to(dtype=dtype)
-        self.down_proj = self.down_proj.to(dtype=dtype)
-        if self.gate_proj is not None:
-            self.gate_proj = self.gate_proj.to(dtype=dtype)
-        return self
-
-
-@dataclass
-class VOTensors:
-    v_proj: Tensor
-    o_proj: Tensor
-
-    def to(self, dtype):
-        self.v_proj, self.o_proj = self.v_proj.to(dtype=dtype), self.o_proj.to(dtype=dtype)
-        return self
-
-
-@dataclass
-class QKTensors:
-    query_proj: Tensor
-    key_proj: Tensor
-
-    def to(self, dtype):
-        self.query_proj, self.key_proj = self.query_proj.to(dtype=dtype), self.key_proj.to(dtype=dtype)
-        return self
-
-
-@dataclass
-class MLPComponents:
-    block: Optional[nn.Module]
-    up_proj: nn.Module
-    down_proj: nn.Module
-    gate_proj: Optional[nn.Module] = None
-
-
-@dataclass
-class QKComponents:
-    block: Optional[nn.Module]
-    query_proj: nn.Module
-    key_proj: nn.Module
-
-
-@dataclass
-class VOComponents:
-    block: Optional[nn.Module]
-    v_proj: nn.Module
-    o_proj: nn.Module
-
-
-@dataclass
-class AttentionComponents:
-    block: nn.Module
-    q_proj: nn.Module
-    k_proj: nn.Module
-    v_proj: Optional[nn.Module] = None
-    o_proj: Optional[nn.Module] = None
+from .components import (AttentionComponents, MLPComponents, MLPTensors, QKComponents, QKTensors,  # noqa: F401
+                         VOComponents, VOTensors)
 
 
 def build_metrics(all_metrics: dict) -> dict:
-    """model_adapter.py:85-94."""
-    now = datetime.now()
-    run = now.strftime("%Y_%m_%d--%H_%M_%S")
-    m = {"RunName": run, "RunDate": now.strftime("%b %d, %Y %I:%M %p"), "latent_moe_metrics": {}}
-    all_metrics[run] = m
+    """Kept for callers of the reference's helper; the store itself lives in adapters/metrics.py."""
+    m = _metrics.new_run()
+    all_metrics[m["RunName"]] = m
     return m
 
 
@@ -109,7 +41,7 @@ class ModelAdapter(ABC):
         self.tokenizer = tokenizer
         self.calibs = None
         ModelAdapter.load_metrics()
-        self.metrics = build_metrics(ModelAdapter._metrics)
+        self.metrics = _metrics.new_run()
 
     # ---- construction (model_adapter.py:118-135) ----
     @staticmethod
@@ -126,28 +58,19 @@ class ModelAdapter(ABC):
             return LlamaAdapter(model, tokenizer=tokenizer)
         raise RuntimeError("Unsupported model architecture")
 
-    # ---- metrics (model_adapter.py:137-182) ----
+    # ---- metrics: thin delegates to adapters/metrics.py ----
     @staticmethod
     def load_metrics(path="./metrics/metrics.json"):
-        if not ModelAdapter._metrics and os.path.exists(path):
-            with open(path) as f:
-                ModelAdapter._metrics = json.load(f)
+        _metrics.load(path)
+        ModelAdapter._metrics = _metrics.ALL_RUNS
 
     @staticmethod
     def save_metrics_static(path="./metrics/metrics.json", backup_dir="./metrics/backups/",
                             jsons_path="./metrics/jsons/", run_metrics: Optional[dict] = None):
-        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
-        os.makedirs(backup_dir, exist_ok=True)
-        with open(path, "w") as f:
-            json.dump(ModelAdapter._metrics, f, indent=4)
-        if run_metrics:
-            os.makedirs(jsons_path, exist_ok=True)
-            note = (run_metrics.get("note") or "")[:15]
-            with open(os.path.join(jsons_path, f"{run_metrics['RunName']}--{note}.json"), "w") as f:
-                json.dump(run_metrics, f, indent=4)
+        _metrics.save(path, backup_dir, jsons_path, run_metrics)
 
     def save_metrics(self, path="./metrics/metrics.json", backup_dir="./metrics/backups/"):
-        ModelAdapter.save_metrics_static(path=path, backup_dir=backup_dir, run_metrics=self.metrics)
+        _metrics.save(path=path, backup_dir=backup_dir, run_metrics=self.metrics)
 
     # ---- reconstruction: per-(layer, stage) artefacts and the final swap (model_adapter.py:184-237) ----
     def save_layer(self, output_dir: str, suffix: str, weights: dict, layer_idx):

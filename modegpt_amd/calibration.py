@@ -1,10 +1,18 @@
-"""Calibration: run the model over the calibration batches while hooks accumulate the fp64 second-moment
-matrices, plus Block-Influence scores (reference: src/calibration.py)."""
+"""Calibration pass: one sweep of the model over the calibration batches during which adapter hooks stream every
+target layer's activations into the HIP covariance kernel, plus Block-Influence scores from the hidden states.
+
+Public entry point and return contract follow the reference (src/calibration.py:18-36):
+    load_calibs(adapter, n_samples, batch_size, dataset, load_calibs_from, calibs_save_path, target_layers)
+        -> (cov_mlp, cov_q, cov_k, cov_x, bi_scores)
+each cov_* a list with one fp64 device tensor per layer (None outside target_layers), bi_scores a list of floats
+for ALL layers.  Internals differ: sigma buffers are lower-triangular until one fused mirror+normalise pass at the
+end, and the BI running sums stay on the device (one host sync per calibration, not one per layer per batch).
+"""
 from __future__ import annotations
 
 import logging
 import random
-from typing import List
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
@@ -18,13 +26,53 @@ logger = logging.getLogger("MoDeGPT")
 np.random.seed(1234)
 random.seed(1234)
 
-SEQ_LEN_NORMALISER = 2048  # calibration.py:141: the normaliser is n_texts * 2048 whatever the real length
+# The normaliser is n_texts * 2048 whatever the real sequence length is (src/calibration.py:141).
+TOKENS_PER_TEXT_NORMALISER = 2048
+
+
+class SigmaBuffers:
+    """The four statistic families of the target layers (shapes: src/calibration.py:82-96)."""
+
+    KINDS = ("mlp", "q", "k", "x")
+
+    def __init__(self, adapter: ModelAdapter, target_layers: Sequence[int], device=calib_device):
+        L = adapter.n_layers
+        hd, d, f = adapter.head_dim, adapter.d_model, adapter.get_n_inner()
+        shapes = {"mlp": (f, f), "q": (adapter.n_heads, hd, hd), "k": (adapter.n_kv_heads, hd, hd), "x": (d, d)}
+        self.lists: Dict[str, List[Optional[torch.Tensor]]] = {k: [None] * L for k in self.KINDS}
+        self.layers = list(target_layers)
+        for i in self.layers:
+            for kind, shp in shapes.items():
+                self.lists[kind][i] = torch.zeros(*shp, dtype=dtype_p, device=device)
+
+    def finalize(self, n_texts: int) -> None:
+        """sigma <- sigma / (n_texts * 2048), lower triangle mirrored into the upper (src/calibration.py:141-146)."""
+        scale = 1.0 / (n_texts * TOKENS_PER_TEXT_NORMALISER)
+        for i in self.layers:
+            for kind in self.KINDS:
+                ops.cov_finalize(self.lists[kind][i], scale)
+
+
+class BlockInfluence:
+    """bi[l] = (1/n_texts) * sum over batches of mean_T sum_B (1 - cos(h_l, h_{l+1}))  (src/calibration.py:118-136)."""
+
+    def __init__(self, n_layers: int, device=calib_device):
+        self.n_layers = n_layers
+        self.acc = torch.zeros(n_layers, dtype=torch.float64, device=device)
+
+    def add_batch(self, hidden_states) -> None:
+        T = hidden_states[0].shape[1]
+        step = torch.zeros_like(self.acc)
+        for l in range(self.n_layers):
+            ops.bi_accum(step[l:l + 1], hidden_states[l], hidden_states[l + 1])
+        self.acc += step / T
+
+    def scores(self, n_texts: int) -> List[float]:
+        return [v / n_texts for v in self.acc.cpu().tolist()]
 
 
 def load_calibs(adapter: ModelAdapter, n_samples: int, batch_size: int, dataset: str = "wikitext",
                 load_calibs_from="", calibs_save_path="", target_layers: List[int] = []):
-    """calibration.py:18-36 -> (cov_mlp, cov_q, cov_k, cov_x, bi_scores); the four lists have one entry per
-    layer, None for layers outside target_layers."""
     return _calibrate_model(adapter, n_samples=n_samples, batch_size=batch_size, dataset=dataset,
                             target_layers=target_layers)
 
@@ -33,63 +81,39 @@ def load_calibs(adapter: ModelAdapter, n_samples: int, batch_size: int, dataset:
 def _calibrate_model(adapter: ModelAdapter, n_samples: int, batch_size: int, target_layers: List[int] = [],
                      dataset="wikitext"):
     model = adapter.model
-    n_layers, n_heads, head_dim = adapter.n_layers, adapter.n_heads, adapter.head_dim
-    blocks = adapter.get_transformer_blocks()
-    if not target_layers:
-        target_layers = list(range(n_layers))
-    model.config.output_hidden_states = True
+    targets = list(target_layers) if target_layers else list(range(adapter.n_layers))
     if adapter.calibs is None:
         from .eval import load_calibration_texts
-        adapter.calibs = load_calibration_texts(calib_size=n_samples, model=adapter.model, tokenizer=adapter.tokenizer,
+        adapter.calibs = load_calibration_texts(calib_size=n_samples, model=model, tokenizer=adapter.tokenizer,
                                                 batch_size=batch_size, dataset=dataset)
     logger.info(f"Detected architecture: {adapter.arch}")
-    logger.info(f"target_layers = {target_layers}")
+    logger.info(f"target_layers = {targets}")
     logger.info("Calibrating model")
 
-    cov_mlp = [None] * n_layers
-    cov_q = [None] * n_layers
-    cov_k = [None] * n_layers
-    cov_x = [None] * n_layers
-    d_int = adapter.get_n_inner()
-    for i in target_layers:  # calibration.py:82-96
-        cov_mlp[i] = torch.zeros(d_int, d_int, dtype=dtype_p, device=calib_device)
-        cov_q[i] = torch.zeros(n_heads, head_dim, head_dim, dtype=dtype_p, device=calib_device)
-        cov_k[i] = torch.zeros(adapter.n_kv_heads, head_dim, head_dim, dtype=dtype_p, device=calib_device)
-        cov_x[i] = torch.zeros(adapter.d_model, adapter.d_model, dtype=dtype_p, device=calib_device)
-
-    handles = []
-    for i in target_layers:
-        adapter.register_hooks(i, blocks[i], cov_mlp_list=cov_mlp, cov_q_list=cov_q, cov_k_list=cov_k,
-                               cov_x_list=cov_x, handles=handles, logger=logger)
-
+    sig = SigmaBuffers(adapter, targets)
+    bi = BlockInfluence(adapter.n_layers)
+    blocks = adapter.get_transformer_blocks()
+    handles: list = []
+    for i in targets:
+        adapter.register_hooks(i, blocks[i], cov_mlp_list=sig.lists["mlp"], cov_q_list=sig.lists["q"],
+                               cov_k_list=sig.lists["k"], cov_x_list=sig.lists["x"], handles=handles, logger=logger)
+    model.config.output_hidden_states = True
     model.eval()
-    bi_dev = torch.zeros(n_layers, dtype=torch.float64, device=calib_device)  # running sums stay on the GPU
-    bi_scores = [0.0] * n_layers
     n_texts = 0
-    for batch in adapter.calibs:
-        n_texts += len(batch)
-        out = model(batch, output_hidden_states=True)
-        hs = out.hidden_states
-        T = hs[0].shape[1]
-        step = torch.zeros(n_layers, dtype=torch.float64, device=calib_device)
-        for l in range(n_layers):  # calibration.py:118-124: sum_B (1 - cos) then mean over T
-            ops.bi_accum(step[l:l + 1], hs[l], hs[l + 1])
-        bi_dev += step / T
-        del hs, out
-    for h in handles:
-        h.remove()
-    bi_host = bi_dev.cpu().tolist()  # one sync for all layers (the reference syncs per layer per batch)
-    for l in range(n_layers):
-        bi_scores[l] = bi_host[l] / n_texts
+    try:
+        for batch in adapter.calibs:
+            n_texts += len(batch)
+            out = model(batch, output_hidden_states=True)
+            bi.add_batch(out.hidden_states)
+            del out
+    finally:
+        for h in handles:
+            h.remove()
+    bi_scores = bi.scores(n_texts)
     adapter.bi_scores = bi_scores
-
-    scale = 1.0 / (n_texts * SEQ_LEN_NORMALISER)
-    for i in target_layers:  # calibration.py:141-146, fused with the lower->upper mirror
-        for buf in (cov_mlp[i], cov_x[i], cov_k[i], cov_q[i]):
-            ops.cov_finalize(buf, scale)
+    sig.finalize(n_texts)
     logger.info("Finished calibration and computed BI scores.")
-    return cov_mlp, cov_q, cov_k, cov_x, bi_scores
+    return sig.lists["mlp"], sig.lists["q"], sig.lists["k"], sig.lists["x"], bi_scores
 
 
-# the reference names this function with two leading underscores
-__calibrate_model = _calibrate_model
+__calibrate_model = _calibrate_model  # the reference's (name-mangled) spelling

@@ -1,118 +1,116 @@
-"""Module-level constants and HF model IO of the reference's src/model_utils.py.
+"""Run-wide constants read by the hot path, and the HF checkpoint IO around it.
 
-The constants are read by the hot path exactly as in the reference (model_utils.py:15-31).  Model IO is HF
-plumbing (network / disk bound, SURVEY.md section 2 "OUT OF SCOPE"): kept API-compatible, not accelerated.
+The constants keep the reference's names and values (src/model_utils.py:15-31) because adapters and compressors
+import them by name.  The IO functions are API-compatible plumbing (HF load / save, network or disk bound --
+SURVEY.md section 2 "OUT OF SCOPE"): nothing here is accelerated, it only has to write a checkpoint the reference's
+patched modeling files can load.
 """
 from __future__ import annotations
 
 import logging
 import os
 import shutil
+import threading
+import time
 
 import torch
 
 logger = logging.getLogger("MoDeGPT")
 
-dtype_p = torch.float64   # precision of the statistics and factorizations   (model_utils.py:15)
-dtype_f = torch.float16   # (unused legacy) final cast type                   (model_utils.py:19)
-parallel = False          # reference's disabled two-GPU stub                 (model_utils.py:26)
+# ---- precision / placement constants -------------------------------------------------------------------------
+dtype_p = torch.float64      # statistics and factorizations
+dtype_f = torch.float16      # legacy "final" dtype (the artefacts are bf16)
+parallel = False             # the reference's two-GPU stub; multi-GPU here is sharding.py, not this flag
 conservative = True
 d1 = "cuda:0"
 d2 = "cuda:1" if parallel else "cuda:0"
-calib_device = "cuda:1" if parallel else "cuda:0"
+calib_device = d2
 
-_REBUILD_FILE = {"opt": "OPTRebuild.py", "llama": "LlamaRebuild.py"}
+# architecture -> modeling file the checkpoint must ship with (written by the reference, src/patchers/)
+REBUILD_FILES = {"opt": "OPTRebuild.py", "llama": "LlamaRebuild.py", "qwen": "DenseQwenRebuild.py"}
 
 
-def start_memory_usage_worker(path: str = "./.mem-usage", period_s: float = 1.0):
-    """Daemon thread writing process RSS to ./.mem-usage once a second (model_utils.py:34-60)."""
-    import threading
-    import time
+def rebuild_file_for(arch: str) -> str:
+    for key, fname in REBUILD_FILES.items():
+        if key in arch:
+            return fname
+    raise Exception("Cannot save compressed model ... no compressed model definition")
 
+
+def start_memory_usage_worker(path: str = "./.mem-usage", period_s: float = 1.0) -> threading.Thread:
+    """1 Hz RSS monitor writing ./.mem-usage (daemon thread), as the reference's run does."""
     import psutil
+    me = psutil.Process(os.getpid())
 
-    def run():
-        proc = psutil.Process(os.getpid())
+    def loop():
         while True:
-            rss = proc.memory_info().rss / 2 ** 30
+            gib = me.memory_info().rss / 2 ** 30
+            text = f"[Monitor] Process RAM: {gib:.2f} GB\nSystem RAM: {psutil.virtual_memory().percent}% used"
+            if gib > 60:
+                text += "\n\nCRITICAL WARNING: Process nearing 64GB RAM limit! Crash imminent.\n"
             with open(path, "w") as f:
-                f.write(f"[Monitor] Process RAM: {rss:.2f} GB\nSystem RAM: {psutil.virtual_memory().percent}% used")
+                f.write(text)
             time.sleep(period_s)
 
-    t = threading.Thread(target=run, daemon=True)
+    t = threading.Thread(target=loop, daemon=True)
     t.start()
     return t
 
 
-def _fix_pad(tokenizer):
-    if tokenizer is not None and tokenizer.pad_token is None:
-        tokenizer.pad_token = tokenizer.eos_token
+def _causal_lm(source: str):
+    from transformers import AutoModelForCausalLM
+    return AutoModelForCausalLM.from_pretrained(source, device_map="auto", trust_remote_code=True, torch_dtype="auto")
+
+
+def _tokenizer(source: str):
+    from transformers import AutoTokenizer
+    tok = AutoTokenizer.from_pretrained(source)
+    if tok.pad_token is None:
+        tok.pad_token = tok.eos_token
         logger.info("No pad_token found. Set pad_token = eos_token.")
+    return tok
 
 
 def load_model(model_name: str, device: int = 0):
-    """model_utils.py:63-80."""
-    from transformers import AutoModelForCausalLM, AutoTokenizer
+    """(model, tokenizer, config) of an official checkpoint."""
     logger.info(f"Loading model from: {model_name}")
-    tokenizer = AutoTokenizer.from_pretrained(model_name)
-    model = AutoModelForCausalLM.from_pretrained(model_name, device_map="auto", trust_remote_code=True,
-                                                 torch_dtype="auto")
-    _fix_pad(tokenizer)
-    return model, tokenizer, model.config
+    model = _causal_lm(model_name)
+    return model, _tokenizer(model_name), model.config
 
 
-def rebuild_file_for(arch: str) -> str:
-    if arch in _REBUILD_FILE:
-        return _REBUILD_FILE[arch]
-    if "qwen" in arch:
-        return "DenseQwenRebuild.py"
-    raise Exception("Cannot save compressed model ... no compressed model definition")
+def reload_compressed_model(model_dir: str, device="cuda:0", tokenizer_source: str = ""):
+    """Load an original OR compressed checkpoint; a compressed one names its tokenizer in tokenizer_source.txt and
+    its modeling file through config.auto_map (trust_remote_code)."""
+    logger.info(f"Reloading compressed model from: {model_dir}")
+    marker = os.path.join(model_dir, "tokenizer_source.txt")
+    if not tokenizer_source:
+        tokenizer_source = open(marker).read().strip() if os.path.exists(marker) else model_dir
+    model = _causal_lm(model_dir).to(device).eval()
+    return model, _tokenizer(tokenizer_source)
 
 
 def save_compressed_model(adapter, rotary_masks, save_dir: str, source_model_name: str,
                           patchers_dir: str = "./src/patchers"):
-    """Checkpoint writer with the reference's artefact set (model_utils.py:83-126): pytorch_model*.bin
-    (safe_serialization=False), tokenizer, rotary_masks.pt, config.mask_path (absolute), torch_dtype=bfloat16, the
-    arch's *Rebuild.py copied next to the weights, tokenizer_source.txt.  The *Rebuild.py modeling files are the
-    reference's own (inference-time, out of scope here): they are copied from `patchers_dir` when present."""
+    """Write the artefact set the reference's loader expects: pytorch_model*.bin (safe_serialization=False),
+    tokenizer files, rotary_masks.pt + config.mask_path (absolute), config dtype bfloat16, the architecture's
+    *Rebuild.py next to the weights, tokenizer_source.txt."""
     model, tokenizer = adapter.model, adapter.tokenizer
-    rebuild_path = os.path.join(patchers_dir, rebuild_file_for(adapter.arch))
     os.makedirs(save_dir, exist_ok=True)
-    if rotary_masks is not None:
-        mask_path = os.path.abspath(os.path.join(save_dir, "rotary_masks.pt"))
-        model.config.mask_path = mask_path
-    else:
-        mask_path = None
-        model.config.mask_path = None
-    model.config.torch_dtype = "bfloat16"
-    model.config.dtype = "bfloat16"
+    mask_path = os.path.abspath(os.path.join(save_dir, "rotary_masks.pt")) if rotary_masks is not None else None
+    model.config.mask_path = mask_path
+    model.config.torch_dtype = model.config.dtype = "bfloat16"
     logger.info(f"Saving compressed model to {save_dir}")
     model.save_pretrained(save_dir, safe_serialization=False)
     if tokenizer is not None:
         tokenizer.save_pretrained(save_dir)
-    if rotary_masks is not None:
+    if mask_path is not None:
         torch.save(rotary_masks, mask_path)
-    if os.path.exists(rebuild_path):
-        shutil.copy(rebuild_path, save_dir)
+    rebuild = os.path.join(patchers_dir, rebuild_file_for(adapter.arch))
+    if os.path.exists(rebuild):
+        shutil.copy(rebuild, save_dir)
     else:
-        logger.warning(f"{rebuild_path} not found: checkpoint written without its modeling file "
-                       "(run from the reference checkout, or pass patchers_dir)")
+        logger.warning(f"{rebuild} not found: checkpoint written without its modeling file (run from the reference "
+                       "checkout or pass patchers_dir)")
     with open(os.path.join(save_dir, "tokenizer_source.txt"), "w") as f:
         f.write(source_model_name.strip())
     logger.info(f"Model, tokenizer, and tokenizer_source.txt saved to {save_dir}")
-
-
-def reload_compressed_model(model_dir: str, device="cuda:0", tokenizer_source: str = ""):
-    """model_utils.py:129-165."""
-    from transformers import AutoModelForCausalLM, AutoTokenizer
-    logger.info(f"Reloading compressed model from: {model_dir}")
-    if not tokenizer_source:
-        p = os.path.join(model_dir, "tokenizer_source.txt")
-        tokenizer_source = open(p).read().strip() if os.path.exists(p) else model_dir
-    tokenizer = AutoTokenizer.from_pretrained(tokenizer_source)
-    model = AutoModelForCausalLM.from_pretrained(model_dir, trust_remote_code=True, device_map="auto",
-                                                 torch_dtype="auto")
-    _fix_pad(tokenizer)
-    model.to(device)
-    model.eval()
-    return model, tokenizer
