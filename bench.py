@@ -174,6 +174,13 @@ def main():
 
     n_launch, flops, ms = timer.summary()
     achieved = flops / (ms * 1e-3) / 1e12
+    # HBM bytes per launch come from a separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run of the same kernel on the
+    # same four launch shapes (PMC passes cannot ride along a timed run); only valid for the default workload.
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_cov_hbm_traffic.json")
+    if os.path.exists(tpath) and a.model == "llama-3-8b" and a.batch_size == 16:
+        with open(tpath) as f:
+            traffic = json.load(f)["avg_hbm_bytes_per_launch_over_the_four"]
     out = {
         "metric": "transformer layers compressed/sec (covariance+decomp+rebuild), Llama-3-8B @30%",
         "value": world * a.steps / elapsed, "unit": "layers/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -184,7 +191,9 @@ def main():
                                f"{ridges}, one layer per step per GPU", "layers_per_gpu": a.steps,
                    "parallelism": f"layer-sharded x{world}, one all-gather"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                     "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), "
+                                     "profiles/r01_cov_hbm_traffic.json",
                      "kernel": "cov_accum_kernel (v_mfma_f64_16x16x4_f64)", "launches": n_launch,
                      "avg_launch_ms": ms / n_launch, "flop_per_launch": flops / n_launch,
                      "flop_count": "SYRK: tokens * n * (n + 1) per launch"},
