@@ -19,17 +19,19 @@ _MAX_CLAMP_ITERS = 10_000
 def sqrt_M(M: Tensor, ridge_lambda=1e-4, scaled=False, debug: str = "", inverse_sqrt=False):
     """Symmetric square root with an eigenvalue ridge (compression_utils.py:15-55): eigh, lambda += ridge *
     (max lambda if scaled else 1), sqrt(clamp >= 0), V diag V^T; optionally the inverse root with the 1e-12 clamp.
-    Runs the batched LDS Jacobi solver (mdg_sqrt_psd_small); M may be [n, n] or [batch, n, n], n <= 128 even.
-
-    The d_model-sized call the reference makes from compress_vo (compress_vo.py:44) does not exist in this
-    engine -- compress_vo works on the head-sized Gram matrix instead (DESIGN.md "Identities") -- so larger n is
-    rejected loudly rather than served by some other library."""
+    M may be [n, n] or [batch, n, n].  Head-sized inputs (even n <= 128) run the batched LDS Jacobi solver
+    (mdg_sqrt_psd_small); anything else goes through the block-Jacobi solver (mdg_sqrt_psd_large), one matrix at a
+    time.  The d_model-sized call the reference makes from compress_vo (compress_vo.py:44) is supported but this
+    engine's own compress_vo never makes it (DESIGN.md "Identities")."""
     n = M.shape[-1]
-    if n > 128 or n % 2:
-        raise NotImplementedError(
-            f"sqrt_M: n={n} is outside the device solver's range (even n <= 128). The hot path never needs it: "
-            "compress_vo uses the Gram identity and compress_qk the diagonal identity.")
-    root, inv_root, lam = ops.sqrt_psd_small(M, ridge_lambda, scaled, inverse_sqrt)
+    if n <= 128 and n % 2 == 0:
+        root, inv_root, lam = ops.sqrt_psd_small(M, ridge_lambda, scaled, inverse_sqrt)
+    else:
+        mats = M.reshape(-1, n, n)
+        parts = [ops.sqrt_psd_large(m, ridge_lambda, scaled, inverse_sqrt) for m in mats]
+        root = torch.stack([p[0] for p in parts]).reshape(M.shape)
+        inv_root = torch.stack([p[1] for p in parts]).reshape(M.shape) if inverse_sqrt else None
+        lam = torch.stack([p[2].sort(descending=True).values for p in parts])
     if debug or bool((lam[..., -1] < 0).any()):
         lam_h = lam.reshape(-1, n).cpu()
         for row in lam_h:

@@ -3,6 +3,8 @@
 // of the path after the Gram reformulation (DESIGN.md "Identities"): VO's thin SVD (compress_vo.py:130,187,194)
 // and sqrt_M at head size (compression_utils.py:21).  The north_star keeps the eigensolve off the MFMA; this is
 // a latency/LDS kernel.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace mdg {
@@ -12,8 +14,11 @@ constexpr int JP = JN + 1;   // LDS pitch
 constexpr int JT = 512;      // threads
 
 // A [batch][n][n] (lower triangle read, buffer then reused as V^T scratch), evals desc, evecs columns.
+// sorted != 0: eigenvalues descending (ties by index); sorted == 0: eigenvalue j stays in position j, so for a
+// nearly diagonal input the eigenvector matrix is a small rotation -- what block Jacobi needs (a sorting solver acts
+// as a permutation there and shuffles off-diagonal mass around the schedule instead of annihilating it).
 __global__ __launch_bounds__(JT) void syevj_kernel(double* Ag, int n, double* evals, double* evecs, int* info,
-                                                   int max_sweeps) {
+                                                   int max_sweeps, int sorted) {
   __shared__ double a[JN * JP];
   __shared__ double cs_c[JN / 2], cs_s[JN / 2];
   __shared__ int pr[JN / 2], qr[JN / 2];
@@ -110,11 +115,12 @@ __global__ __launch_bounds__(JT) void syevj_kernel(double* Ag, int n, double* ev
   // descending order, ties by index
   if (tid < n) {
     const double mine = a[tid * JP + tid];
-    int pos = 0;
-    for (int k = 0; k < n; k++) {
-      const double o = a[k * JP + k];
-      pos += (o > mine || (o == mine && k < tid)) ? 1 : 0;
-    }
+    int pos = sorted ? 0 : tid;
+    if (sorted)
+      for (int k = 0; k < n; k++) {
+        const double o = a[k * JP + k];
+        pos += (o > mine || (o == mine && k < tid)) ? 1 : 0;
+      }
     order[pos] = tid;
     ev[pos] = mine;
   }
@@ -153,11 +159,13 @@ __global__ __launch_bounds__(256) void sqrt_rebuild_kernel(const double* evals, 
   }
 }
 
-int syevj_batched(double* A, int64_t n, int64_t batch, double* evals, double* evecs, int* dflag, hipStream_t st) {
+int syevj_batched(double* A, int64_t n, int64_t batch, double* evals, double* evecs, int* dflag, hipStream_t st,
+                  int max_sweeps = 40, int sorted = 1) {
   MDG_CHECK_ARG(n >= 2 && n <= JN && n % 2 == 0, "syevj: n=%lld must be even and in [2, 128]", (long long)n);
   MDG_CHECK_ARG(batch > 0 && batch < (1ll << 31), "syevj: bad batch");
   MDG_HIP(hipMemsetAsync(dflag, 0, sizeof(int), st));
-  hipLaunchKernelGGL(syevj_kernel, dim3((unsigned)batch), dim3(JT), 0, st, A, (int)n, evals, evecs, dflag, 40);
+  hipLaunchKernelGGL(syevj_kernel, dim3((unsigned)batch), dim3(JT), 0, st, A, (int)n, evals, evecs, dflag, max_sweeps,
+                     sorted);
   MDG_LAUNCH_CHECK();
   return MDG_OK;
 }
@@ -173,6 +181,189 @@ int check_flag(int* dflag, hipStream_t st, const char* what) {
   return MDG_OK;
 }
 
+
+// ---------------------------------------------------------------- large n: block Jacobi out of the pieces above
+// sqrt_M at d_model size (the reference calls it from compress_vo.py:44; this engine's VO stage does not need it, the
+// entry exists so the function keeps its full domain).  Two-sided block Jacobi on 64-wide blocks: neighbouring blocks
+// (2i, 2i+1) form 128x128 sub-problems solved by syevj_kernel, their rotations are applied to block rows / columns
+// and to V by three batched GEMMs, then the blocks are physically rotated round-robin so that after nb-1 rounds every
+// pair has met.  Everything is uniform-stride batched work; no per-pair launches.
+int gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const void* A, int a_dtype, int64_t sa_i, int64_t sa_k,
+             const int64_t* a_rows, const void* B, int b_dtype, int64_t sb_k, int64_t sb_j, double beta, void* C,
+             int c_dtype, int64_t ldc, int64_t batch, int64_t a_bs, int64_t b_bs, int64_t c_bs, int flags,
+             hipStream_t st);
+
+__global__ __launch_bounds__(256) void bj_init_kernel(const double* M, int64_t n, int64_t ld, double* A, double* V,
+                                                      int64_t np) {
+  const int64_t i = blockIdx.x;
+  for (int64_t j = threadIdx.x; j < np; j += 256) {
+    double v = 0.;
+    if (i < n && j < n) v = (j <= i) ? M[i * ld + j] : M[j * ld + i];  // lower triangle is authoritative
+    A[i * np + j] = v;
+    V[i * np + j] = (i == j) ? 1. : 0.;
+  }
+}
+
+__global__ __launch_bounds__(256) void bj_extract_diag_kernel(const double* A, int64_t np, double* D) {
+  const int64_t b = blockIdx.x;
+  const double* src = A + b * 128 * np + b * 128;
+  for (int e = threadIdx.x; e < 128 * 128; e += 256) D[b * 128 * 128 + e] = src[(int64_t)(e / 128) * np + e % 128];
+}
+
+// dst[I][J] = src[rowmap(I)][colmap(J)] with the maps acting on 64-wide blocks (perm == nullptr -> identity on rows)
+__global__ __launch_bounds__(256) void bj_permute_kernel(const double* src, double* dst, int64_t np, const int* row_perm,
+                                                         const int* col_perm) {
+  const int64_t i = blockIdx.x;
+  const int64_t si = row_perm ? (int64_t)row_perm[i >> 6] * 64 + (i & 63) : i;
+  for (int64_t j = threadIdx.x; j < np; j += 256) {
+    const int64_t sj = (int64_t)col_perm[j >> 6] * 64 + (j & 63);
+    dst[i * np + j] = src[si * np + sj];
+  }
+}
+
+// red[0] += sum of squares of the off-diagonal, red[1] += of everything (one workgroup per row)
+__global__ __launch_bounds__(256) void bj_offnorm_kernel(const double* A, int64_t np, double* red) {
+  __shared__ double s0[256], s1[256];
+  const int64_t i = blockIdx.x;
+  double off = 0., tot = 0.;
+  for (int64_t j = threadIdx.x; j < np; j += 256) {
+    const double v = A[i * np + j];
+    tot += v * v;
+    if (j != i) off += v * v;
+  }
+  s0[threadIdx.x] = off;
+  s1[threadIdx.x] = tot;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      s0[threadIdx.x] += s0[threadIdx.x + o];
+      s1[threadIdx.x] += s1[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    atomicAdd(&red[0], s0[0]);
+    atomicAdd(&red[1], s1[0]);
+  }
+}
+
+// W[:, j] = V[:, j] * f(lambda_j), W2 likewise with g; lambda = diag(A); single workgroup computes max first
+__global__ __launch_bounds__(256) void bj_scale_kernel(const double* A, const double* V, int64_t np, int64_t n, double ridge,
+                                                       int scaled, double* W, double* W2, double* evals_out) {
+  __shared__ double red[256];
+  double mx = -1e300;
+  for (int64_t j = threadIdx.x; j < np; j += 256) mx = fmax(mx, A[j * np + j]);
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  const double scale = scaled ? red[0] : 1.0;
+  const int64_t i = blockIdx.x;
+  for (int64_t j = threadIdx.x; j < np; j += 256) {
+    const double lam = A[j * np + j];
+    const double l = lam + ridge * scale;
+    const double rt = sqrt(l > 0. ? l : 0.);
+    const double v = V[i * np + j];
+    W[i * np + j] = v * rt;
+    if (W2) W2[i * np + j] = v / (rt > 1e-12 ? rt : 1e-12);
+    if (i == 0 && evals_out && j < np) evals_out[j] = lam;
+  }
+}
+
+}  // namespace mdg
+
+using namespace mdg;
+
+extern "C" size_t mdg_sqrt_psd_large_ws_bytes(int64_t n) {
+  const size_t np = (size_t)ceil_div(n, 128) * 128;
+  return (4 * np * np + 2 * (np / 128) * 128 * 128 + np + 64) * sizeof(double) + 2 * (np / 64) * sizeof(int) + 256;
+}
+
+extern "C" int mdg_sqrt_psd_large(const double* M, int64_t n, int64_t ld, double ridge, int scaled, double* root,
+                                  double* inv_root, double* evals_out, void* ws, size_t ws_bytes, void* stream) {
+  MDG_CLEAR();
+  MDG_CHECK_ARG(M && root && n > 0 && ld >= n, "mdg_sqrt_psd_large: bad arguments");
+  MDG_CHECK_ARG(ws && ws_bytes >= mdg_sqrt_psd_large_ws_bytes(n), "mdg_sqrt_psd_large: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t np = ceil_div(n, 128) * 128, m = np / 128, nb = 2 * m;
+  double* A = (double*)ws;
+  double* A2 = A + np * np;
+  double* V = A2 + np * np;
+  double* V2 = V + np * np;
+  double* D = V2 + np * np;
+  double* J = D + m * 128 * 128;
+  double* ev = J + m * 128 * 128;
+  double* red = ev + np;          // [0] off^2, [1] total^2
+  int* dflag = (int*)(red + 8);
+  int* perm = (int*)(red + 16);   // round-robin source block of every destination block
+  // round-robin rotation of the 64-blocks: pairs are (2i, 2i+1); block 0 stays, the others move one seat
+  {
+    int host_perm[2 * 1024];
+    MDG_CHECK_ARG(nb <= 2 * 1024, "mdg_sqrt_psd_large: n too large");
+    for (int64_t i = 0; i < m; i++) {
+      host_perm[2 * i] = (i == 0) ? 0 : (i == 1 ? 1 : (int)(2 * (i - 1)));
+      host_perm[2 * i + 1] = (i < m - 1) ? (int)(2 * (i + 1) + 1) : (int)(2 * (m - 1));
+    }
+    if (m == 1) { host_perm[0] = 0; host_perm[1] = 1; }
+    MDG_HIP(hipMemcpyAsync(perm, host_perm, nb * sizeof(int), hipMemcpyHostToDevice, st));
+    MDG_HIP(hipStreamSynchronize(st));  // host_perm is a stack array
+  }
+  hipLaunchKernelGGL(bj_init_kernel, dim3((unsigned)np), dim3(256), 0, st, M, n, ld, A, V, np);
+  MDG_LAUNCH_CHECK();
+  const int64_t bs_rows = 128 * np, bs_cols = 128, bs_blk = 128 * 128;
+  const int rounds = nb > 2 ? (int)(nb - 1) : 1;
+  bool done = false;
+  for (int sweep = 0; sweep < 30 && !done; sweep++) {
+    for (int r = 0; r < rounds; r++) {
+      hipLaunchKernelGGL(bj_extract_diag_kernel, dim3((unsigned)m), dim3(256), 0, st, A, np, D);
+      MDG_LAUNCH_CHECK();
+      MDG_TRY(syevj_batched(D, 128, m, ev, J, dflag, st, 6, 0));  // partial, UNSORTED inner solves
+      // A2 = blockdiag(J)^T A     (block rows)
+      MDG_TRY(gemm_f64(128, np, 128, 1.0, J, MDG_F64, 1, 128, nullptr, A, MDG_F64, np, 1, 0.0, A2, MDG_F64, np, m, bs_blk,
+                       bs_rows, bs_rows, 0, st));
+      // A = A2 blockdiag(J)       (block columns)
+      MDG_TRY(gemm_f64(np, 128, 128, 1.0, A2, MDG_F64, np, 1, nullptr, J, MDG_F64, 128, 1, 0.0, A, MDG_F64, np, m, bs_cols,
+                       bs_blk, bs_cols, 0, st));
+      // V2 = V blockdiag(J)
+      MDG_TRY(gemm_f64(np, 128, 128, 1.0, V, MDG_F64, np, 1, nullptr, J, MDG_F64, 128, 1, 0.0, V2, MDG_F64, np, m, bs_cols,
+                       bs_blk, bs_cols, 0, st));
+      if (nb > 2) {
+        hipLaunchKernelGGL(bj_permute_kernel, dim3((unsigned)np), dim3(256), 0, st, A, A2, np, perm, perm);
+        hipLaunchKernelGGL(bj_permute_kernel, dim3((unsigned)np), dim3(256), 0, st, V2, V, np, (const int*)nullptr, perm);
+        MDG_LAUNCH_CHECK();
+        double* t = A; A = A2; A2 = t;
+      } else {
+        double* t = V; V = V2; V2 = t;
+      }
+    }
+    MDG_HIP(hipMemsetAsync(red, 0, 2 * sizeof(double), st));
+    hipLaunchKernelGGL(bj_offnorm_kernel, dim3((unsigned)np), dim3(256), 0, st, A, np, red);
+    MDG_LAUNCH_CHECK();
+    double h[2];
+    MDG_HIP(hipMemcpyAsync(h, red, sizeof(h), hipMemcpyDeviceToHost, st));
+    MDG_HIP(hipStreamSynchronize(st));
+    if (getenv("MDG_DEBUG_JACOBI")) fprintf(stderr, "block-jacobi sweep %d: off^2 %.3e tot^2 %.3e\n", sweep, h[0], h[1]);
+    done = h[0] <= 1e-26 * h[1] || h[1] == 0.;  // ||off||_F <= 1e-13 ||A||_F
+  }
+  if (!done) {
+    set_error("mdg_sqrt_psd_large: block Jacobi did not converge in 30 sweeps");
+    return MDG_ERR_NO_CONVERGE;
+  }
+  // root = (V f(lambda)) V^T ; inverse root likewise.  W lives in A2 / V2 (both free now).
+  hipLaunchKernelGGL(bj_scale_kernel, dim3((unsigned)np), dim3(256), 0, st, A, V, np, n, ridge, scaled, A2,
+                     inv_root ? V2 : (double*)nullptr, evals_out ? ev : (double*)nullptr);
+  MDG_LAUNCH_CHECK();
+  MDG_TRY(gemm_f64(n, n, np, 1.0, A2, MDG_F64, np, 1, nullptr, V, MDG_F64, 1, np, 0.0, root, MDG_F64, n, 1, 0, 0, 0, 0, st));
+  if (inv_root)
+    MDG_TRY(gemm_f64(n, n, np, 1.0, V2, MDG_F64, np, 1, nullptr, V, MDG_F64, 1, np, 0.0, inv_root, MDG_F64, n, 1, 0, 0, 0, 0,
+                     st));
+  if (evals_out) MDG_HIP(hipMemcpyAsync(evals_out, ev, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+  return MDG_OK;
+}
+
+namespace mdg {
 }  // namespace mdg
 
 using namespace mdg;

@@ -15,7 +15,8 @@ int gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const void* A, int a
              const int64_t* a_rows, const void* B, int b_dtype, int64_t sb_k, int64_t sb_j, double beta, void* C,
              int c_dtype, int64_t ldc, int64_t batch, int64_t a_bs, int64_t b_bs, int64_t c_bs, int flags,
              hipStream_t st);
-int syevj_batched(double* A, int64_t n, int64_t batch, double* evals, double* evecs, int* dflag, hipStream_t st);
+int syevj_batched(double* A, int64_t n, int64_t batch, double* evals, double* evecs, int* dflag, hipStream_t st,
+                  int max_sweeps = 40, int sorted = 1);
 int check_flag(int* dflag, hipStream_t st, const char* what);
 
 // dst (f64, ld) = scale * src (bf16, ld_src)

@@ -159,6 +159,25 @@ def sqrt_psd_small(M: torch.Tensor, ridge: float, scaled: bool, want_inverse: bo
     return root.reshape(M.shape), (None if inv_root is None else inv_root.reshape(M.shape)), evals
 
 
+def sqrt_psd_large(M: torch.Tensor, ridge: float, scaled: bool, want_inverse: bool):
+    """sqrt_M for one symmetric matrix of any size (block Jacobi): returns (root, inv_root or None, evals unsorted)."""
+    _need_gpu(M)
+    lib = _lib.load()
+    if M.dim() != 2 or M.shape[0] != M.shape[1]:
+        raise ValueError("sqrt_psd_large expects one square matrix")
+    M2 = M if (M.dtype == torch.float64 and M.stride(1) == 1) else M.to(torch.float64).contiguous()
+    n = M2.shape[0]
+    root = torch.empty(n, n, dtype=torch.float64, device=M.device)
+    inv_root = torch.empty(n, n, dtype=torch.float64, device=M.device) if want_inverse else None
+    evals = torch.empty(n, dtype=torch.float64, device=M.device)
+    nbytes = lib.mdg_sqrt_psd_large_ws_bytes(n)
+    ws, wsp = _ws(nbytes, M.device)
+    with torch.cuda.device(M.device):
+        check(lib.mdg_sqrt_psd_large(M2.data_ptr(), n, M2.stride(0), float(ridge), int(scaled), root.data_ptr(),
+                                     _p(inv_root), evals.data_ptr(), wsp, nbytes, _stream(M)), "mdg_sqrt_psd_large")
+    return root, inv_root, evals
+
+
 # ------------------------------------------------------------------ MLP
 def ridge_scores(Cm: torch.Tensor, ridge: float) -> torch.Tensor:
     """diag((C + ridge I)^-1) for a symmetric PD fp64 matrix."""

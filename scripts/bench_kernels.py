@@ -67,3 +67,8 @@ if "cov1r" in which:
     t = timeit(lambda: ops.cov_accum(S1, X), n=3)
     ex = 496 * 128 * 128 * 2 * 131072
     print(f"cov 1-round {131072}x{n}: {t*1e3:.1f} ms  {131072*n*(n+1)/t/1e12:.1f} TF syrk, executed {ex/t/1e12:.1f} TF on 496/512 slots -> {ex/t/1e12*512/496:.1f} TF-equivalent")
+if "sqrt" in which:
+    import time
+    X = acts(16384, 4096).double(); M = X.T @ X / 16384
+    t0 = time.time(); r, ri, lam = ops.sqrt_psd_large(M, 1e-5, False, True); torch.cuda.synchronize()
+    print(f"sqrt_psd_large n=4096: {time.time()-t0:.2f} s; check ||r r - (M + rho I)||/||M|| = {((r @ r - M - 1e-5*torch.eye(4096, device=dev, dtype=F64)).norm()/M.norm()).item():.2e}")

@@ -291,3 +291,34 @@ def test_probe(ops, dev):
     tf = ops.probe_mfma_f64(2048)
     print(f"fp64 MFMA probe: {tf:.1f} TFLOP/s")
     assert 20 < tf < 200
+
+
+@pytest.mark.parametrize("n", [130, 200, 384, 1024])
+def test_sqrt_psd_large(ops, dev, n):
+    """sqrt_M beyond head size (block Jacobi) against the oracle's eigh route, incl. a rank-deficient input."""
+    gen = torch.Generator().manual_seed(n)
+    t = n // 2 if n == 200 else 3 * n          # n == 200: fewer tokens than features -> singular sigma
+    X = acts(gen, t, n).double()
+    M = X.T @ X / t
+    want_s, want_i = O.sqrt_M(M, 1e-5, inverse_sqrt=True)
+    root, inv, lam = ops.sqrt_psd_large(M.to(dev), 1e-5, False, True)
+    assert rel(root, want_s) < 1e-10
+    assert rel(inv, want_i) < 1e-7
+    assert rel(lam.sort().values, torch.linalg.eigvalsh(M)) < 1e-11
+    want_sc = O.sqrt_M(M, 1e-3, scaled=True)
+    root2, _, _ = ops.sqrt_psd_large(M.to(dev), 1e-3, True, False)
+    assert rel(root2, want_sc) < 1e-10
+
+
+def test_sqrt_M_surface_dispatch(dev):
+    """compression_utils.sqrt_M keeps the reference's full domain: batched head-size and d_model-size inputs."""
+    from modegpt_amd.compression_utils import sqrt_M
+    gen = torch.Generator().manual_seed(4)
+    X = acts(gen, 900, 256).double()
+    M = X.T @ X / 900
+    s, si = sqrt_M(M.to(dev), ridge_lambda=1e-4, inverse_sqrt=True)
+    ws, wi = O.sqrt_M(M, 1e-4, inverse_sqrt=True)
+    assert rel(s, ws) < 1e-10 and rel(si, wi) < 1e-7
+    Mh = torch.stack([M[:64, :64], M[64:128, 64:128]])
+    sh = sqrt_M(Mh.to(dev))
+    assert rel(sh[1], O.sqrt_M(Mh[1])) < 1e-10
