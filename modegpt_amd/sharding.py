@@ -103,11 +103,12 @@ def unpack_layer(rec: torch.Tensor) -> Tuple[int, Dict[str, torch.Tensor], Optio
     return layer_idx, out, mask
 
 
-def allgather_records(records: List[torch.Tensor], per_rank: int, world: int) -> List[torch.Tensor]:
-    """The single data-path collective: every rank contributes `per_rank` records padded to a common stride."""
+def allgather_records(records: List[torch.Tensor], per_rank: int, world: int, force_collective: bool = False) -> List[torch.Tensor]:
+    """The single data-path collective: every rank contributes `per_rank` records padded to a common stride.
+    force_collective runs the all-gather even at world == 1 (lets a 1-GPU box exercise the RCCL code path)."""
     dev = records[0].device if records else torch.device("cuda" if torch.cuda.is_available() else "cpu")
     longest = torch.tensor([max([r.numel() for r in records] + [0])], dtype=torch.int64, device=dev)
-    if world > 1:
+    if world > 1 or force_collective:
         dist.all_reduce(longest, op=dist.ReduceOp.MAX)  # 8-byte size agreement, not a data-path exchange
     stride = (int(longest.item()) + 3) // 4 * 4          # rows stay 8-byte aligned for the int64 header views
     PRE = 4                                                 # words 0..3: slot-in-use flag (+ alignment pad)
@@ -115,7 +116,7 @@ def allgather_records(records: List[torch.Tensor], per_rank: int, world: int) ->
     for i, r in enumerate(records):
         send[i, 0] = 1
         send[i, PRE:PRE + r.numel()] = r
-    if world == 1:
+    if world == 1 and not force_collective:
         return [send[i, PRE:] for i in range(per_rank) if send[i, 0] == 1]
     recv = torch.empty(world * per_rank, PRE + stride, dtype=torch.int16, device=dev)
     # byte views: every backend moves uint8 (gloo has no int16)

@@ -288,3 +288,38 @@ def test_full_size_vo_properties(dev):
             assert rel(o64[:, qh * r:(qh + 1) * r] @ vh, full @ P.T) < 1e-7
         assert lam.min().item() > 0 and got.min().item() >= -1e-12
     assert torch.equal(v.cpu(), v64.cpu().to(torch.bfloat16)) and torch.equal(o.cpu(), o64.cpu().to(torch.bfloat16))
+
+
+def test_rccl_allgather_path_single_rank(dev):
+    """The N > 1 collective code (RCCL all-reduce of the stride + all_gather_into_tensor of the packed records) run
+    on a 1-rank nccl group: same calls, same tensors, one GPU."""
+    import socket
+    import torch.distributed as dist
+    from modegpt_amd import sharding as S
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        g = torch.Generator().manual_seed(0)
+        recs, want = [], []
+        for i, r in enumerate((5, 9)):
+            t = {"up": torch.randn(r, 16, generator=g).bfloat16().to(dev), "gate": None,
+                 "down": torch.randn(16, r, generator=g).bfloat16().to(dev),
+                 "q_proj": torch.randn(2 * r, 16, generator=g).bfloat16().to(dev)}
+            m = (torch.arange(2 * r).reshape(2, r) + i).to(dev)
+            recs.append(S.pack_layer(7 + i, t, m))
+            want.append((7 + i, t, m))
+        out = S.allgather_records(recs, 2, 1, force_collective=True)
+        assert len(out) == 2
+        for rec, (li, t, m) in zip(out, want):
+            idx, tensors, mask = S.unpack_layer(rec)
+            assert idx == li and torch.equal(mask, m)
+            for k, v in t.items():
+                if v is not None:
+                    assert torch.equal(tensors[k], v)
+    finally:
+        dist.destroy_process_group()
