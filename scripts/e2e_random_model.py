@@ -59,7 +59,10 @@ del cov_mlp, cov_q, cov_k, cov_x
 t0 = time.time(); ad.convert_model(saved_layers_dir=ad.config.temp_storage_dir); ad.patch_config(); t_cv = time.time() - t0
 cfg = model.config
 print(f"convert_model + patch_config: {t_cv:.1f} s; gate_ranks[:4] {cfg.gate_ranks[:4]} q_ranks[:2] {cfg.q_ranks[:2]} v_ranks[:2] {cfg.v_ranks[:2]} mask {tuple(masks[0].shape)}")
-# (the compressed model cannot run under the stock HF modeling code: per-layer head dims / ranks need the reference's
-#  *Rebuild.py modeling files, which ship with the checkpoint -- out of scope here)
+from modegpt_amd.patchers import install_compressed_attention
+from modegpt_amd.eval import compute_perplexity
+install_compressed_attention(ad, masks)
+t0 = time.time(); ppl = compute_perplexity(model, None, dataset="synthetic", adapter=ad, batch_size=4); t_ppl = time.time() - t0
+print(f"compressed model, in-process compressed attention: synthetic-token perplexity {ppl:.1f} (random weights; vocab 32000) in {t_ppl:.1f} s")
 print(f"TOTAL {t_cal + t_mlp + t_qk + t_vo:.1f} s for {L} layers = {L / (t_cal + t_mlp + t_qk + t_vo):.3f} layers/s (model forward and artefact IO included)")
 shutil.rmtree(tmp, ignore_errors=True)

@@ -55,7 +55,7 @@ def test_dropin_functions_on_golden(dev, name):
 
 
 # ---------------------------------------------------------------- random-init HF model through load_calibs
-def _tiny_model(kind, dev):
+def _tiny_model(kind, dev, init_std=0.02):
     transformers = pytest.importorskip("transformers")
     torch.manual_seed(0)
     if kind == "opt":
@@ -64,12 +64,14 @@ def _tiny_model(kind, dev):
         m = transformers.OPTForCausalLM(cfg)
     elif kind == "qwen3":
         cfg = transformers.Qwen3Config(hidden_size=128, intermediate_size=320, num_hidden_layers=2, num_attention_heads=4,
-                                       num_key_value_heads=2, head_dim=32, vocab_size=211, max_position_embeddings=64)
+                                       num_key_value_heads=2, head_dim=32, vocab_size=211, max_position_embeddings=64,
+                                       initializer_range=init_std)
         m = transformers.Qwen3ForCausalLM(cfg)
     else:
         kv = 2 if kind == "llama_gqa" else 4
         cfg = transformers.LlamaConfig(hidden_size=128, intermediate_size=320, num_hidden_layers=2, num_attention_heads=4,
-                                       num_key_value_heads=kv, head_dim=32, vocab_size=211, max_position_embeddings=64)
+                                       num_key_value_heads=kv, head_dim=32, vocab_size=211, max_position_embeddings=64,
+                                       initializer_range=init_std)
         m = transformers.LlamaForCausalLM(cfg)
     return m.to(dev).to(torch.bfloat16).eval()
 
@@ -323,3 +325,83 @@ def test_rccl_allgather_path_single_rank(dev):
                     assert torch.equal(tensors[k], v)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["llama_gqa", "llama_mha", "qwen3"])
+def test_keep_everything_reproduces_the_model(dev, kind, tmp_path):
+    """compression_ratio = 0: every stage keeps full rank, so the compressed model (Nystrom refit with all columns,
+    q/k columns PERMUTED into score order with RoPE cos/sin gathered by the rotary mask, V/O re-factored through the
+    full SVD) must reproduce the original logits up to bf16 rounding.  Exercises the artefact layout, the mask order,
+    the GQA head mapping and the in-process compressed attention in one go."""
+    from modegpt_amd.adapters.CompressionConfig import CompressionConfig
+    from modegpt_amd.adapters.model_adapter import ModelAdapter
+    from modegpt_amd.calibration import load_calibs
+    from modegpt_amd.compression.compress_mlp import compress_nystrom
+    from modegpt_amd.compression.compress_qk import compress_qk
+    from modegpt_amd.compression.compress_vo import compress_vo
+    from modegpt_amd.patchers import install_compressed_attention
+
+    # init std 0.15 instead of 0.02: MLP activations of O(1) as in a trained model, so that the ABSOLUTE 1e-6 ridge
+    # of the Nystrom refit (compress_mlp.py:56) is negligible against sigma_mlp's spectrum (with the default tiny
+    # init sigma_mlp ~ 1e-7 and the refit legitimately shrinks down_proj)
+    model = _tiny_model(kind, dev, init_std=0.15)
+    ad = ModelAdapter.from_model(model, None)
+    ad.config = CompressionConfig(temp_storage_dir=str(tmp_path / "layers"), nystrom_ridge=1e-4, ridge_qk=1e-2,
+                                  ridge_vo=1e-5, dataset="synthetic", order="mlp,qk,vo")
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(0, 211, (2, 48), generator=g).to(dev)
+    with torch.no_grad():
+        ref = model(ids).logits.float()
+    cov_mlp, cov_q, cov_k, cov_x, bi = load_calibs(ad, n_samples=8, batch_size=4, dataset="synthetic", target_layers=[])
+    keep = [1.0] * ad.n_layers
+    layers = list(range(ad.n_layers))
+    compress_nystrom(ad, cov_mlp, keep, layers)
+    masks = compress_qk(ad, (cov_q, cov_k), keep, target_layers=layers)
+    compress_vo(ad, cov_x, keep, target_layers=layers)
+    assert masks[0].shape == (ad.n_kv_heads, ad.head_dim)
+    assert sorted(masks[0][0].tolist()) == list(range(ad.head_dim))      # a permutation of all columns
+    ad.convert_model(saved_layers_dir=ad.config.temp_storage_dir)
+    install_compressed_attention(ad, masks)
+    with torch.no_grad():
+        got = model(ids).logits.float()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 5e-2, f"compressed-at-full-rank logits differ by {err:.3e} (bf16 model)"
+    # and a genuinely compressed model still runs
+    model2 = _tiny_model(kind, dev)
+    ad2 = ModelAdapter.from_model(model2, None)
+    ad2.config = CompressionConfig(temp_storage_dir=str(tmp_path / "layers2"), nystrom_ridge=1e-4, ridge_qk=1e-2,
+                                   ridge_vo=1e-5, dataset="synthetic", order="mlp,qk,vo")
+    c = load_calibs(ad2, n_samples=8, batch_size=4, dataset="synthetic", target_layers=[])
+    keep2 = [0.6] * ad2.n_layers
+    compress_nystrom(ad2, c[0], keep2, layers)
+    m2 = compress_qk(ad2, (c[1], c[2]), keep2, target_layers=layers)
+    compress_vo(ad2, c[3], keep2, target_layers=layers)
+    ad2.convert_model(saved_layers_dir=ad2.config.temp_storage_dir)
+    install_compressed_attention(ad2, m2)
+    with torch.no_grad():
+        out = model2(ids).logits
+    assert out.shape == ref.shape and bool(torch.isfinite(out.float()).all())
+
+
+def test_opt_compressed_forward_runs(dev, tmp_path):
+    from modegpt_amd.adapters.CompressionConfig import CompressionConfig
+    from modegpt_amd.adapters.model_adapter import ModelAdapter
+    from modegpt_amd.calibration import load_calibs
+    from modegpt_amd.compression.compress_mlp import compress_nystrom
+    from modegpt_amd.compression.compress_qk import compress_qk
+    from modegpt_amd.compression.compress_vo import compress_vo
+    from modegpt_amd.patchers import install_compressed_attention
+    model = _tiny_model("opt", dev)
+    ad = ModelAdapter.from_model(model, None)
+    ad.config = CompressionConfig(temp_storage_dir=str(tmp_path / "l"), dataset="synthetic", order="mlp,qk,vo")
+    c = load_calibs(ad, n_samples=8, batch_size=4, dataset="synthetic", target_layers=[])
+    keep, layers = [0.75] * ad.n_layers, list(range(ad.n_layers))
+    compress_nystrom(ad, c[0], keep, layers)
+    compress_qk(ad, (c[1], c[2]), keep, target_layers=layers)
+    compress_vo(ad, c[3], keep, target_layers=layers)
+    ad.convert_model(saved_layers_dir=ad.config.temp_storage_dir)
+    install_compressed_attention(ad, None)
+    ids = torch.randint(0, 211, (2, 32)).to(dev)
+    with torch.no_grad():
+        out = model(ids).logits
+    assert out.shape[:2] == (2, 32) and bool(torch.isfinite(out.float()).all())
