@@ -405,3 +405,39 @@ def test_opt_compressed_forward_runs(dev, tmp_path):
     with torch.no_grad():
         out = model(ids).logits
     assert out.shape[:2] == (2, 32) and bool(torch.isfinite(out.float()).all())
+
+
+@pytest.mark.parametrize("name,keep", [("qwen3-14b", 0.7), ("llama-2-7b", 0.7)])
+def test_other_baseline_shapes_one_layer(dev, name, keep):
+    """BASELINE configs #2 / #5 at their real layer shapes (d = 5120 / d_ff = 17408; the MHA two-SVD VO path with
+    32 kv heads), 16384 calibration tokens: the drop-in functions run and satisfy the size-independent invariants."""
+    from modegpt_amd import engine, ops
+    shape = dict(engine.SHAPES[name])
+    w = engine.make_layer_weights(shape, 7, dev)
+    ad = engine.TensorAdapter(shape, {0: w})
+    covs = engine.new_covs(shape, dev)
+    for b in range(2):
+        engine.accumulate(covs, engine.make_activation_batch(shape, 8192, seed=90 + b, device=dev), shape)
+    engine.finalize(covs, 8)
+    assert torch.equal(covs["mlp"], covs["mlp"].T)
+    out, mask = engine.compress_layer(ad, 0, covs, keep)
+    f, d, nh, nkv, hd = shape["d_ff"], shape["d"], shape["n_heads"], shape["n_kv_heads"], shape["head_dim"]
+    r_mlp, r = int(f * keep), 88
+    assert out["up"].shape == (r_mlp, d) and out["gate"].shape == (r_mlp, d) and out["down"].shape == (d, r_mlp)
+    assert out["q_proj"].shape == (nh * r, d) and out["k_proj"].shape == (nkv * r, d)
+    assert out["v_proj"].shape == (nkv * r, d) and out["o_proj"].shape == (d, nh * r)
+    assert mask.shape == (nkv, r) and int(mask.max()) < hd
+    for h in range(nkv):                                   # RoPE pairing: second half = first half + hd/2
+        assert torch.equal(mask[h, r // 2:], mask[h, : r // 2] + hd // 2)
+    # selected up rows are rows of W_up in ascending index order
+    idx = ops.select_smallest_sorted(ops.ridge_scores(covs["mlp"], float(torch.tensor(1e-4, dtype=torch.float32).double())), r_mlp)
+    assert torch.equal(out["up"], w["up"][idx]) and bool((idx[1:] > idx[:-1]).all())
+    # VO invariant on two heads: v' (Sigma_x + rho) v'^T = I_r up to the bf16 rounding of v'
+    Cr = covs["x"].clone()
+    Cr.diagonal().add_(1e-5)
+    for h in (0, nkv - 1):
+        vh = out["v_proj"][h * r:(h + 1) * r].double()
+        G = vh @ Cr @ vh.T
+        assert (G - torch.eye(r, dtype=F64, device=dev)).abs().max().item() < 0.1
+    for t in out.values():
+        assert bool(torch.isfinite(t.float()).all())
