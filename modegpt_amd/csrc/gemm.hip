@@ -2,6 +2,8 @@
 // (Cholesky trailing updates, TRSM by inverted diagonal blocks, triangular inverse, Nystrom cross term
 // C[idx,:] @ W_d^T with fused row gather, VO Gram / factor products with fused bf16 load and store).
 // Same 128x128 workgroup tile / 4-wave / LDS-fp64-panel core as cov.hip.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace mdg {
@@ -18,6 +20,7 @@ struct GemmArgs {
   int64_t ldc;
   int64_t a_bs, b_bs, c_bs;
   int flags, tiles_m, tiles_n, c_dtype;
+  int fast_ok;  // operands satisfy the 16-byte alignment rules of the vector staging path (host-checked)
 };
 
 // Stage one BKx128 panel: element (x, k) of the operand lives at base + off(x) + k*sk.
@@ -47,6 +50,155 @@ __device__ __forceinline__ void gemm_store_panel(double* panel, int tid, const d
     int x = kcontig ? (e / BK) : (e % TILE);
     panel[k * PITCH + x] = regs[p];
   }
+}
+
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const Acc& acc, int64_t batch, int64_t i0, int64_t j0,
+                                              int wr, int wc, int lane) {
+  const bool c_bf16 = (g.c_dtype == MDG_BF16);
+  char* Cb = (char*)g.C + batch * g.c_bs * (c_bf16 ? 2 : 8);
+#pragma unroll
+  for (int sa = 0; sa < 4; sa++)
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+      int64_t gr = i0 + acc_row(wr, lane, sa, reg);
+      if (gr >= g.M) continue;
+      int64_t gc0 = j0 + acc_col(wc, lane, 0);
+      int64_t e0 = gr * g.ldc + gc0;
+#pragma unroll
+      for (int sb = 0; sb < 4; sb++) {
+        if (gc0 + sb >= g.N) continue;
+        double v = g.alpha * acc.v[sa][sb][reg];
+        if (!c_bf16) {
+          double* dst = (double*)Cb + e0 + sb;
+          if (g.beta != 0.) v += g.beta * *dst;
+          *dst = v;
+        } else {
+          ((bf16_t*)Cb)[e0 + sb] = f64_to_bf16(v);
+        }
+      }
+    }
+}
+
+// ---------------------------------------------------------------- vector staging for interior tiles
+// Same lesson as the covariance kernel: every staging instruction costs MFMA issue slots.  Interior tiles whose k-range
+// is a whole number of stages take this path: 16-byte global loads at (uniform base + constant per-lane 32-bit
+// offset) -- the base lives in SGPRs and is bumped by scalar adds, so a load costs no VALU -- no bounds tests, no
+// offset-table reads, static buffer parity.
+template <int DT, bool KC> struct FastPanel;
+
+template <bool KC> struct FastPanel<MDG_F64, KC> {
+  d2 r[4];
+  unsigned voff[4];  // byte offsets from the stage base
+  int lo[4];         // LDS element index of the first value
+  __device__ __forceinline__ void init(int64_t sx, int64_t sk, int64_t x0, const int64_t* rows, int tid) {
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      const int e = tid + 256 * p;
+      if (KC) {
+        const int kp = e & 7, x = e >> 3;
+        const int64_t row = rows ? rows[x0 + x] : x0 + x;
+        voff[p] = (unsigned)((row * sx + 2 * kp) * 8);
+        lo[p] = (2 * kp) * PITCH + x;
+      } else {
+        const int xp = e & 63, k = e >> 6;
+        voff[p] = (unsigned)((k * sk + x0 + 2 * xp) * 8);
+        lo[p] = k * PITCH + 2 * xp;
+      }
+    }
+  }
+  __device__ __forceinline__ void load(const char* base) {
+#pragma unroll
+    for (int p = 0; p < 4; p++) r[p] = *(const d2*)(base + voff[p]);
+  }
+  __device__ __forceinline__ void store(double* panel) const {
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      if (KC) {
+        panel[lo[p]] = r[p].x;
+        panel[lo[p] + PITCH] = r[p].y;
+      } else {
+        *(d2*)(panel + lo[p]) = r[p];
+      }
+    }
+  }
+  static __device__ __forceinline__ int64_t stage_bytes(int64_t sk) { return (KC ? BK : BK * sk) * 8; }
+};
+
+template <bool KC> struct FastPanel<MDG_BF16, KC> {
+  uint4 r;
+  unsigned voff;
+  int lo;
+  __device__ __forceinline__ void init(int64_t sx, int64_t sk, int64_t x0, const int64_t* rows, int tid) {
+    if (KC) {
+      const int kp = tid & 1, x = tid >> 1;
+      const int64_t row = rows ? rows[x0 + x] : x0 + x;
+      voff = (unsigned)((row * sx + 8 * kp) * 2);
+      lo = (8 * kp) * PITCH + x;
+    } else {
+      const int xp = tid & 15, k = tid >> 4;
+      voff = (unsigned)((k * sk + x0 + 8 * xp) * 2);
+      lo = k * PITCH + 8 * xp;
+    }
+  }
+  __device__ __forceinline__ void load(const char* base) { r = *(const uint4*)(base + voff); }
+  __device__ __forceinline__ void store(double* panel) const {
+    const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const double v0 = (double)__uint_as_float(w[q] << 16), v1 = (double)__uint_as_float(w[q] & 0xffff0000u);
+      if (KC) {
+        panel[lo + (2 * q) * PITCH] = v0;
+        panel[lo + (2 * q + 1) * PITCH] = v1;
+      } else {
+        *(d2*)(panel + lo + 2 * q) = (d2){v0, v1};
+      }
+    }
+  }
+  static __device__ __forceinline__ int64_t stage_bytes(int64_t sk) { return (KC ? BK : BK * sk) * 2; }
+};
+
+template <int ADT, int BDT, bool AKC, bool BKC>
+__device__ __forceinline__ void gemm_tile_fast(const GemmArgs& g, double* lds, const char* Ab, const char* Bb, int64_t i0,
+                                               int64_t j0, int64_t k_begin, int64_t n_stage, Acc& acc, int tid, int lane,
+                                               int wr, int wc) {
+  FastPanel<ADT, AKC> fa;
+  FastPanel<BDT, BKC> fb;
+  // uniform stage bases: tile origin + first k of the range; per-lane offsets cover the row/col and in-stage k
+  const int64_t esa = (int64_t)sizeof(typename ElemOf<ADT>::type), esb = (int64_t)sizeof(typename ElemOf<BDT>::type);
+  const bool gather = g.a_rows != nullptr;
+  fa.init(g.sa_i, g.sa_k, gather ? i0 : 0, g.a_rows, tid);   // with a gather the row offset is absolute
+  fb.init(g.sb_j, g.sb_k, 0, nullptr, tid);
+  const char* pa = Ab + ((gather || !AKC ? 0 : i0 * g.sa_i) + (AKC ? k_begin : k_begin * g.sa_k + i0)) * esa;
+  const char* pb = Bb + ((BKC ? j0 * g.sb_j + k_begin : k_begin * g.sb_k + j0)) * esb;
+  const int64_t da = FastPanel<ADT, AKC>::stage_bytes(g.sa_k), db = FastPanel<BDT, BKC>::stage_bytes(g.sb_k);
+  fa.load(pa);
+  fb.load(pb);
+  fa.store(lds);
+  fb.store(lds + 2 * PANEL);
+  __syncthreads();
+  auto stage = [&](int64_t s, auto cur_c) {
+    constexpr int CUR = decltype(cur_c)::value;
+    const bool more = s + 1 < n_stage;
+    if (more) {
+      pa += da;
+      pb += db;
+      fa.load(pa);
+    }
+    mma_steps<0, BK / 8>(lds + CUR * PANEL, lds + (2 + CUR) * PANEL, wr, wc, lane, acc);
+    if (more) {
+      fa.store(lds + (CUR ^ 1) * PANEL);
+      fb.load(pb);
+    }
+    mma_steps<BK / 8, BK / 4>(lds + CUR * PANEL, lds + (2 + CUR) * PANEL, wr, wc, lane, acc);
+    if (more) fb.store(lds + (2 + (CUR ^ 1)) * PANEL);
+    __syncthreads();
+  };
+  int64_t s = 0;
+  for (; s + 1 < n_stage; s += 2) {
+    stage(s, std::integral_constant<int, 0>{});
+    stage(s + 1, std::integral_constant<int, 1>{});
+  }
+  if (s < n_stage) stage(s, std::integral_constant<int, 0>{});
 }
 
 template <int ADT, int BDT, bool AKC, bool BKC>
@@ -83,10 +235,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   }
   __syncthreads();
 
+  const int64_t n_stage = k_end > k_begin ? (k_end - k_begin + BK - 1) / BK : 0;
+  const bool interior = i0 + TILE <= g.M && j0 + TILE <= g.N;
+  if (g.fast_ok && interior && n_stage > 0 && (k_end - k_begin) % BK == 0 && (AKC || !g.a_rows)) {
+    Acc facc;  // separate accumulator set: the two paths never share live registers
+    acc_zero(facc);
+    gemm_tile_fast<ADT, BDT, AKC, BKC>(g, lds, Ab, Bb, i0, j0, k_begin, n_stage, facc, tid, lane, wr, wc);
+    gemm_epilogue(g, facc, batch, i0, j0, wr, wc, lane);
+    return;
+  }
   Acc acc;
   acc_zero(acc);
   double rg[8];  // one panel's prefetch at a time: A rides under the first half of a stage, B under the second
-  const int64_t n_stage = k_end > k_begin ? (k_end - k_begin + BK - 1) / BK : 0;
   if (n_stage > 0) {
     gemm_load_panel<ADT, AKC>(Ab, aoff, g.sa_k, k_begin, k_end, tid, rg);
     gemm_store_panel<AKC>(lds, tid, rg);
@@ -111,29 +271,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  const bool c_bf16 = (g.c_dtype == MDG_BF16);
-  char* Cb = (char*)g.C + batch * g.c_bs * (c_bf16 ? 2 : 8);
-#pragma unroll
-  for (int sa = 0; sa < 4; sa++)
-#pragma unroll
-    for (int reg = 0; reg < 4; reg++) {
-      int64_t gr = i0 + acc_row(wr, lane, sa, reg);
-      if (gr >= g.M) continue;
-      int64_t gc0 = j0 + acc_col(wc, lane, 0);
-      int64_t e0 = gr * g.ldc + gc0;
-#pragma unroll
-      for (int sb = 0; sb < 4; sb++) {
-        if (gc0 + sb >= g.N) continue;
-        double v = g.alpha * acc.v[sa][sb][reg];
-        if (!c_bf16) {
-          double* dst = (double*)Cb + e0 + sb;
-          if (g.beta != 0.) v += g.beta * *dst;
-          *dst = v;
-        } else {
-          ((bf16_t*)Cb)[e0 + sb] = f64_to_bf16(v);
-        }
-      }
-    }
+  gemm_epilogue(g, acc, batch, i0, j0, wr, wc, lane);
 }
 
 template <int ADT, int BDT>
@@ -170,6 +308,18 @@ int gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const void* A, int a
   MDG_CHECK_ARG(nt < (1ll << 31) && batch < 65536, "mdg_gemm_f64: grid too large");
   dim3 grid((unsigned)nt, (unsigned)batch);
   g.c_dtype = c_dtype;
+  {  // 16-byte alignment rules of FastPanel: per-operand unit (2 doubles / 8 bf16) along the vector-load axis
+    const int64_t ua = a_dtype == MDG_F64 ? 2 : 8, ub = b_dtype == MDG_F64 ? 2 : 8;
+    const bool a_kc = (sa_k == 1 && sa_i != 1), b_kc = (sb_k == 1 && sb_j != 1);
+    bool ok = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && (a_bs % ua == 0) && (b_bs % ub == 0);
+    ok = ok && (a_kc ? sa_i % ua == 0 : (sa_i == 1 && sa_k % ua == 0));
+    ok = ok && (b_kc ? sb_j % ub == 0 : (sb_j == 1 && sb_k % ub == 0));
+    // per-lane offsets are 32-bit: the furthest element a stage touches must be < 4 GiB from the stage base
+    const int64_t span_a = a_rows ? (int64_t)1 << 62 : (a_kc ? TILE * sa_i : BK * sa_k + TILE) * (int64_t)(16 / ua);
+    const int64_t span_b = (b_kc ? TILE * sb_j : BK * sb_k + TILE) * (int64_t)(16 / ub);
+    ok = ok && span_b < ((int64_t)1 << 32) && (a_rows || span_a < ((int64_t)1 << 32));
+    g.fast_ok = ok ? 1 : 0;
+  }
   if (a_dtype == MDG_F64 && b_dtype == MDG_F64) launch_gemm<MDG_F64, MDG_F64>(g, grid, st);
   else if (a_dtype == MDG_F64) launch_gemm<MDG_F64, MDG_BF16>(g, grid, st);
   else if (b_dtype == MDG_F64) launch_gemm<MDG_BF16, MDG_F64>(g, grid, st);

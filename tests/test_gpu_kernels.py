@@ -110,7 +110,8 @@ def test_bi_accum(ops, dev):
 
 
 # ---------------------------------------------------------------- GEMM
-@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (200, 130, 77), (64, 300, 512), (1, 1, 1), (257, 129, 16)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (200, 130, 77), (64, 300, 512), (1, 1, 1), (257, 129, 16),
+                                   (256, 256, 64), (384, 128, 160), (300, 260, 48)])  # interior tiles: vector staging
 @pytest.mark.parametrize("ta,tb", [(False, False), (True, False), (False, True), (True, True)])
 def test_gemm(ops, dev, M, N, K, ta, tb):
     gen = torch.Generator().manual_seed(M * 7 + N * 3 + K)
@@ -135,6 +136,29 @@ def test_gemm_bf16_gather(ops, dev):
     outb = torch.empty(150, 90, dtype=torch.bfloat16, device=dev)
     ops.gemm(A.to(dev), B.to(dev), outb, trans_b=True, a_rows=rows.to(dev))
     assert torch.equal(outb.cpu(), want.to(torch.bfloat16))
+
+
+def test_gemm_fast_path_bf16_and_gather(ops, dev):
+    """Interior tiles, 16-byte aligned operands: the vector-staging path with a gathered fp64 A (k-contiguous) and a
+    bf16 B in both layouts, fp64 and bf16 outputs."""
+    gen = torch.Generator().manual_seed(11)
+    A = torch.randn(700, 512, generator=gen, dtype=F64)
+    rows = torch.randperm(700, generator=gen)[:256].sort().values
+    Bt = torch.randn(384, 512, generator=gen).to(torch.bfloat16)      # used transposed: k-contiguous B
+    want = A[rows] @ Bt.double().T
+    out = torch.empty(256, 384, dtype=F64, device=dev)
+    ops.gemm(A.to(dev), Bt.to(dev), out, trans_b=True, a_rows=rows.to(dev))
+    assert rel(out, want) < 1e-13
+    Bn = torch.randn(512, 384, generator=gen).to(torch.bfloat16)      # j-contiguous B
+    want2 = A[:256] @ Bn.double()
+    out2 = torch.empty(256, 384, dtype=torch.bfloat16, device=dev)
+    ops.gemm(A[:256].to(dev), Bn.to(dev), out2)
+    assert torch.equal(out2.cpu(), want2.to(torch.bfloat16))
+    Ab = torch.randn(256, 512, generator=gen).to(torch.bfloat16)      # bf16 A as in the VO stage
+    want3 = Ab.double() @ A[:512, :256].contiguous()
+    out3 = torch.zeros(256, 256, dtype=F64, device=dev)
+    ops.gemm(Ab.to(dev), A[:512, :256].contiguous().to(dev), out3)
+    assert rel(out3, want3) < 1e-13
 
 
 # ---------------------------------------------------------------- Cholesky family
