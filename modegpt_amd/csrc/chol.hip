@@ -14,74 +14,130 @@ int gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const void* A, int a
 constexpr int NB = 128;
 constexpr int DP = NB + 1;  // LDS pitch (fp64) of the diagonal block: odd pitch -> conflict-free column walks
 
-// Factorise the nb x nb diagonal block at A (lower), write L back, write inv(L) (identity padded to 128x128)
-// to inv.  info: first failing global pivot index + 1 (atomicMin-style, 0 = ok).
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// Factorise the nb x nb diagonal block at A (lower), write L back, write inv(L) (identity padded to 128x128) to inv.
+// info: first failing global pivot index + 1 (0 = ok).
+//
+// One workgroup, block resident in LDS.  A column-by-column sweep needs a workgroup barrier per column and again two
+// per column for the inverse (384 barriers, ~200 us: the factorisation was barrier-bound).  Instead the 128 columns go
+// in 8 steps of 16: the 16x16 diagonal sub-block is factorised AND inverted by one wave entirely in registers (lane i
+// owns row i; pivots and multipliers are broadcast with v_readlane, no LDS round trips, no barriers), the 16-wide panel
+// below is solved by multiplying with that inverse (one thread per row), and the rank-16 update of the trailing part
+// is spread over all 16 waves: 3 barriers per step.  inv(L) is then assembled from the 16x16 inverses by three
+// levels of block doubling, X21 = -X22 (L21 X11), with T = L21 X11 parked in the (not yet written) global output.
 __global__ __launch_bounds__(1024) void potrf_diag_kernel(double* A, int64_t lda, int nb, int64_t k0, double* inv,
-                                                         int* info) {
-  __shared__ double a[NB * DP];
-  __shared__ double piv[NB];   // pivots d_j, later 1/L_jj
-  __shared__ double xd[NB];    // diagonal of inv(L)
-  constexpr int PT = 1024;  // 16 waves: the column updates are LDS-latency bound, so more waves in flight = faster
-  const int tid = threadIdx.x;
-  for (int e = tid; e < nb * nb; e += PT) {
-    int i = e / nb, j = e % nb;
-    a[i * DP + j] = (j <= i) ? A[(int64_t)i * lda + j] : 0.;
+                                                          int* info) {
+  constexpr int PT = 1024, SB = 16;
+  __shared__ double a[NB * DP];        // lower: A then L;  strict upper: inv(L) transposed (X[i][j] at a[j][i])
+  __shared__ double xd[NB];            // diagonal of inv(L)
+  __shared__ double dinv[SB * (SB + 1)];  // inverse of the current 16x16 diagonal sub-block
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int e = tid; e < NB * NB; e += PT) {
+    const int i = e / NB, j = e % NB;
+    double v = 0.;
+    if (i < nb && j <= i) v = A[(int64_t)i * lda + j];
+    else if (i >= nb && i == j) v = 1.;  // identity padding keeps the arithmetic of a ragged last block uniform
+    a[i * DP + j] = v;
   }
   __syncthreads();
-  // right-looking, scaling deferred: after step j column j holds the unscaled L column, a[j][j] the pivot.
-  const int tr = tid >> 5, tc = tid & 31;
-  for (int j = 0; j < nb; j++) {
-    double d = a[j * DP + j];
-    if (!(d > 0.)) {  // also catches NaN
-      if (tid == 0) {
-        int want = (int)(k0 + j + 1);
-        int old = atomicCAS(info, 0, want);
-        (void)old;
+
+  for (int kb = 0; kb < NB; kb += SB) {
+    if (wave == 0) {  // ---- 16x16 diagonal sub-block: Cholesky + inverse in registers
+      double row[SB], x[SB];
+      const int li = lane & 15;
+#pragma unroll
+      for (int c = 0; c < SB; c++) row[c] = (lane < SB && c <= li) ? a[(kb + li) * DP + kb + c] : 0.;
+#pragma unroll
+      for (int j = 0; j < SB; j++) {
+        double d = readlane_f64(row[j], j);
+        if (!(d > 0.)) {  // also catches NaN; uniform across the wave
+          if (lane == 0 && kb + j < nb) atomicCAS(info, 0, (int)(k0 + kb + j + 1));
+          d = 1.;
+        }
+        const double rs = 1. / sqrt(d);
+        row[j] = (li == j) ? d * rs : row[j] * rs;  // l_jj = sqrt(d), l_ij = a_ij / sqrt(d)
+#pragma unroll
+        for (int c = j + 1; c < SB; c++) row[c] -= row[j] * readlane_f64(row[j], c);
       }
-      d = 1.;
-      __syncthreads();
-      if (tid == 0) a[j * DP + j] = 1.;
+#pragma unroll
+      for (int i = 0; i < SB; i++) {  // lane j solves L x = e_j
+        double sacc = (i == li) ? 1. : 0.;
+#pragma unroll
+        for (int c = 0; c < i; c++) sacc -= readlane_f64(row[c], i) * x[c];
+        x[i] = sacc / readlane_f64(row[i], i);
+      }
+      if (lane < SB) {
+#pragma unroll
+        for (int c = 0; c < SB; c++) {
+          if (c <= li) a[(kb + li) * DP + kb + c] = row[c];          // L (rows of this lane)
+          dinv[c * (SB + 1) + li] = (c >= li) ? x[c] : 0.;           // X[c][li], column li of the inverse
+          if (c > li) a[(kb + li) * DP + kb + c] = x[c];             // X[c][li] kept transposed in the upper part
+        }
+        xd[kb + li] = x[li];
+      }
     }
-    const double rd = 1. / d;
-    for (int i = j + 1 + tr; i < nb; i += 32) {
-      const double lij = a[i * DP + j] * rd;
-      for (int k = j + 1 + tc; k <= i; k += 32) a[i * DP + k] -= lij * a[k * DP + j];
+    __syncthreads();
+    const int o = kb + SB, n2 = NB - o;
+    if (tid < n2) {  // ---- panel: L21 = A21 inv(L11)^T, one thread per row
+      const int i = o + tid;
+      double ar[SB], out[SB];
+#pragma unroll
+      for (int t = 0; t < SB; t++) ar[t] = a[i * DP + kb + t];
+#pragma unroll
+      for (int c = 0; c < SB; c++) {
+        double sacc = 0.;
+#pragma unroll
+        for (int t = 0; t <= c; t++) sacc += ar[t] * dinv[c * (SB + 1) + t];
+        out[c] = sacc;
+      }
+#pragma unroll
+      for (int c = 0; c < SB; c++) a[i * DP + kb + c] = out[c];
+    }
+    __syncthreads();
+    for (int e = tid; e < n2 * n2; e += PT) {  // ---- rank-16 update of the trailing lower triangle
+      const int i = e / n2, j = e % n2;
+      if (j > i) continue;
+      const double* ri = a + (o + i) * DP + kb;
+      const double* rj = a + (o + j) * DP + kb;
+      double sacc = 0.;
+#pragma unroll
+      for (int t = 0; t < SB; t++) sacc += ri[t] * rj[t];
+      a[(o + i) * DP + o + j] -= sacc;
     }
     __syncthreads();
   }
-  if (tid < nb) piv[tid] = 1. / sqrt(a[tid * DP + tid]);
-  __syncthreads();
   for (int e = tid; e < nb * nb; e += PT) {
-    int i = e / nb, j = e % nb;
-    if (j < i) a[i * DP + j] *= piv[j];
-  }
-  __syncthreads();
-  if (tid < nb) {
-    a[tid * DP + tid] = 1. / piv[tid];  // L_jj = sqrt(d_j)
-    xd[tid] = piv[tid];                 // X_jj = 1 / L_jj
-  }
-  __syncthreads();
-  for (int e = tid; e < nb * nb; e += PT) {
-    int i = e / nb, j = e % nb;
+    const int i = e / nb, j = e % nb;
     if (j <= i) A[(int64_t)i * lda + j] = a[i * DP + j];
   }
-  // inv(L): X starts as I; for k: row k of X final after scaling; rows below get X[i][:] -= L[i][k] X[k][:].
-  // X[i][j] (i > j) is kept transposed in the (unused) upper triangle: a[j][i].  Upper triangle is zero here.
-  for (int k = 0; k < nb; k++) {
-    // scale row k: X[k][j] for j < k  (X[k][k] = xd[k] already holds 1/L_kk)
-    // combined with the update below by carrying the scale: process row k scaling first.
-    for (int j = tid; j < k; j += PT) a[j * DP + k] *= xd[k];
+  // ---- inv(L) by block doubling: diagonal 16x16 inverses are in place (transposed, upper part + xd)
+  for (int s2 = SB; s2 < NB; s2 *= 2) {
+    const int outs = (NB / (2 * s2)) * s2 * s2;
+    for (int e = tid; e < outs; e += PT) {  // T = L21 X11 -> global scratch (the slot X21 will occupy)
+      const int pr = e / (s2 * s2), r = (e % (s2 * s2)) / s2, c = e % s2;
+      const int C0 = pr * 2 * s2, R0 = C0 + s2;
+      double sacc = a[(R0 + r) * DP + C0 + c] * xd[C0 + c];
+      for (int t = c + 1; t < s2; t++) sacc += a[(R0 + r) * DP + C0 + t] * a[(C0 + c) * DP + C0 + t];
+      inv[(R0 + r) * NB + C0 + c] = sacc;
+    }
     __syncthreads();
-    const int rows = nb - 1 - k;
-    for (int e = tid; e < rows * (k + 1); e += PT) {
-      int i = k + 1 + e % rows, j = e / rows;
-      double xkj = (j == k) ? xd[k] : a[j * DP + k];
-      a[j * DP + i] -= a[i * DP + k] * xkj;
+    for (int e = tid; e < outs; e += PT) {  // X21 = -X22 T, stored transposed in the upper part
+      const int pr = e / (s2 * s2), r = (e % (s2 * s2)) / s2, c = e % s2;
+      const int C0 = pr * 2 * s2, R0 = C0 + s2;
+      double sacc = xd[R0 + r] * inv[(R0 + r) * NB + C0 + c];
+      for (int t = 0; t < r; t++) sacc += a[(R0 + t) * DP + R0 + r] * inv[(R0 + t) * NB + C0 + c];
+      a[(C0 + c) * DP + R0 + r] = -sacc;
     }
     __syncthreads();
   }
   for (int e = tid; e < NB * NB; e += PT) {
-    int i = e / NB, j = e % NB;
+    const int i = e / NB, j = e % NB;
     double v;
     if (i >= nb || j >= nb) v = (i == j) ? 1. : 0.;
     else if (j < i) v = a[j * DP + i];
