@@ -49,7 +49,7 @@ __global__ __launch_bounds__(1024) void potrf_diag_kernel(double* A, int64_t lda
 
   for (int kb = 0; kb < NB; kb += SB) {
     if (wave == 0) {  // ---- 16x16 diagonal sub-block: Cholesky + inverse in registers
-      double row[SB], x[SB];
+      double row[SB], x[SB], rdiag[SB];  // rdiag[j] = 1 / L_jj (wave-uniform)
       const int li = lane & 15;
 #pragma unroll
       for (int c = 0; c < SB; c++) row[c] = (lane < SB && c <= li) ? a[(kb + li) * DP + kb + c] : 0.;
@@ -60,7 +60,8 @@ __global__ __launch_bounds__(1024) void potrf_diag_kernel(double* A, int64_t lda
           if (lane == 0 && kb + j < nb) atomicCAS(info, 0, (int)(k0 + kb + j + 1));
           d = 1.;
         }
-        const double rs = 1. / sqrt(d);
+        const double rs = rsqrt(d);                 // one reciprocal square root instead of a sqrt and a divide
+        rdiag[j] = rs;
         row[j] = (li == j) ? d * rs : row[j] * rs;  // l_jj = sqrt(d), l_ij = a_ij / sqrt(d)
 #pragma unroll
         for (int c = j + 1; c < SB; c++) row[c] -= row[j] * readlane_f64(row[j], c);
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(1024) void potrf_diag_kernel(double* A, int64_t lda
         double sacc = (i == li) ? 1. : 0.;
 #pragma unroll
         for (int c = 0; c < i; c++) sacc -= readlane_f64(row[c], i) * x[c];
-        x[i] = sacc / readlane_f64(row[i], i);
+        x[i] = sacc * rdiag[i];
       }
       if (lane < SB) {
 #pragma unroll
@@ -100,15 +101,16 @@ __global__ __launch_bounds__(1024) void potrf_diag_kernel(double* A, int64_t lda
       for (int c = 0; c < SB; c++) a[i * DP + kb + c] = out[c];
     }
     __syncthreads();
-    for (int e = tid; e < n2 * n2; e += PT) {  // ---- rank-16 update of the trailing lower triangle
-      const int i = e / n2, j = e % n2;
-      if (j > i) continue;
+    // ---- rank-16 update of the trailing lower triangle: 32 x 32 thread grid striding rows and columns
+    for (int i = tid >> 5; i < n2; i += 32) {
       const double* ri = a + (o + i) * DP + kb;
-      const double* rj = a + (o + j) * DP + kb;
-      double sacc = 0.;
+      for (int j = tid & 31; j <= i; j += 32) {
+        const double* rj = a + (o + j) * DP + kb;
+        double sacc = 0.;
 #pragma unroll
-      for (int t = 0; t < SB; t++) sacc += ri[t] * rj[t];
-      a[(o + i) * DP + o + j] -= sacc;
+        for (int t = 0; t < SB; t++) sacc += ri[t] * rj[t];
+        a[(o + i) * DP + o + j] -= sacc;
+      }
     }
     __syncthreads();
   }
