@@ -7,6 +7,8 @@
 // the token dimension is streamed through LDS in 16-token stages, converted to fp64 once while staging, so
 // the inner loop is LDS reads + 16 MFMAs per 4 tokens.  The kernel is fp64-MFMA bound: at 128x128 tiles the
 // operand traffic is 2 B/cycle/CU (DESIGN.md "cov_accum").
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.hpp"
@@ -365,13 +367,23 @@ static int cov_ksplit(int64_t n_tokens, int64_t n_feat, int64_t batch, int64_t* 
   if (max_split > 256) max_split = 256;
   int64_t best = 1;
   double best_cost = 0.;
+  if (const char* ev = getenv("MDG_COV_KSPLIT")) {  // experiment knob (scripts/bench_kernels.py); not used by the engine
+    const int64_t f = atoll(ev);
+    if (f >= 1 && f <= max_split) {
+      const int64_t tps = (int64_t)align_up((size_t)ceil_div(n_tokens, f), BK);
+      *tokens_per_split = tps;
+      return (int)ceil_div(n_tokens, tps);
+    }
+  }
   for (int64_t ks = 1; ks <= max_split; ks++) {
     const int64_t tps = (int64_t)align_up((size_t)ceil_div(n_tokens, ks), BK);
     const int64_t real = ceil_div(n_tokens, tps);
     if (real != ks) continue;
     double rounds = (double)ceil_div(blocks * ks, (int64_t)slots);
     double cost = rounds * (double)tps * us_per_token + (ks > 1 ? (double)(blocks * ks) * us_per_tile_rt + 3.0 : 0.);
-    if (ks == 1 || cost < best_cost * 0.95) {  // 5 % hysteresis towards fewer splits (the tail round runs 1 workgroup per CU and is faster than the model says)
+    // hysteresis towards fewer splits: leaving ks = 1 must pay 5 % (it adds a reduce kernel and a workspace; the tail
+    // round of an unsplit launch runs one workgroup per CU and is faster than this model says), going deeper 2 %
+    if (ks == 1 || cost < best_cost * (best == 1 ? 0.95 : 0.98)) {
       best = ks;
       best_cost = cost;
     }
