@@ -13,7 +13,7 @@ and weights are resident in HBM before the timed region.  With N GPUs every rank
 compressed layers on every rank.
 
 The JSON line also carries
-  roofline     -- the dominant kernel (cov_accum_kernel, fp64 MFMA bound): algorithmic SYRK flops of its launches
+  roofline     -- the dominant kernel (cov_accum_multi_kernel, fp64 MFMA bound): algorithmic SYRK flops of its launches
                   in the timed region / their summed durations (HIP events on the launch stream)
   cpu_baseline -- this repo's CPU oracle (torch-CPU fp64 restatement of the reference) timed on the host cores
                   on a bounded sample of the same workload (N = 1, rank 0 only)
@@ -67,11 +67,9 @@ def step(shape, adapter, layer_idx, batches, keep, n_texts, timer=None):
         t = b["h"].shape[0]
         if timer is None:
             engine.accumulate(covs, b, shape)
-        else:  # same four launches as engine.accumulate, each bracketed by events; flops = SYRK count
-            timer.run(t * f * (f + 1), lambda: ops.cov_accum(covs["mlp"], b["h"]))
-            timer.run(t * d * (d + 1), lambda: ops.cov_accum(covs["x"], b["x"]))
-            timer.run(t * nh * hd * (hd + 1), lambda: ops.cov_accum(covs["q"], b["q"], n_heads=nh))
-            timer.run(t * nkv * hd * (hd + 1), lambda: ops.cov_accum(covs["k"], b["k"], n_heads=nkv))
+        else:  # the same fused launch as engine.accumulate (all four hooks of the layer), bracketed by events
+            flops = t * (f * (f + 1) + d * (d + 1) + (nh + nkv) * hd * (hd + 1))   # SYRK count of the four problems
+            timer.run(flops, lambda: engine.accumulate(covs, b, shape))
     engine.finalize(covs, n_texts)
     tensors, mask = engine.compress_layer(adapter, layer_idx, covs, keep)
     return tensors, mask, covs
@@ -194,9 +192,10 @@ def main():
                      "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                      "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), "
                                      "profiles/r01_cov_hbm_traffic.json",
-                     "kernel": "cov_accum_kernel (v_mfma_f64_16x16x4_f64)", "launches": n_launch,
+                     "kernel": "cov_accum_multi_kernel (v_mfma_f64_16x16x4_f64; sigma_mlp + sigma_x + sigma_q + sigma_k of "
+                               "one calibration batch in one launch)", "launches": n_launch,
                      "avg_launch_ms": ms / n_launch, "flop_per_launch": flops / n_launch,
-                     "flop_count": "SYRK: tokens * n * (n + 1) per launch"},
+                     "flop_count": "SYRK: tokens * sum over the four problems of n * (n + 1) per launch"},
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         li, tensors, mask, covs = last

@@ -64,6 +64,18 @@ size_t mdg_cov_accum_ws_bytes(int64_t n_tokens, int64_t n_feat, int64_t batch);
 int mdg_cov_accum(const void* x, int dtype, int64_t n_tokens, int64_t n_feat, int64_t batch, int64_t ld,
                   int relu, double* sigma, int64_t ld_sigma, int64_t sigma_batch_stride, void* ws,
                   size_t ws_bytes, void* stream);
+/* The same accumulate for up to 4 problems of one calibration batch in ONE launch (the four hooks of a layer:
+ * sigma_mlp, sigma_x, sigma_q, sigma_k): the small problems' workgroups fill the slots the large one's last,
+ * under-filled round leaves idle.  Put the largest problem first.  Every problem must have n_feat % 128 == 0 and
+ * 16-byte aligned rows (otherwise call mdg_cov_accum per problem); no ReLU.  `problems` is a HOST array. */
+typedef struct {
+  const void* x;   /* [n_tokens, >= batch*n_feat], ld elements per token */
+  int64_t n_tokens, n_feat, batch, ld;
+  double* sigma;   /* [batch][n_feat][ld_sigma] */
+  int64_t ld_sigma, sigma_batch_stride;
+} mdg_cov_problem;
+size_t mdg_cov_accum_multi_ws_bytes(int n, const mdg_cov_problem* problems, int dtype);
+int mdg_cov_accum_multi(int n, const mdg_cov_problem* problems, int dtype, void* ws, size_t ws_bytes, void* stream);
 /* sigma[b] <- scale * sigma[b] on the lower triangle, mirrored into the upper.  scale = 1/(n_texts*2048)
  * reproduces calibration.py:141-146. */
 int mdg_cov_finalize(double* sigma, int64_t n, int64_t batch, int64_t ld_sigma, int64_t sigma_batch_stride,

@@ -20,6 +20,13 @@ MDG_GEMM_LOWER_ONLY, MDG_GEMM_A_LOWER_TRI, MDG_GEMM_B_LOWER_TRI, MDG_GEMM_A_UPPE
 
 _i64, _i32, _f64, _ptr, _sz = C.c_int64, C.c_int, C.c_double, C.c_void_p, C.c_size_t
 
+
+class CovProblem(C.Structure):
+    """mdg_cov_problem"""
+    _fields_ = [("x", _ptr), ("n_tokens", _i64), ("n_feat", _i64), ("batch", _i64), ("ld", _i64), ("sigma", _ptr),
+                ("ld_sigma", _i64), ("sigma_batch_stride", _i64)]
+
+
 # name -> (restype, argtypes); must list every symbol the header declares (tests/test_abi.py checks it)
 SIGNATURES = {
     "mdg_abi_version": (_i32, []),
@@ -27,6 +34,8 @@ SIGNATURES = {
     "mdg_device_info": (_i32, [_i32, C.c_char_p, _i32, C.POINTER(_i32), C.POINTER(_i64)]),
     "mdg_cov_accum_ws_bytes": (_sz, [_i64, _i64, _i64]),
     "mdg_cov_accum": (_i32, [_ptr, _i32, _i64, _i64, _i64, _i64, _i32, _ptr, _i64, _i64, _ptr, _sz, _ptr]),
+    "mdg_cov_accum_multi_ws_bytes": (_sz, [_i32, C.POINTER(CovProblem), _i32]),
+    "mdg_cov_accum_multi": (_i32, [_i32, C.POINTER(CovProblem), _i32, _ptr, _sz, _ptr]),
     "mdg_cov_finalize": (_i32, [_ptr, _i64, _i64, _i64, _i64, _f64, _ptr]),
     "mdg_bi_ws_bytes": (_sz, [_i64]),
     "mdg_bi_accum": (_i32, [_ptr, _ptr, _i32, _i64, _i64, _i64, _ptr, _ptr, _sz, _ptr]),

@@ -28,13 +28,35 @@ class LlamaAdapter(ModelAdapter):
 
     # ---- hooks ----
     def register_hooks(self, layer_idx, block, cov_mlp_list, cov_q_list, cov_k_list, cov_x_list, handles, logger):
-        handles.append(block.mlp.down_proj.register_forward_pre_hook(self._llama_pre_gate_hook(layer_idx, cov_mlp_list)))
-        handles.append(block.input_layernorm.register_forward_hook(self._input_hook(layer_idx, cov_x_list)))
-        handles.append(block.self_attn.k_proj.register_forward_hook(
-            self._make_proj_hook(layer_idx, cov_k_list, self.n_kv_heads, self.head_dim, block)))
-        handles.append(block.self_attn.q_proj.register_forward_hook(
-            self._make_proj_hook(layer_idx, cov_q_list, self.n_heads, self.head_dim, block)))
+        """Same four hook sites as the reference.  The three attention-side statistics are not launched when their hook
+        fires: the hook only parks a reference to the activation, and the layer's last hook (the pre-hook of
+        mlp.down_proj) sends all four problems of the layer to the device in ONE fused launch
+        (ops.cov_accum_multi -> mdg_cov_accum_multi), so the small problems' workgroups run in the slots the large one
+        leaves free.  Nothing is copied; the parked tensors live until the end of the layer's forward."""
+        parked = {}
 
+        def park(kind):
+            @torch.no_grad()
+            def hook(module, inp, out):
+                parked[kind] = out
+            return hook
+
+        @torch.no_grad()
+        def flush(module, input):
+            items = [(cov_mlp_list[layer_idx], input[0], 1)]
+            for kind, lst, heads in (("x", cov_x_list, 1), ("q", cov_q_list, self.n_heads), ("k", cov_k_list, self.n_kv_heads)):
+                t = parked.pop(kind, None)
+                if t is not None:
+                    items.append((lst[layer_idx], t, heads))
+            ops.cov_accum_multi(items)
+            return None
+
+        handles.append(block.input_layernorm.register_forward_hook(park("x")))
+        handles.append(block.self_attn.k_proj.register_forward_hook(park("k")))
+        handles.append(block.self_attn.q_proj.register_forward_hook(park("q")))
+        handles.append(block.mlp.down_proj.register_forward_pre_hook(flush))
+
+    # The reference's per-statistic hook factories, kept for adapters that register them one by one.
     @staticmethod
     def _llama_pre_gate_hook(layer_idx, cov_mlp_list):
         """sigma_mlp += H^T H, H = the input of down_proj (LlamaAdapter.py:127-136)."""

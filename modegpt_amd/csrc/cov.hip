@@ -162,12 +162,12 @@ __device__ __forceinline__ void mma_half_with_staging(const double* __restrict__
     }
 }
 
+// `split` = which token range, `slot` = index of this (batch, tile) among the a.batch * a.ntri tiles of the problem.
 template <int DT, bool RELU, bool FAST, bool DIAG>
-__device__ __forceinline__ void cov_tile(const CovArgs& a, double* lds, int b, int bi, int bj) {
+__device__ __forceinline__ void cov_tile(const CovArgs& a, double* lds, int b, int bi, int bj, int split, int slot) {
   typedef Stage<DT> S;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int split = blockIdx.y;
   const int64_t tok_begin = (int64_t)split * a.tokens_per_split;
   int64_t tok_end = tok_begin + a.tokens_per_split;
   if (tok_end > a.n_tokens) tok_end = a.n_tokens;
@@ -248,7 +248,7 @@ __device__ __forceinline__ void cov_tile(const CovArgs& a, double* lds, int b, i
           if (gc0 + sb < a.n_feat) row[sb] += acc.v[sa][sb][reg];
       }
   } else {
-    double* pt = a.partial + ((int64_t)split * gridDim.x + blockIdx.x) * (TILE * TILE);
+    double* pt = a.partial + ((int64_t)split * (a.batch * a.ntri) + slot) * (TILE * TILE);
 #pragma unroll
     for (int sa = 0; sa < 4; sa++)
 #pragma unroll
@@ -267,8 +267,36 @@ __global__ __launch_bounds__(256, 2) void cov_accum_kernel(CovArgs a) {
   const int b = blockIdx.x / a.ntri, t = blockIdx.x % a.ntri;
   int bi, bj;
   tri_decode(t, bi, bj);
-  if (bi == bj) cov_tile<DT, RELU, FAST, true>(a, lds, b, bi, bj);
-  else cov_tile<DT, RELU, FAST, false>(a, lds, b, bi, bj);
+  if (bi == bj) cov_tile<DT, RELU, FAST, true>(a, lds, b, bi, bj, blockIdx.y, blockIdx.x);
+  else cov_tile<DT, RELU, FAST, false>(a, lds, b, bi, bj, blockIdx.y, blockIdx.x);
+}
+
+// Several covariance problems of one calibration batch in ONE launch (the four hooks of a layer: sigma_mlp, sigma_x,
+// sigma_q, sigma_k).  Launched one after the other, each pays its own under-filled last round (6328 tiles on 512
+// slots leave 328 slots idle for a whole tile time) and the small problems cannot fill the GPU at all; in one grid the
+// workgroups of the small problems (split finely over tokens) are dispatched into the slots the big one leaves free.
+// Units are ordered big problem first.  FAST path only (full tiles, 16-byte aligned rows), no ReLU.
+constexpr int MULTI_MAX = 4;
+struct CovMulti {
+  int n;
+  int unit_start[MULTI_MAX + 1];
+  CovArgs p[MULTI_MAX];
+};
+
+template <int DT>
+__global__ __launch_bounds__(256, 2) void cov_accum_multi_kernel(CovMulti m) {
+  __shared__ double lds[4 * PANEL];
+  int u = blockIdx.x, pi = 0;
+  while (pi + 1 < m.n && u >= m.unit_start[pi + 1]) pi++;
+  u -= m.unit_start[pi];
+  const CovArgs& a = m.p[pi];
+  const int tiles = a.batch * a.ntri;
+  const int split = u / tiles, slot = u % tiles;
+  const int b = slot / a.ntri, t = slot % a.ntri;
+  int bi, bj;
+  tri_decode(t, bi, bj);
+  if (bi == bj) cov_tile<DT, false, true, true>(a, lds, b, bi, bj, split, slot);
+  else cov_tile<DT, false, true, false>(a, lds, b, bi, bj, split, slot);
 }
 
 // sigma tile += sum over splits (fixed order) of the partial tiles.  grid = (tiles, 64): 256 elements per block.
@@ -466,6 +494,85 @@ extern "C" int mdg_cov_accum(const void* x, int dtype, int64_t n_tokens, int64_t
     hipLaunchKernelGGL(cov_reduce_kernel, dim3(a.batch * a.ntri, TILE * TILE / 256), dim3(256), 0, st, a);
     MDG_LAUNCH_CHECK();
   }
+  return MDG_OK;
+}
+
+// split factor of a secondary problem inside a fused launch: units of about 4096 tokens pack the free slots finely
+static int multi_ksplit(int64_t n_tokens, int64_t* tokens_per_split) {
+  int64_t ks = n_tokens / 4096;
+  if (ks < 1) ks = 1;
+  if (ks > 64) ks = 64;
+  int64_t tps = (int64_t)align_up((size_t)ceil_div(n_tokens, ks), BK);
+  *tokens_per_split = tps;
+  return (int)ceil_div(n_tokens, tps);
+}
+
+static int multi_plan(int n, const mdg_cov_problem* pr, int dtype, CovMulti* m, size_t* ws_need) {
+  MDG_CHECK_ARG(n >= 1 && n <= MULTI_MAX && pr, "mdg_cov_accum_multi: 1..%d problems", MULTI_MAX);
+  MDG_CHECK_ARG(dtype >= MDG_BF16 && dtype <= MDG_F64, "mdg_cov_accum_multi: unknown dtype %d", dtype);
+  const size_t esz = dtype_size(dtype);
+  size_t off = 0;
+  int64_t units = 0;
+  m->n = n;
+  for (int i = 0; i < n; i++) {
+    const mdg_cov_problem& q = pr[i];
+    MDG_CHECK_ARG(q.n_tokens > 0 && q.n_feat > 0 && q.batch > 0 && q.x && q.sigma, "mdg_cov_accum_multi: problem %d empty", i);
+    MDG_CHECK_ARG(q.n_feat % TILE == 0 && q.ld >= q.n_feat * q.batch && q.ld_sigma >= q.n_feat,
+                  "mdg_cov_accum_multi: problem %d needs n_feat %% 128 == 0 (got %lld) and consistent strides", i,
+                  (long long)q.n_feat);
+    MDG_CHECK_ARG((uintptr_t)q.x % 16 == 0 && (q.ld * esz) % 16 == 0,
+                  "mdg_cov_accum_multi: problem %d is not 16-byte aligned (use mdg_cov_accum)", i);
+    CovArgs& a = m->p[i];
+    a.x = q.x; a.ld = q.ld; a.n_tokens = q.n_tokens; a.n_feat = (int)q.n_feat; a.batch = (int)q.batch;
+    a.tiles = (int)(q.n_feat / TILE); a.ntri = a.tiles * (a.tiles + 1) / 2;
+    a.sigma = q.sigma; a.ld_sigma = q.ld_sigma; a.sigma_bs = q.sigma_batch_stride; a.vec_ok = 1;
+    const int64_t tiles = (int64_t)a.batch * a.ntri;
+    if (i == 0 && tiles >= 768) { a.ksplit = 1; a.tokens_per_split = (int64_t)align_up((size_t)q.n_tokens, BK); }
+    else a.ksplit = multi_ksplit(q.n_tokens, &a.tokens_per_split);
+    a.partial = nullptr;
+    m->unit_start[i] = (int)units;
+    units += tiles * a.ksplit;
+    MDG_CHECK_ARG(units < (1ll << 30), "mdg_cov_accum_multi: grid too large");
+    if (a.ksplit > 1) {
+      a.partial = (double*)off;  // offset for now, rebased on the workspace by the caller
+      off += (size_t)a.ksplit * tiles * TILE * TILE * sizeof(double);
+    }
+  }
+  m->unit_start[n] = (int)units;
+  *ws_need = off;
+  return MDG_OK;
+}
+
+extern "C" size_t mdg_cov_accum_multi_ws_bytes(int n, const mdg_cov_problem* problems, int dtype) {
+  CovMulti m;
+  size_t need = 0;
+  if (multi_plan(n, problems, dtype, &m, &need) != MDG_OK) return 0;
+  return need;
+}
+
+extern "C" int mdg_cov_accum_multi(int n, const mdg_cov_problem* problems, int dtype, void* ws, size_t ws_bytes,
+                                   void* stream) {
+  MDG_CLEAR();
+  CovMulti m;
+  size_t need = 0;
+  MDG_TRY(multi_plan(n, problems, dtype, &m, &need));
+  MDG_CHECK_ARG(need == 0 || (ws && ws_bytes >= need), "mdg_cov_accum_multi: workspace %zu < required %zu", ws_bytes, need);
+  for (int i = 0; i < n; i++)
+    if (m.p[i].ksplit > 1) m.p[i].partial = (double*)((char*)ws + (size_t)m.p[i].partial);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)m.unit_start[n]);
+  switch (dtype) {
+    case MDG_BF16: hipLaunchKernelGGL(cov_accum_multi_kernel<MDG_BF16>, grid, dim3(256), 0, st, m); break;
+    case MDG_F16: hipLaunchKernelGGL(cov_accum_multi_kernel<MDG_F16>, grid, dim3(256), 0, st, m); break;
+    case MDG_F32: hipLaunchKernelGGL(cov_accum_multi_kernel<MDG_F32>, grid, dim3(256), 0, st, m); break;
+    default: hipLaunchKernelGGL(cov_accum_multi_kernel<MDG_F64>, grid, dim3(256), 0, st, m); break;
+  }
+  MDG_LAUNCH_CHECK();
+  for (int i = 0; i < n; i++)
+    if (m.p[i].ksplit > 1) {
+      hipLaunchKernelGGL(cov_reduce_kernel, dim3(m.p[i].batch * m.p[i].ntri, TILE * TILE / 256), dim3(256), 0, st, m.p[i]);
+      MDG_LAUNCH_CHECK();
+    }
   return MDG_OK;
 }
 

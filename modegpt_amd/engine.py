@@ -68,11 +68,15 @@ def new_covs(shape: dict, device) -> Dict[str, torch.Tensor]:
 
 
 def accumulate(covs: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], shape: dict) -> None:
-    """What the four hooks of one layer do for one calibration batch."""
-    ops.cov_accum(covs["mlp"], batch["h"], relu=(shape["arch"] == "opt"))
-    ops.cov_accum(covs["x"], batch["x"])
-    ops.cov_accum(covs["q"], batch["q"], n_heads=shape["n_heads"])
-    ops.cov_accum(covs["k"], batch["k"], n_heads=shape["n_kv_heads"])
+    """What the four hooks of one layer do for one calibration batch: one fused launch (the Llama / Qwen3 adapters
+    defer sigma_x / sigma_q / sigma_k to the layer's last hook for exactly this); OPT's ReLU statistic stays separate."""
+    if shape["arch"] == "opt":
+        ops.cov_accum(covs["mlp"], batch["h"], relu=True)
+        ops.cov_accum_multi([(covs["x"], batch["x"], 1), (covs["q"], batch["q"], shape["n_heads"]),
+                             (covs["k"], batch["k"], shape["n_kv_heads"])])
+        return
+    ops.cov_accum_multi([(covs["mlp"], batch["h"], 1), (covs["x"], batch["x"], 1),
+                         (covs["q"], batch["q"], shape["n_heads"]), (covs["k"], batch["k"], shape["n_kv_heads"])])
 
 
 def finalize(covs: Dict[str, torch.Tensor], n_texts: int) -> None:

@@ -63,6 +63,46 @@ def cov_accum(sigma: torch.Tensor, x: torch.Tensor, n_heads: int = 1, relu: bool
                                 sigma.data_ptr(), feat, feat * feat, wsp, nbytes, _stream(x)), "mdg_cov_accum")
 
 
+def cov_accum_multi(items) -> None:
+    """One launch for several covariance problems of the same calibration batch.  items: sequence of
+    (sigma, x, n_heads), largest problem first.  Falls back to one cov_accum call per item when the fused kernel's
+    preconditions do not hold (mixed dtypes, feature count not a multiple of 128, unaligned rows)."""
+    items = [(s_, x_, h_) for (s_, x_, h_) in items if x_.numel() > 0]
+    if not items:
+        return
+    lib = _lib.load()
+    prepared = []
+    dtype = items[0][1].dtype
+    fusable = len(items) <= 4
+    for sigma, x, n_heads in items:
+        _need_gpu(sigma, x)
+        if sigma.dtype != torch.float64 or not sigma.is_contiguous():
+            raise ValueError("sigma must be a contiguous float64 tensor")
+        x2 = x.detach().reshape(-1, x.shape[-1])
+        if x2.stride(-1) != 1:
+            x2 = x2.contiguous()
+        feat = sigma.shape[-1]
+        if x2.shape[1] != n_heads * feat:
+            raise ValueError(f"shape mismatch: x {tuple(x.shape)} vs sigma {tuple(sigma.shape)} with n_heads={n_heads}")
+        esz = x2.element_size()
+        fusable = fusable and x2.dtype == dtype and feat % 128 == 0 and x2.data_ptr() % 16 == 0 and \
+            (x2.stride(0) * esz) % 16 == 0 and x2.device == items[0][1].device
+        prepared.append((sigma, x2, n_heads, feat))
+    if not fusable:
+        for sigma, x2, n_heads, _ in prepared:
+            cov_accum(sigma, x2, n_heads=n_heads)
+        return
+    arr = (_lib.CovProblem * len(prepared))()
+    for i, (sigma, x2, n_heads, feat) in enumerate(prepared):
+        arr[i] = _lib.CovProblem(x2.data_ptr(), x2.shape[0], feat, n_heads, x2.stride(0), sigma.data_ptr(), feat, feat * feat)
+    dev = prepared[0][1].device
+    nbytes = lib.mdg_cov_accum_multi_ws_bytes(len(prepared), arr, _DT[dtype])
+    ws, wsp = _ws(nbytes, dev)
+    with torch.cuda.device(dev):
+        check(lib.mdg_cov_accum_multi(len(prepared), arr, _DT[dtype], wsp, nbytes, _stream(prepared[0][1])),
+              "mdg_cov_accum_multi")
+
+
 def cov_finalize(sigma: torch.Tensor, scale: float) -> None:
     """sigma <- scale * sigma (lower) mirrored into the upper triangle."""
     _need_gpu(sigma)

@@ -67,6 +67,11 @@ def _tiny_model(kind, dev, init_std=0.02):
                                        num_key_value_heads=2, head_dim=32, vocab_size=211, max_position_embeddings=64,
                                        initializer_range=init_std)
         m = transformers.Qwen3ForCausalLM(cfg)
+    elif kind == "llama_128":   # every statistic a multiple of 128 wide: the hooks take the fused-launch path
+        cfg = transformers.LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                                       num_key_value_heads=1, head_dim=128, vocab_size=211, max_position_embeddings=64,
+                                       initializer_range=init_std)
+        m = transformers.LlamaForCausalLM(cfg)
     else:
         kv = 2 if kind == "llama_gqa" else 4
         cfg = transformers.LlamaConfig(hidden_size=128, intermediate_size=320, num_hidden_layers=2, num_attention_heads=4,
@@ -104,7 +109,7 @@ def _capture(adapter, batches):
     return store, [b / n_texts for b in bi], n_texts
 
 
-@pytest.mark.parametrize("kind", ["llama_gqa", "llama_mha", "qwen3", "opt"])
+@pytest.mark.parametrize("kind", ["llama_gqa", "llama_mha", "qwen3", "opt", "llama_128"])
 def test_model_end_to_end(dev, kind, tmp_path):
     from modegpt_amd.adapters.CompressionConfig import CompressionConfig
     from modegpt_amd.adapters.model_adapter import ModelAdapter

@@ -346,3 +346,30 @@ def test_sqrt_M_surface_dispatch(dev):
     Mh = torch.stack([M[:64, :64], M[64:128, 64:128]])
     sh = sqrt_M(Mh.to(dev))
     assert rel(sh[1], O.sqrt_M(Mh[1])) < 1e-10
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_cov_accum_multi(ops, dev, dtype):
+    """Four problems of one batch in one launch == four separate launches == the oracle; incl. the fallback path."""
+    gen = torch.Generator().manual_seed(21)
+    t = 1000
+    H, X, Q, K = acts(gen, t, 512, dtype), acts(gen, t, 256, dtype), acts(gen, t, 4 * 128, dtype), acts(gen, t, 2 * 128, dtype)
+    want = [torch.zeros(1, 512, 512, dtype=F64), torch.zeros(1, 256, 256, dtype=F64), torch.zeros(4, 128, 128, dtype=F64),
+            torch.zeros(2, 128, 128, dtype=F64)]
+    for w, a, h in zip(want, (H, X, Q, K), (1, 1, 4, 2)):
+        O.cov_accum_heads(w, a, h, w.shape[-1])
+    got = [torch.zeros(512, 512, dtype=F64, device=dev), torch.zeros(256, 256, dtype=F64, device=dev),
+           torch.zeros(4, 128, 128, dtype=F64, device=dev), torch.zeros(2, 128, 128, dtype=F64, device=dev)]
+    for _ in range(2):
+        ops.cov_accum_multi([(got[0], H.to(dev), 1), (got[1], X.to(dev), 1), (got[2], Q.to(dev), 4), (got[3], K.to(dev), 2)])
+    for g, w in zip(got, want):
+        ops.cov_finalize(g, 0.5)
+        assert rel(g.reshape(w.shape), w) < 1e-13
+    # fallback: a head size that is not a multiple of 128 cannot be fused
+    Q2 = acts(gen, t, 4 * 64, dtype)
+    w2 = torch.zeros(4, 64, 64, dtype=F64)
+    O.cov_accum_heads(w2, Q2, 4, 64)
+    g2, g3 = torch.zeros(4, 64, 64, dtype=F64, device=dev), torch.zeros(256, 256, dtype=F64, device=dev)
+    ops.cov_accum_multi([(g3, X.to(dev), 1), (g2, Q2.to(dev), 4)])
+    ops.cov_finalize(g2, 1.0)
+    assert rel(g2, w2) < 1e-13
