@@ -178,7 +178,7 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "r01_cov_hbm_traffic.json")
     if os.path.exists(tpath) and a.model == "llama-3-8b" and a.batch_size == 16:
         with open(tpath) as f:
-            traffic = json.load(f)["avg_hbm_bytes_per_launch_over_the_four"]
+            traffic = json.load(f)["hbm_bytes_per_launch"]
     out = {
         "metric": "transformer layers compressed/sec (covariance+decomp+rebuild), Llama-3-8B @30%",
         "value": world * a.steps / elapsed, "unit": "layers/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

@@ -38,6 +38,9 @@ if "cov" in which:
     K = acts(T, nkv * hd); Sk = torch.zeros(nkv, hd, hd, dtype=F64, device=dev)
     t = timeit(lambda: ops.cov_accum(Sk, K, n_heads=nkv), n=3)
     print(f"cov k    {T}x{nkv}x{hd}: {t*1e3:.1f} ms  {T*nkv*hd*(hd+1)/t/1e12:.1f} TF")
+    t = timeit(lambda: ops.cov_accum_multi([(S, H, 1), (Sx, X, 1), (Sq, Q, nh), (Sk, K, nkv)]), n=3)
+    fl4 = T * (d_ff * (d_ff + 1) + d * (d + 1) + (nh + nkv) * hd * (hd + 1))
+    print(f"cov fused (mlp+x+q+k, one launch): {t*1e3:.1f} ms  {fl4/t/1e12:.1f} TF")
     t = timeit(lambda: ops.cov_finalize(S, 1.0 / T), n=2)
     print(f"finalize {d_ff}: {t*1e3:.2f} ms")
     if "mlp" in which:

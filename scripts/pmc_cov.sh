@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC pass over the Sigma_mlp covariance launch: rocprofv3 --pmc <counters> on scripts/bench_kernels.py cov
+# PMC pass over the fused covariance launch (sigma_mlp + sigma_x + sigma_q + sigma_k of one batch): rocprofv3 --pmc <counters> on scripts/bench_kernels.py cov
 export TMPDIR=/tmp
 R=$PWD
 OUT=$R/gpurun_out/$1; shift
@@ -10,7 +10,7 @@ import sqlite3,glob
 db=sqlite3.connect(glob.glob("$OUT/*.db")[0]); cur=db.cursor()
 q="""select d.id, (d.end-d.start)/1e6, p.name, sum(e.value) from rocpd_pmc_event e join rocpd_info_pmc p on e.pmc_id=p.id
 join rocpd_kernel_dispatch d on e.event_id=d.event_id join rocpd_info_kernel_symbol s on d.kernel_id=s.id
-where s.kernel_name like '%cov_accum%' and d.grid_size_x>=1619968 group by d.id, p.name order by d.id, p.name"""
+where s.kernel_name like '%cov_accum_multi%' group by d.id, p.name order by d.id, p.name"""
 rows=list(cur.execute(q))
 first=rows[0][0]
 for r in rows:
