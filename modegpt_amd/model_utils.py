@@ -91,7 +91,8 @@ def reload_compressed_model(model_dir: str, device="cuda:0", tokenizer_source: s
 
 def save_compressed_model(adapter, rotary_masks, save_dir: str, source_model_name: str,
                           patchers_dir: str = "./src/patchers"):
-    """Write the artefact set the reference's loader expects: pytorch_model*.bin (safe_serialization=False),
+    """Write the artefact set the reference's loader expects: pytorch_model*.bin (safe_serialization=False is passed as
+    upstream does; transformers >= 5 ignores it and writes model.safetensors, which the same loader reads),
     tokenizer files, rotary_masks.pt + config.mask_path (absolute), config dtype bfloat16, the architecture's
     *Rebuild.py next to the weights, tokenizer_source.txt."""
     model, tokenizer = adapter.model, adapter.tokenizer
