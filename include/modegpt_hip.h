@@ -136,12 +136,14 @@ int mdg_select_smallest_sorted(const double* scores, int64_t n, int64_t k, int64
  * Q/K row gathers, compress_qk.py:375-376). */
 int mdg_gather_rows_16(const void* src, int64_t ld_src, const int64_t* rows, int64_t n_rows, int64_t n_cols,
                        void* out, int64_t ld_out, void* stream);
-/* down_out [d, r] (bf16, ld_out) = ((C[idx,idx] + eps I)^-1 C[idx,:] W_d^T)^T, W_d bf16 [d, n] (ld_wd).
+/* down_out [d, r] (bf16, ld_out) = ((C[idx,idx] + eps I)^-1 C[idx,:] W_d^T)^T, W_d [d, n] (ld_wd) of dtype w_dtype:
+ * MDG_BF16, or MDG_F64 for checkpoints in another precision (fp16 OPT: the caller widens exactly, as the reference's
+ * .to(float64) does).
  * compress_mlp.py:52-62,97.  down_f64 (optional, [r, d] row-major) receives the fp64 solution before the
  * cast.  ws: mdg_nystrom_down_ws_bytes(n, r, d).  SYNCHRONISES. */
 size_t mdg_nystrom_down_ws_bytes(int64_t n, int64_t r, int64_t d);
 int mdg_nystrom_down(const double* C, int64_t n, int64_t ldc, const int64_t* idx, int64_t r, const void* Wd,
-                     int64_t d, int64_t ld_wd, double eps, void* down_out, int64_t ld_out, double* down_f64,
+                     int64_t d, int64_t ld_wd, int w_dtype, double eps, void* down_out, int64_t ld_out, double* down_f64,
                      void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ QK: CR selection
@@ -155,13 +157,13 @@ int mdg_qk_select(const double* cov_q, const double* cov_k, int n_heads, int n_k
 
 /* ------------------------------------------------------------------ VO: SVD of sqrt(C) W_v^T
  * v_out [n_kv*rank, d] bf16, o_out [d, n_heads*rank] bf16 (compress_vo.py:89-90).  W_v [n_kv*hd, d],
- * W_o [d, n_heads*hd] bf16.  n_kv == n_heads selects the two-SVD MHA variant (compress_vo.py:162-223), else the
+ * W_o [d, n_heads*hd], both of dtype w_dtype (MDG_BF16 or MDG_F64).  n_kv == n_heads selects the two-SVD MHA variant (compress_vo.py:162-223), else the
  * grouped one (:112-159).  Works on the Gram matrix W_v (C + rho I) W_v^T (DESIGN.md "Identities"), so the
  * d x d eigensolve and inverse of compress_vo.py:43-45 never happen.  v_f64 / o_f64 optional fp64 copies of
  * the factors.  ws: mdg_vo_compress_ws_bytes.  SYNCHRONISES. */
 size_t mdg_vo_compress_ws_bytes(int64_t d, int n_heads, int n_kv, int hd);
 int mdg_vo_compress(const double* cov_x, int64_t d, int64_t ldc, const void* Wv, int64_t ld_wv, const void* Wo,
-                    int64_t ld_wo, int n_heads, int n_kv, int hd, int rank, double ridge, void* v_out,
+                    int64_t ld_wo, int w_dtype, int n_heads, int n_kv, int hd, int rank, double ridge, void* v_out,
                     int64_t ld_v, void* o_out, int64_t ld_o, double* v_f64, double* o_f64, void* ws,
                     size_t ws_bytes, void* stream);
 

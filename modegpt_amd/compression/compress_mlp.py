@@ -41,7 +41,7 @@ def compress_weights(comps: MLPComponents, C: Tensor, keep_ratio: float, layer_i
     if comps.gate_proj is not None:
         W_g = comps.gate_proj.weight.detach().to(device=d2, dtype=torch.bfloat16)
         gate = ops.gather_rows(W_g, idx)                              # W_g[topk, :]               (:50)
-    W_d = comps.down_proj.weight.detach().to(device=d2, dtype=torch.bfloat16)
+    W_d = comps.down_proj.weight.detach().to(device=d2)              # bf16 as is; fp16/fp32 widen exactly to fp64
     down = ops.nystrom_down(C, idx, W_d, eps=1e-6)                    # [d, r] bf16                (:52-62)
     return up.T, down.T, (None if gate is None else gate.T), rank
 

@@ -22,10 +22,11 @@ extern "C" size_t mdg_nystrom_down_ws_bytes(int64_t n, int64_t r, int64_t d) {
 }
 
 extern "C" int mdg_nystrom_down(const double* C, int64_t n, int64_t ldc, const int64_t* idx, int64_t r, const void* Wd,
-                                int64_t d, int64_t ld_wd, double eps, void* down_out, int64_t ld_out,
+                                int64_t d, int64_t ld_wd, int w_dtype, double eps, void* down_out, int64_t ld_out,
                                 double* down_f64, void* ws, size_t ws_bytes, void* stream) {
   MDG_CLEAR();
   MDG_CHECK_ARG(C && idx && Wd && down_out, "mdg_nystrom_down: null pointer");
+  MDG_CHECK_ARG(w_dtype == MDG_BF16 || w_dtype == MDG_F64, "mdg_nystrom_down: W_d must be bf16 or f64 (got %d)", w_dtype);
   MDG_CHECK_ARG(n > 0 && r > 0 && r <= n && d > 0 && ldc >= n && ld_wd >= n && ld_out >= r,
                 "mdg_nystrom_down: bad sizes (n=%lld r=%lld d=%lld)", (long long)n, (long long)r, (long long)d);
   MDG_CHECK_ARG(ws && ws_bytes >= mdg_nystrom_down_ws_bytes(n, r, d), "mdg_nystrom_down: workspace %zu < required %zu",
@@ -37,7 +38,7 @@ extern "C" int mdg_nystrom_down(const double* C, int64_t n, int64_t ldc, const i
   // C_kk + eps I  (lower)                                           compress_mlp.py:52,56
   MDG_TRY(copy_lower(C, ldc, idx, Ckk, r, r, eps, st));
   // cross = C[idx,:] @ W_d^T  -> [r, d]                             compress_mlp.py:54
-  MDG_TRY(gemm_f64(r, d, n, 1.0, C, MDG_F64, ldc, 1, idx, Wd, MDG_BF16, 1, ld_wd, 0.0, X, MDG_F64, d, 1, 0, 0, 0, 0, st));
+  MDG_TRY(gemm_f64(r, d, n, 1.0, C, MDG_F64, ldc, 1, idx, Wd, w_dtype, 1, ld_wd, 0.0, X, MDG_F64, d, 1, 0, 0, 0, 0, st));
   MDG_TRY(potrf_lower(Ckk, r, r, inv, st));                       // compress_mlp.py:56
   MDG_TRY(potrs_lower(Ckk, r, r, inv, X, d, d, st));              // compress_mlp.py:57
   if (down_f64) MDG_HIP(hipMemcpyAsync(down_f64, X, (size_t)r * d * sizeof(double), hipMemcpyDeviceToDevice, st));

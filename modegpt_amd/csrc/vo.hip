@@ -19,11 +19,12 @@ int syevj_batched(double* A, int64_t n, int64_t batch, double* evals, double* ev
                   int max_sweeps = 40, int sorted = 1);
 int check_flag(int* dflag, hipStream_t st, const char* what);
 
-// dst (f64, ld) = scale * src (bf16, ld_src)
-__global__ __launch_bounds__(256) void scale_bf16_to_f64_kernel(const bf16_t* src, int64_t ld_src, int64_t cols,
-                                                                double scale, double* dst, int64_t ld) {
+// dst (f64, ld) = scale * src (bf16 or f64, ld_src)
+template <int DT>
+__global__ __launch_bounds__(256) void scale_to_f64_kernel(const void* src, int64_t ld_src, int64_t cols, double scale,
+                                                           double* dst, int64_t ld) {
   const int64_t r = blockIdx.x;
-  for (int64_t c = threadIdx.x; c < cols; c += 256) dst[r * ld + c] = scale * bf16_to_f64(src[r * ld_src + c]);
+  for (int64_t c = threadIdx.x; c < cols; c += 256) dst[r * ld + c] = scale * load_f64<DT>(src, r * ld_src + c);
 }
 
 // grouped: P[h][a][k] = V[k][a] / S_a, Q[h][k][a] = V[k][a] * S_a  (a < r)
@@ -117,11 +118,13 @@ extern "C" size_t mdg_vo_compress_ws_bytes(int64_t d, int n_heads, int n_kv, int
 }
 
 extern "C" int mdg_vo_compress(const double* cov_x, int64_t d, int64_t ldc, const void* Wv, int64_t ld_wv, const void* Wo,
-                               int64_t ld_wo, int n_heads, int n_kv, int hd, int rank, double ridge, void* v_out,
+                               int64_t ld_wo, int w_dtype, int n_heads, int n_kv, int hd, int rank, double ridge, void* v_out,
                                int64_t ld_v, void* o_out, int64_t ld_o, double* v_f64, double* o_f64, void* ws,
                                size_t ws_bytes, void* stream) {
   MDG_CLEAR();
   MDG_CHECK_ARG(cov_x && Wv && Wo && v_out && o_out, "mdg_vo_compress: null pointer");
+  MDG_CHECK_ARG(w_dtype == MDG_BF16 || w_dtype == MDG_F64, "mdg_vo_compress: weights must be bf16 or f64 (got %d)", w_dtype);
+  const int64_t wsz = w_dtype == MDG_BF16 ? 2 : 8;
   MDG_CHECK_ARG(n_kv > 0 && n_heads % n_kv == 0 && hd >= 2 && hd <= 128 && hd % 2 == 0,
                 "mdg_vo_compress: unsupported head layout (n_heads=%d n_kv=%d hd=%d)", n_heads, n_kv, hd);
   MDG_CHECK_ARG(rank >= 1 && rank <= hd, "mdg_vo_compress: rank %d outside [1, %d]", rank, hd);
@@ -134,13 +137,15 @@ extern "C" int mdg_vo_compress(const double* cov_x, int64_t d, int64_t ldc, cons
   const bool mha = (g == 1);
   const int64_t rows = (int64_t)n_kv * hd, hh = (int64_t)hd * hd;
   // T = W_v (Sigma_x + rho I) = rho W_v + W_v Sigma_x                       [n_kv*hd, d]
-  hipLaunchKernelGGL(scale_bf16_to_f64_kernel, dim3((unsigned)rows), dim3(256), 0, st, (const bf16_t*)Wv, ld_wv, d, ridge,
-                     w.T, d);
+  if (w_dtype == MDG_BF16)
+    hipLaunchKernelGGL(scale_to_f64_kernel<MDG_BF16>, dim3((unsigned)rows), dim3(256), 0, st, Wv, ld_wv, d, ridge, w.T, d);
+  else
+    hipLaunchKernelGGL(scale_to_f64_kernel<MDG_F64>, dim3((unsigned)rows), dim3(256), 0, st, Wv, ld_wv, d, ridge, w.T, d);
   MDG_LAUNCH_CHECK();
-  MDG_TRY(gemm_f64(rows, d, d, 1.0, Wv, MDG_BF16, ld_wv, 1, nullptr, cov_x, MDG_F64, ldc, 1, 1.0, w.T, MDG_F64, d, 1, 0, 0,
+  MDG_TRY(gemm_f64(rows, d, d, 1.0, Wv, w_dtype, ld_wv, 1, nullptr, cov_x, MDG_F64, ldc, 1, 1.0, w.T, MDG_F64, d, 1, 0, 0,
                    0, 0, st));
   // G_h = T_h W_v,h^T                                                        [hd, hd] per kv head
-  MDG_TRY(gemm_f64(hd, hd, d, 1.0, w.T, MDG_F64, d, 1, nullptr, Wv, MDG_BF16, 1, ld_wv, 0.0, w.G, MDG_F64, hd, n_kv,
+  MDG_TRY(gemm_f64(hd, hd, d, 1.0, w.T, MDG_F64, d, 1, nullptr, Wv, w_dtype, 1, ld_wv, 0.0, w.G, MDG_F64, hd, n_kv,
                    (int64_t)hd * d, (int64_t)hd * ld_wv, hh, 0, st));
   MDG_TRY(syevj_batched(w.G, hd, n_kv, w.evals, w.evecs, w.flag, st));
   if (!mha) {
@@ -149,7 +154,7 @@ extern "C" int mdg_vo_compress(const double* cov_x, int64_t d, int64_t ldc, cons
   } else {
     MDG_TRY(check_flag(w.flag, st, "mdg_vo_compress (first SVD)"));
     // M_h = W_o,h^T W_o,h
-    MDG_TRY(gemm_f64(hd, hd, d, 1.0, Wo, MDG_BF16, 1, ld_wo, nullptr, Wo, MDG_BF16, ld_wo, 1, 0.0, w.Mh, MDG_F64, hd,
+    MDG_TRY(gemm_f64(hd, hd, d, 1.0, Wo, w_dtype, 1, ld_wo, nullptr, Wo, w_dtype, ld_wo, 1, 0.0, w.Mh, MDG_F64, hd,
                      n_heads, hd, hd, hh, 0, st));
     hipLaunchKernelGGL(vo_sv_kernel, dim3(n_kv), dim3(256), 0, st, w.evals, w.evecs, hd, w.Y);
     MDG_LAUNCH_CHECK();
@@ -166,7 +171,7 @@ extern "C" int mdg_vo_compress(const double* cov_x, int64_t d, int64_t ldc, cons
   for (int pass = 0; pass < (v_f64 ? 2 : 1); pass++) {
     void* out = pass ? (void*)v_f64 : v_out;
     int64_t ld = pass ? d : ld_v;
-    MDG_TRY(gemm_f64(rank, d, hd, 1.0, w.P, MDG_F64, hd, 1, nullptr, Wv, MDG_BF16, ld_wv, 1, 0.0, out,
+    MDG_TRY(gemm_f64(rank, d, hd, 1.0, w.P, MDG_F64, hd, 1, nullptr, Wv, w_dtype, ld_wv, 1, 0.0, out,
                      pass ? MDG_F64 : MDG_BF16, ld, n_kv, (int64_t)rank * hd, (int64_t)hd * ld_wv, (int64_t)rank * ld, 0,
                      st));
   }
@@ -175,7 +180,7 @@ extern "C" int mdg_vo_compress(const double* cov_x, int64_t d, int64_t ldc, cons
     for (int j = 0; j < g; j++) {
       char* out = pass ? (char*)(o_f64 + (int64_t)j * rank) : (char*)o_out + (int64_t)j * rank * 2;
       int64_t ld = pass ? (int64_t)n_heads * rank : ld_o;
-      MDG_TRY(gemm_f64(d, rank, hd, 1.0, (const bf16_t*)Wo + (int64_t)j * hd, MDG_BF16, ld_wo, 1, nullptr, w.Q, MDG_F64,
+      MDG_TRY(gemm_f64(d, rank, hd, 1.0, (const char*)Wo + (int64_t)j * hd * wsz, w_dtype, ld_wo, 1, nullptr, w.Q, MDG_F64,
                        rank, 1, 0.0, out, pass ? MDG_F64 : MDG_BF16, ld, n_kv, (int64_t)g * hd, (int64_t)hd * rank,
                        (int64_t)g * rank, 0, st));
     }

@@ -38,6 +38,15 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+def _as_weight(W: torch.Tensor) -> torch.Tensor:
+    """Weights enter the fp64 GEMMs either as bf16 (converted exactly on load) or as fp64; fp16 / fp32 checkpoints are
+    widened to fp64 first, exactly, instead of being squeezed through bf16."""
+    W = W.detach()
+    if W.dtype not in (torch.bfloat16, torch.float64):
+        W = W.to(torch.float64)
+    return W if W.stride(-1) == 1 else W.contiguous()
+
+
 # ------------------------------------------------------------------ covariance
 def cov_accum(sigma: torch.Tensor, x: torch.Tensor, n_heads: int = 1, relu: bool = False) -> None:
     """sigma (lower triangle) += X^T X in fp64.  x: [..., n_heads*feat] (bf16/f16/f32/f64, last dim
@@ -263,13 +272,11 @@ def gather_rows(W: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
 
 def nystrom_down(Cm: torch.Tensor, idx: torch.Tensor, W_down: torch.Tensor, eps: float = 1e-6,
                  want_f64: bool = False):
-    """down' [d, r] bf16 = ((C[idx,idx] + eps I)^-1 C[idx,:] W_down^T)^T;  W_down: [d, n] bf16."""
+    """down' [d, r] bf16 = ((C[idx,idx] + eps I)^-1 C[idx,:] W_down^T)^T;  W_down: [d, n], bf16 as is, any other
+    dtype widened exactly to fp64 (what the reference's .to(float64) does; bf16 would lose bits of an fp16 weight)."""
     _need_gpu(Cm, idx, W_down)
     lib = _lib.load()
-    if W_down.dtype != torch.bfloat16:
-        W_down = W_down.to(torch.bfloat16)
-    if W_down.stride(1) != 1:
-        W_down = W_down.contiguous()
+    W_down = _as_weight(W_down)
     n, r, d = Cm.shape[0], idx.numel(), W_down.shape[0]
     idx = idx.to(torch.int64).contiguous()
     out = torch.empty(d, r, dtype=torch.bfloat16, device=Cm.device)
@@ -278,7 +285,7 @@ def nystrom_down(Cm: torch.Tensor, idx: torch.Tensor, W_down: torch.Tensor, eps:
     ws, wsp = _ws(nbytes, Cm.device)
     with torch.cuda.device(Cm.device):
         check(lib.mdg_nystrom_down(Cm.data_ptr(), n, Cm.stride(0), idx.data_ptr(), r, W_down.data_ptr(), d,
-                                   W_down.stride(0), float(eps), out.data_ptr(), out.stride(0), _p(f64), wsp, nbytes,
+                                   W_down.stride(0), _DT[W_down.dtype], float(eps), out.data_ptr(), out.stride(0), _p(f64), wsp, nbytes,
                                    _stream(Cm)), "mdg_nystrom_down")
     return (out, f64) if want_f64 else out
 
@@ -308,10 +315,9 @@ def vo_compress(cov_x: torch.Tensor, W_v: torch.Tensor, W_o: torch.Tensor, n_hea
     """Returns (v_proj [n_kv*rank, d] bf16, o_proj [d, n_heads*rank] bf16[, v_f64, o_f64])."""
     _need_gpu(cov_x, W_v, W_o)
     lib = _lib.load()
-    Wv = W_v.to(torch.bfloat16)
-    Wo = W_o.to(torch.bfloat16)
-    Wv = Wv if Wv.stride(1) == 1 else Wv.contiguous()
-    Wo = Wo if Wo.stride(1) == 1 else Wo.contiguous()
+    Wv, Wo = _as_weight(W_v), _as_weight(W_o)
+    if Wv.dtype != Wo.dtype:
+        Wv, Wo = Wv.to(torch.float64), Wo.to(torch.float64)
     Cx = cov_x if (cov_x.dtype == torch.float64 and cov_x.stride(1) == 1) else cov_x.to(torch.float64).contiguous()
     d = Cx.shape[0]
     dev = Cx.device
@@ -323,7 +329,7 @@ def vo_compress(cov_x: torch.Tensor, W_v: torch.Tensor, W_o: torch.Tensor, n_hea
     ws, wsp = _ws(nbytes, dev)
     with torch.cuda.device(dev):
         check(lib.mdg_vo_compress(Cx.data_ptr(), d, Cx.stride(0), Wv.data_ptr(), Wv.stride(0), Wo.data_ptr(),
-                                  Wo.stride(0), n_heads, n_kv, hd, rank, float(ridge), v_out.data_ptr(),
+                                  Wo.stride(0), _DT[Wv.dtype], n_heads, n_kv, hd, rank, float(ridge), v_out.data_ptr(),
                                   v_out.stride(0), o_out.data_ptr(), o_out.stride(0), _p(v64), _p(o64), wsp, nbytes,
                                   _stream(Cx)), "mdg_vo_compress")
     return (v_out, o_out, v64, o64) if want_f64 else (v_out, o_out)

@@ -373,3 +373,29 @@ def test_cov_accum_multi(ops, dev, dtype):
     ops.cov_accum_multi([(g3, X.to(dev), 1), (g2, Q2.to(dev), 4)])
     ops.cov_finalize(g2, 1.0)
     assert rel(g2, w2) < 1e-13
+
+
+# ---------------------------------------------------------------- non-bf16 checkpoints (fp16 OPT, fp32)
+@pytest.mark.parametrize("wdt", [torch.float16, torch.float32])
+@pytest.mark.parametrize("name", ["tiny_gqa", "tiny_opt"])
+def test_weights_not_bf16_are_widened_exactly(ops, dev, name, wdt):
+    """The reference widens weights with .to(float64); an fp16 / fp32 weight must not be squeezed through bf16 on its
+    way into the factorisations.  The weights here carry mantissa bits bf16 cannot hold."""
+    c = Case(name)
+    gen = torch.Generator().manual_seed(11)
+    jitter = lambda W: (W.float() * (1 + 2 ** -9 * torch.randn(W.shape, generator=gen))).to(wdt)
+    Wd, Wv, Wo = jitter(c.W["down"]), jitter(c.W["v"]), jitter(c.W["o"])
+    assert not torch.equal(Wd.to(torch.bfloat16).to(wdt), Wd)
+    Cm = c.f64["sigma_mlp"]
+    ref_down = O.nystrom_down(Cm, Wd, c.mlp_idx)                       # [r, d] fp64
+    _, down64 = ops.nystrom_down(Cm.to(dev), c.mlp_idx.to(dev), Wd.to(dev), want_f64=True)
+    assert rel(down64, ref_down) < 1e-7
+    lossy = O.nystrom_down(Cm, Wd.to(torch.bfloat16), c.mlp_idx)
+    assert rel(down64, ref_down) < 1e-3 * rel(lossy, ref_down)
+
+    _, (v_ref, o_ref) = O.compress_vo_layer(Wv, Wo, c.f64["sigma_x"], c.n_h, c.n_kv, c.hd, c.vo_rank, c.ridges["ridge_vo"])
+    v, o, v64, o64 = ops.vo_compress(c.f64["sigma_x"].to(dev), Wv.to(dev), Wo.to(dev), c.n_h, c.n_kv, c.hd, c.vo_rank,
+                                     c.ridges["ridge_vo"], want_f64=True)
+    r = c.vo_rank
+    assert rel(vo_products(v64.cpu(), o64.cpu(), c.n_h, c.n_kv, r), vo_products(v_ref, o_ref, c.n_h, c.n_kv, r)) < 1e-8
+    assert v.dtype == torch.bfloat16 and o.dtype == torch.bfloat16
