@@ -182,6 +182,25 @@ size_t mdg_sqrt_psd_large_ws_bytes(int64_t n);
 int mdg_sqrt_psd_large(const double* M, int64_t n, int64_t ld, double ridge, int scaled, double* root,
                        double* inv_root, double* evals_out, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------ compressed-model attention
+ * Rotary embedding of a compressed layer's q or k projection, fused with the gather of cos/sin by the layer's rotary
+ * mask, the optional Qwen3 masked RMSNorm, and the transpose into the layout attention consumes.  Replaces the eager
+ * chains apply_rotary_pos_emb(..., rotary_mask) (src/patchers/LlamaRebuild.py:153-176) and _masked_rms_norm
+ * (src/patchers/DenseQwenRebuild.py:262-286).
+ *   x    [B*T, n_heads*r] rows of pitch ld_x elements (the projection output, token-major), dtype bf16 / f16 / f32
+ *   out  [B, n_heads, T, r] contiguous, same dtype
+ *   cos, sin  [Bc, T, hd] same dtype; cs_batch_stride elements between batches, 0 = one table shared by every batch
+ *   mask int64 [n_kv, r] -- kept column j of (kv) head g is original column mask[g, j] in [0, hd); query heads use the
+ *        row of their kv head (h / (n_heads / n_kv)); the two halves [0, r/2) and [r/2, r) are the rotate_half partners.
+ *        NULL = identity (then r must equal hd).  Out-of-range entries are clamped (memory safety only).
+ *   norm_w  [hd] same dtype or NULL: y = dtype(norm_w[mask] * (float(x) * rsqrt(mean(float(x)^2 over the r kept columns)
+ *        + eps))) is applied before the rotation.
+ * Every product and the sum are rounded to the element dtype one op at a time, as torch's eager expression does: the
+ * rotation is bit-identical to it; the fp32 sum of squares of the norm is taken in a fixed (16-lane tree) order. */
+int mdg_rope_gather(const void* x, int dtype, int64_t ld_x, int64_t B, int64_t T, int n_heads, int n_kv, int r, int hd,
+                    const void* cos, const void* sin, int64_t cs_batch_stride, const int64_t* mask,
+                    const void* norm_w, double eps, void* out, void* stream);
+
 /* ------------------------------------------------------------------ utilities
  * out_bf16[j, i] = bf16(in_f64[i, j])  (transpose + cast with torch's double->float->bf16 rounding) */
 int mdg_cast_transpose_f64_bf16(const double* in, int64_t rows, int64_t cols, int64_t ld_in, void* out,

@@ -62,6 +62,8 @@ SIGNATURES = {
     "mdg_sqrt_psd_small": (_i32, [_ptr, _i64, _i64, _f64, _i32, _ptr, _ptr, _ptr, _ptr, _sz, _ptr]),
     "mdg_sqrt_psd_large_ws_bytes": (_sz, [_i64]),
     "mdg_sqrt_psd_large": (_i32, [_ptr, _i64, _i64, _f64, _i32, _ptr, _ptr, _ptr, _ptr, _sz, _ptr]),
+    "mdg_rope_gather": (_i32, [_ptr, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _ptr, _ptr, _i64, _ptr, _ptr, _f64,
+                                _ptr, _ptr]),
     "mdg_cast_transpose_f64_bf16": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _i64, _ptr]),
     "mdg_probe_mfma_f64": (_i32, [_i32, C.POINTER(_f64), _ptr]),
 }

@@ -2,8 +2,8 @@
 
 The constants keep the reference's names and values (src/model_utils.py:15-31) because adapters and compressors
 import them by name.  The IO functions are API-compatible plumbing (HF load / save, network or disk bound --
-SURVEY.md section 2 "OUT OF SCOPE"): nothing here is accelerated, it only has to write a checkpoint the reference's
-patched modeling files can load.
+SURVEY.md section 2 "OUT OF SCOPE"): nothing here is accelerated, it only has to write a checkpoint that loads through
+config.auto_map -- with this engine's modeling files (patchers/*Rebuild.py, shipped by default) or the reference's.
 """
 from __future__ import annotations
 
@@ -26,7 +26,9 @@ d1 = "cuda:0"
 d2 = "cuda:1" if parallel else "cuda:0"
 calib_device = d2
 
-# architecture -> modeling file the checkpoint must ship with (written by the reference, src/patchers/)
+# architecture -> modeling file the checkpoint ships with (this engine's own, modegpt_amd/patchers/; file and class
+# names are the reference's so config.auto_map is unchanged)
+PATCHERS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "patchers")
 REBUILD_FILES = {"opt": "OPTRebuild.py", "llama": "LlamaRebuild.py", "qwen": "DenseQwenRebuild.py"}
 
 
@@ -90,7 +92,7 @@ def reload_compressed_model(model_dir: str, device="cuda:0", tokenizer_source: s
 
 
 def save_compressed_model(adapter, rotary_masks, save_dir: str, source_model_name: str,
-                          patchers_dir: str = "./src/patchers"):
+                          patchers_dir: str = PATCHERS_DIR):
     """Write the artefact set the reference's loader expects: pytorch_model*.bin (safe_serialization=False is passed as
     upstream does; transformers >= 5 ignores it and writes model.safetensors, which the same loader reads),
     tokenizer files, rotary_masks.pt + config.mask_path (absolute), config dtype bfloat16, the architecture's
@@ -106,12 +108,7 @@ def save_compressed_model(adapter, rotary_masks, save_dir: str, source_model_nam
         tokenizer.save_pretrained(save_dir)
     if mask_path is not None:
         torch.save(rotary_masks, mask_path)
-    rebuild = os.path.join(patchers_dir, rebuild_file_for(adapter.arch))
-    if os.path.exists(rebuild):
-        shutil.copy(rebuild, save_dir)
-    else:
-        logger.warning(f"{rebuild} not found: checkpoint written without its modeling file (run from the reference "
-                       "checkout or pass patchers_dir)")
+    shutil.copy(os.path.join(patchers_dir, rebuild_file_for(adapter.arch)), save_dir)
     with open(os.path.join(save_dir, "tokenizer_source.txt"), "w") as f:
         f.write(source_model_name.strip())
     logger.info(f"Model, tokenizer, and tokenizer_source.txt saved to {save_dir}")

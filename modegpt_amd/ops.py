@@ -335,6 +335,37 @@ def vo_compress(cov_x: torch.Tensor, W_v: torch.Tensor, W_o: torch.Tensor, n_hea
     return (v_out, o_out, v64, o64) if want_f64 else (v_out, o_out)
 
 
+def rope_gather(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, mask: Optional[torch.Tensor], n_heads: int,
+                n_kv: int, head_dim: int, norm_weight: Optional[torch.Tensor] = None, eps: float = 1e-6) -> torch.Tensor:
+    """Rotary embedding of a compressed q / k projection.  x: [B, T, n_heads*r] (bf16 / f16 / f32, last dim
+    contiguous); cos, sin: [B or 1, T, head_dim]; mask: int64 [n_kv, r] or None; returns [B, n_heads, T, r].
+    With `norm_weight` ([head_dim]) the Qwen3 masked RMSNorm runs first (DenseQwenRebuild.py:262-286)."""
+    _need_gpu(x, cos, sin)
+    lib = _lib.load()
+    B, T, width = x.shape
+    r = width // n_heads
+    if r * n_heads != width:
+        raise ValueError(f"rope_gather: projection width {width} is not a multiple of n_heads={n_heads}")
+    if x.stride(2) != 1 or x.stride(0) != T * x.stride(1):
+        x = x.contiguous()
+    cos = cos.to(x.dtype).contiguous()
+    sin = sin.to(x.dtype).contiguous()
+    if cos.shape != sin.shape or cos.shape[-2:] != (T, head_dim) or cos.shape[0] not in (1, B):
+        raise ValueError(f"rope_gather: cos/sin {tuple(cos.shape)} / {tuple(sin.shape)} do not fit [B or 1, {T}, {head_dim}]")
+    if mask is not None:
+        if mask.dtype != torch.int64 or tuple(mask.shape) != (n_kv, r):
+            raise ValueError(f"rope_gather: mask must be int64 [{n_kv}, {r}], got {mask.dtype} {tuple(mask.shape)}")
+        mask = mask.contiguous()
+    if norm_weight is not None:
+        norm_weight = norm_weight.detach().to(x.dtype).contiguous()
+    out = torch.empty(B, n_heads, T, r, dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.mdg_rope_gather(x.data_ptr(), _DT[x.dtype], x.stride(1), B, T, n_heads, n_kv, r, head_dim,
+                                  cos.data_ptr(), sin.data_ptr(), 0 if cos.shape[0] == 1 else T * head_dim, _p(mask),
+                                  _p(norm_weight), float(eps), out.data_ptr(), _stream(x)), "mdg_rope_gather")
+    return out
+
+
 def cast_transpose(x: torch.Tensor) -> torch.Tensor:
     """bf16(x^T) for an fp64 matrix, with torch's double->float->bf16 rounding."""
     _need_gpu(x)

@@ -26,9 +26,7 @@ from .compression.compress_qk import compress_qk
 from .compression.compress_vo import compress_vo
 from .compression_utils import allocate_global_sparsity
 from .eval import compute_perplexity
-from .model_utils import (rebuild_file_for, reload_compressed_model, save_compressed_model,
-                          start_memory_usage_worker)
-from .patchers import install_compressed_attention
+from .model_utils import reload_compressed_model, save_compressed_model, start_memory_usage_worker
 
 LAYERS_PER_STEP = 48          # src/run_modegpt.py:107
 DEFAULT_ORDER = "mlp,qk,vo"   # upstream leaves --order unset and then fails on `"mlp" in None`
@@ -102,15 +100,10 @@ def main(trial=None, config: Optional[CompressionConfig] = None):
     adapter.convert_model(saved_layers_dir=config.temp_storage_dir)
     adapter.patch_config()
     save_compressed_model(adapter, rotary_masks=rotary_masks, save_dir=save_dir, source_model_name=config.model)
-    if os.path.exists(os.path.join(save_dir, rebuild_file_for(adapter.arch))):
-        # the reference's flow: reload the checkpoint through its patched modeling file (trust_remote_code)
-        del model, tokenizer
-        _free()
-        adapter.model, adapter.tokenizer = reload_compressed_model(save_dir)
-    else:
-        # not running from the reference checkout: evaluate the live model with the in-process compressed attention
-        logger.warning("no *Rebuild.py next to the checkpoint: evaluating the converted model in process")
-        install_compressed_attention(adapter, rotary_masks if adapter.arch != "opt" else None)
+    # the reference's flow: reload the checkpoint through the modeling file shipped with it (trust_remote_code)
+    del model, tokenizer
+    _free()
+    adapter.model, adapter.tokenizer = reload_compressed_model(save_dir)
     ppl = compute_perplexity(adapter.model, adapter.tokenizer, dataset=config.dataset, adapter=adapter)
     adapter.metrics[f"ppl-{config.dataset}"] = ppl
     adapter.save_metrics()

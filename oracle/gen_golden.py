@@ -17,6 +17,8 @@ What is pinned by the reference's own code (imported, device constants patched
   G5 compress_head_grouped / compress_head
   G6 allocate_global_sparsity
   G7 rank rules of compress_qk / compress_vo (captured through stubs)
+  G8 compressed-attention semantics: src/patchers/LlamaRebuild.apply_rotary_pos_emb with a rotary mask and
+     src/patchers/DenseQwenRebuild.Qwen3Attention._masked_rms_norm (bf16 / fp16 / fp32 inputs) -> rope.npz
 While generating, every reference output is also compared with the oracle and
 the max deviation is printed.
 """
@@ -54,8 +56,23 @@ def make_weight(gen, rows, cols):
     return (torch.randn(rows, cols, generator=gen, dtype=torch.float32) * 0.02).to(BF16)
 
 
+def reference_on_path(ref_root):
+    """Make `import src...` mean the reference checkout.  The repo root carries its own `src` package (the drop-in alias
+    of the reference's command line); it must not be importable while vectors are generated, or the 'reference' outputs
+    would silently be this engine's."""
+    repo = os.path.dirname(HERE)
+    sys.path[:] = [p for p in sys.path if os.path.abspath(p or ".") != repo]
+    for name in [m for m in sys.modules if m == "src" or m.startswith("src.")]:
+        del sys.modules[name]
+    if ref_root not in sys.path:
+        sys.path.insert(0, ref_root)
+    import src
+    where = sorted({os.path.abspath(p) for p in src.__path__})
+    assert where == [os.path.join(os.path.abspath(ref_root), "src")], f"`src` resolves to {where}, not the reference"
+
+
 def load_reference(ref_root):
-    sys.path.insert(0, ref_root)
+    reference_on_path(ref_root)
     import src.model_utils  # noqa: F401
     import src.compression_utils as cu
     import src.compression.compress_mlp as cm
@@ -314,13 +331,63 @@ def gen_misc(R, outdir):
     np.savez_compressed(os.path.join(outdir, "misc.npz"), **out)
 
 
+def gen_rope(ref_root, outdir):
+    """G8.  Inputs are stored as raw bits (uint16 for the half types) so the fixture replays exactly."""
+    reference_on_path(ref_root)
+    import src.patchers.LlamaRebuild as LR
+    import src.patchers.DenseQwenRebuild as QR
+    out = {}
+    gen = torch.Generator().manual_seed(808)
+    bits = lambda t: (t.contiguous().view(torch.int16).numpy().view(np.uint16) if t.element_size() == 2
+                      else t.contiguous().numpy())
+    cases = [("bf16", BF16, 2, 9, 4, 2, 16, 12), ("f16", torch.float16, 1, 21, 6, 2, 32, 22),
+             ("f32", torch.float32, 2, 5, 4, 4, 16, 10), ("bf16_full", BF16, 1, 17, 4, 2, 16, 16)]
+    for name, dt, B, T, n_h, n_kv, hd, r in cases:
+        half = r // 2
+        q = torch.randn(B, n_h, T, r, generator=gen).to(dt)
+        k = torch.randn(B, n_kv, T, r, generator=gen).to(dt)
+        pos = torch.arange(T, dtype=torch.float32)[None].expand(B, T) + torch.arange(B, dtype=torch.float32)[:, None] * 3
+        inv_freq = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+        ang = pos[..., None] * inv_freq
+        emb = torch.cat((ang, ang), dim=-1)
+        cos, sin = emb.cos().to(dt), emb.sin().to(dt)
+        if name.endswith("full"):
+            mask = None
+        else:  # the shape compress_qk produces: score-ordered pair indices, then the same + hd/2
+            idx = torch.stack([torch.randperm(hd // 2, generator=gen)[:half] for _ in range(n_kv)])
+            mask = torch.cat((idx, idx + hd // 2), dim=1)
+        qe, ke = LR.apply_rotary_pos_emb(q, k, cos, sin, rotary_mask=mask)
+        mq, mk = O.apply_rotary_compressed(q, k, cos, sin, mask)
+        assert torch.equal(qe, mq) and torch.equal(ke, mk), "oracle rotary differs from the reference"
+        for key, t in (("q", q), ("k", k), ("cos", cos), ("sin", sin), ("q_out", qe), ("k_out", ke)):
+            out[f"{name}_{key}"] = bits(t)
+        out[f"{name}_mask"] = np.zeros((0, 0), np.int64) if mask is None else mask.numpy()
+        out[f"{name}_dims"] = np.array([B, T, n_h, n_kv, hd, r])
+        if mask is not None:
+            w = (1 + 0.1 * torch.randn(hd, generator=gen)).to(dt)
+            me = types.SimpleNamespace(layer_rotary_mask=mask, num_key_value_groups=n_h // n_kv)
+            norm = types.SimpleNamespace(weight=w, variance_epsilon=1e-6)
+            xq = q.transpose(1, 2).contiguous()   # [B, T, H, r], the layout the reference norms in
+            xk = k.transpose(1, 2).contiguous()
+            nq = QR.Qwen3Attention._masked_rms_norm(me, xq, norm, is_query=True)
+            nk = QR.Qwen3Attention._masked_rms_norm(me, xk, norm, is_query=False)
+            assert torch.equal(nq, O.masked_rms_norm(xq, w, 1e-6, mask, n_h // n_kv))
+            assert torch.equal(nk, O.masked_rms_norm(xk, w, 1e-6, mask, 1))
+            out[f"{name}_norm_w"], out[f"{name}_nq"], out[f"{name}_nk"] = bits(w), bits(nq), bits(nk)
+        print(f"[rope] {name}: oracle == reference (rotary{'' if mask is None else ' + masked norm'}), bit for bit")
+    np.savez_compressed(os.path.join(outdir, "rope.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="", help="'rope' regenerates rope.npz alone")
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     torch.set_num_threads(8)
+    if a.only == "rope":
+        return gen_rope(a.ref, a.out)
     R = load_reference(a.ref)
     recipe = {"nystrom_ridge": 1e-4, "ridge_qk": 1e-2, "ridge_vo": 1e-5}  # tests.sh:100-104
     default = {"nystrom_ridge": 1e-2, "ridge_qk": 1e-6, "ridge_vo": 1e-4}  # CompressionConfig.py:19,32-33
@@ -330,6 +397,7 @@ def main():
     gen_case(R, "tiny_opt", "opt", 64, 160, 4, 4, 16, 512, 2, 0.8, 14, default, a.out)
     gen_case(R, "med_gqa", "llama", 128, 384, 2, 1, 64, 1024, 4, 0.7, 15, recipe, a.out)
     gen_misc(R, a.out)
+    gen_rope(a.ref, a.out)
 
 
 if __name__ == "__main__":

@@ -340,6 +340,47 @@ def compress_vo_layer(W_v, W_o, cov_x, n_heads, n_kv_heads, head_dim, rank, ridg
 
 
 # ----------------------------------------------------------------------------
+# compressed-model attention semantics: what a compressed
+# checkpoint's modeling file does with the rotary masks
+# ----------------------------------------------------------------------------
+
+def rotate_half(x: torch.Tensor) -> torch.Tensor:
+    """cat(-x[half:], x[:half]) along the last axis.  LlamaRebuild.py:120-124."""
+    h = x.shape[-1] // 2
+    return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
+
+
+def apply_rotary_compressed(q: torch.Tensor, k: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
+                            rotary_mask: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+    """q [B, n_h, T, r], k [B, n_kv, T, r], cos/sin [B, T, hd], rotary_mask int64 [n_kv, r] or None.
+    Every head gathers its own columns of cos/sin (query heads share the row of their kv head), then the usual
+    x*cos + rotate_half(x)*sin in the tensors' dtype, one rounded op at a time.  LlamaRebuild.py:153-186.
+    Quirk kept: on the masked route the gather index has batch extent 1 (LlamaRebuild.py:167-175), so torch.gather
+    returns batch 0's cos/sin rows and those are broadcast to every batch; position tables that differ per batch
+    (e.g. left-padded position_ids) are therefore NOT honoured there, while the mask-free route uses them."""
+    if rotary_mask is None:
+        c, s = cos.unsqueeze(1), sin.unsqueeze(1)
+        return q * c + rotate_half(q) * s, k * c + rotate_half(k) * s
+    mk = rotary_mask
+    mq = torch.repeat_interleave(mk, q.shape[1] // k.shape[1], dim=0)
+    pick = lambda tab, m: tab[:1, :, m].permute(0, 2, 1, 3)           # [1, T, H, r] -> [1, H, T, r]
+    q_out = q * pick(cos, mq) + rotate_half(q) * pick(sin, mq)
+    k_out = k * pick(cos, mk) + rotate_half(k) * pick(sin, mk)
+    return q_out, k_out
+
+
+def masked_rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float, rotary_mask: torch.Tensor,
+                    groups: int) -> torch.Tensor:
+    """x [B, T, H, r]: RMSNorm over the r kept columns in fp32, scaled by the norm weight gathered per head through the
+    rotary mask (groups = query heads per kv head, 1 for keys); product in fp32, then back to x.dtype.
+    DenseQwenRebuild.py:262-286."""
+    xf = x.to(torch.float32)
+    normed = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
+    m = torch.repeat_interleave(rotary_mask, groups, dim=0) if groups > 1 else rotary_mask
+    return (weight[m][None, None] * normed).to(x.dtype)
+
+
+# ----------------------------------------------------------------------------
 # whole layer (used by bench.py's cpu_baseline leg and the end-to-end tests)
 # ----------------------------------------------------------------------------
 

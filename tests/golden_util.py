@@ -53,3 +53,25 @@ def canon_rows(v, r):
     s = torch.sign(v[torch.arange(v.shape[0]), i])
     s[s == 0] = 1
     return v * s[:, None], s
+
+
+ROPE_CASES = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "bf16_full": torch.bfloat16}
+
+
+class RopeCase:
+    """One entry of rope.npz: inputs and the reference's outputs of apply_rotary_pos_emb (masked) / _masked_rms_norm."""
+
+    def __init__(self, name):
+        z = np.load(os.path.join(GOLDEN_DIR, "rope.npz"))
+        self.dtype = ROPE_CASES[name]
+
+        def t(key):
+            a = z[f"{name}_{key}"]
+            return torch.from_numpy(a.view(np.int16).copy()).view(self.dtype) if a.dtype == np.uint16 else torch.from_numpy(a)
+        self.B, self.T, self.n_h, self.n_kv, self.hd, self.r = [int(v) for v in z[f"{name}_dims"]]
+        self.q, self.k, self.cos, self.sin, self.q_out, self.k_out = (t(k) for k in ("q", "k", "cos", "sin", "q_out", "k_out"))
+        m = z[f"{name}_mask"]
+        self.mask = None if m.size == 0 else torch.from_numpy(m)
+        self.has_norm = f"{name}_norm_w" in z.files
+        if self.has_norm:
+            self.norm_w, self.nq, self.nk = t("norm_w"), t("nq"), t("nk")

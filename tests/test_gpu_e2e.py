@@ -451,7 +451,8 @@ def test_other_baseline_shapes_one_layer(dev, name, keep):
 def test_run_modegpt_main_on_local_checkpoint(dev, tmp_path, monkeypatch):
     """The driver end to end, exactly as `python -m src.run_modegpt` runs it: a random-init Llama saved to a local
     directory with a toy tokenizer, dataset "synthetic" (no network), 30 % compression, checkpoint written in the
-    reference's artefact set, compressed perplexity evaluated in process."""
+    reference's artefact set (with this engine's LlamaRebuild.py), reloaded through config.auto_map, compressed
+    perplexity evaluated on the reloaded model."""
     transformers = pytest.importorskip("transformers")
     tokenizers = pytest.importorskip("tokenizers")
     import json
@@ -479,6 +480,7 @@ def test_run_modegpt_main_on_local_checkpoint(dev, tmp_path, monkeypatch):
     out = tmp_path / "out" / "model"
     names = set(os.listdir(out))
     assert "rotary_masks.pt" in names and "tokenizer_source.txt" in names and "config.json" in names
+    assert "LlamaRebuild.py" in names
     # safe_serialization=False is requested as upstream does; transformers >= 5 ignores it and writes safetensors,
     # which the same from_pretrained call loads -- accept either weight file
     assert any((n.startswith("pytorch_model") and n.endswith(".bin")) or n.endswith(".safetensors") for n in names), names
@@ -493,3 +495,85 @@ def test_run_modegpt_main_on_local_checkpoint(dev, tmp_path, monkeypatch):
         for suffix in ("mlp", "qk", "vo"):
             assert (tmp_path / "out" / "layers" / f"layer_{i}_{suffix}").exists()
     assert (tmp_path / "metrics" / "metrics.json").exists()
+
+
+def _eager_compressed_attention(model, arch, masks):
+    """Checker: the reference's compressed attention forward restated with torch eager ops + the oracle's rotary /
+    masked-norm functions (LlamaRebuild.py:312-366, DenseQwenRebuild.py:288-345), patched onto the stock modules."""
+    import types
+
+    import torch.nn.functional as F
+
+    def forward(self, hidden_states, position_embeddings=None, attention_mask=None, past_key_values=None, **kw):
+        B, T, _ = hidden_states.shape
+        n_h, n_kv = self.config.num_attention_heads, self.config.num_key_value_heads
+        q, k, v = self.q_proj(hidden_states), self.k_proj(hidden_states), self.v_proj(hidden_states)
+        r = q.shape[-1] // n_h
+        q, k = q.view(B, T, n_h, r), k.view(B, T, n_kv, r)
+        m = self._eager_mask
+        if getattr(self, "q_norm", None) is not None:
+            q = O.masked_rms_norm(q, self.q_norm.weight, self.q_norm.variance_epsilon, m, n_h // n_kv)
+            k = O.masked_rms_norm(k, self.k_norm.weight, self.k_norm.variance_epsilon, m, 1)
+        q, k = q.transpose(1, 2), k.transpose(1, 2)
+        v = v.view(B, T, n_kv, -1).transpose(1, 2)
+        cos, sin = position_embeddings
+        q, k = O.apply_rotary_compressed(q, k, cos, sin, m)
+        k = k.repeat_interleave(n_h // n_kv, dim=1)
+        v = v.repeat_interleave(n_h // n_kv, dim=1)
+        out = F.scaled_dot_product_attention(q, k, v, is_causal=True, scale=float(r) ** -0.5)
+        return self.o_proj(out.transpose(1, 2).reshape(B, T, -1)), None
+
+    for i, layer in enumerate(model.model.layers):
+        layer.self_attn._eager_mask = masks[i].to(layer.self_attn.q_proj.weight.device)
+        layer.self_attn.forward = types.MethodType(forward, layer.self_attn)
+
+
+@pytest.mark.parametrize("kind", ["llama_gqa", "llama_mha", "qwen3"])
+def test_compressed_attention_kernel_vs_eager_and_reload(dev, kind, tmp_path):
+    """SURVEY 8(f) row 3 at model level.  A model compressed at keep 0.6 gives the same logits (a) with the HIP
+    rope-gather forward installed on the live model, (b) with the reference's eager expression (oracle functions) on
+    the same weights, and (c) after save_compressed_model + from_pretrained(trust_remote_code) through the shipped
+    modeling file.  (a) vs (c) must be identical; (a) vs (b) may differ by the attention backend's rounding only."""
+    transformers = pytest.importorskip("transformers")
+    from modegpt_amd.adapters.CompressionConfig import CompressionConfig
+    from modegpt_amd.adapters.model_adapter import ModelAdapter
+    from modegpt_amd.calibration import load_calibs
+    from modegpt_amd.compression.compress_mlp import compress_nystrom
+    from modegpt_amd.compression.compress_qk import compress_qk
+    from modegpt_amd.compression.compress_vo import compress_vo
+    from modegpt_amd.model_utils import save_compressed_model
+    from modegpt_amd.patchers import install_compressed_attention
+
+    model = _tiny_model(kind, dev, init_std=0.15)
+    ad = ModelAdapter.from_model(model, None)
+    ad.config = CompressionConfig(temp_storage_dir=str(tmp_path / "layers"), nystrom_ridge=1e-4, ridge_qk=1e-2,
+                                  ridge_vo=1e-5, dataset="synthetic", order="mlp,qk,vo")
+    c = load_calibs(ad, n_samples=8, batch_size=4, dataset="synthetic", target_layers=[])
+    keep, layers = [0.6] * ad.n_layers, list(range(ad.n_layers))
+    compress_nystrom(ad, c[0], keep, layers)
+    masks = compress_qk(ad, (c[1], c[2]), keep, target_layers=layers)
+    compress_vo(ad, c[3], keep, target_layers=layers)
+    ad.convert_model(saved_layers_dir=ad.config.temp_storage_dir)
+    ids = torch.randint(0, 211, (3, 40), generator=torch.Generator().manual_seed(5)).to(dev)
+
+    ad.patch_config()
+    out = str(tmp_path / "ckpt")
+    save_compressed_model(ad, rotary_masks=masks, save_dir=out, source_model_name="none")
+    loaded = transformers.AutoModelForCausalLM.from_pretrained(out, trust_remote_code=True, dtype=torch.bfloat16).to(dev).eval()
+    assert "Rebuild" in type(loaded).__module__
+    # _tiny_model casts the whole module to bf16, rotary inv_freq included; from_pretrained keeps that buffer in fp32.
+    # Give the live model the loader's table so the two forwards see the same cos / sin.
+    model.model.rotary_emb.inv_freq = loaded.model.rotary_emb.inv_freq.clone()
+
+    install_compressed_attention(ad, masks)
+    with torch.no_grad():
+        live = model(ids).logits.float()
+        again = loaded(ids).logits.float()
+    assert bool(torch.isfinite(live).all())
+    assert torch.equal(live, again), "reloaded checkpoint must reproduce the live compressed model exactly"
+
+    _eager_compressed_attention(model, ad.arch, masks)
+    with torch.no_grad():
+        eager = model(ids).logits.float()
+    err = (live - eager).abs().max().item() / eager.abs().max().item()
+    assert err < 2e-2, f"HIP compressed attention vs eager restatement: {err:.3e}"

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import modegpt_oracle as O
-from tests.golden_util import CASES, Case, canon_rows, vo_products
+from tests.golden_util import CASES, ROPE_CASES, Case, RopeCase, canon_rows, vo_products
 
 pytestmark = pytest.mark.gpu
 F64 = torch.float64
@@ -399,3 +399,99 @@ def test_weights_not_bf16_are_widened_exactly(ops, dev, name, wdt):
     r = c.vo_rank
     assert rel(vo_products(v64.cpu(), o64.cpu(), c.n_h, c.n_kv, r), vo_products(v_ref, o_ref, c.n_h, c.n_kv, r)) < 1e-8
     assert v.dtype == torch.bfloat16 and o.dtype == torch.bfloat16
+
+
+# ---------------------------------------------------------------- compressed-model attention
+def _ulp_mismatch(got, want):
+    """(fraction of elements that differ, max difference in units of the last place of the element dtype)."""
+    if got.dtype == torch.float32:
+        d = (got.view(torch.int32).long() - want.view(torch.int32).long()).abs()
+    else:
+        d = (got.view(torch.int16).long() - want.view(torch.int16).long()).abs()
+    return (d != 0).float().mean().item(), int(d.max())
+
+
+def _rope_through_kernel(ops, dev, x_bhtr, cos, sin, mask, n_kv, hd, norm_w=None):
+    """x given in the reference's [B, H, T, r] layout; the kernel takes the projection layout [B, T, H*r]."""
+    B, H, T, r = x_bhtr.shape
+    x = x_bhtr.transpose(1, 2).reshape(B, T, H * r).contiguous().to(dev)
+    cs = (cos[:1], sin[:1]) if mask is not None else (cos, sin)      # masked route: batch 0's table (oracle docstring)
+    return ops.rope_gather(x, cs[0].to(dev), cs[1].to(dev), None if mask is None else mask.to(dev), H, n_kv, hd,
+                           norm_weight=None if norm_w is None else norm_w.to(dev)).cpu()
+
+
+@pytest.mark.parametrize("name", list(ROPE_CASES))
+def test_rope_golden(ops, dev, name):
+    """Rotation: bit-identical to the reference's eager expression, for q (grouped heads) and k."""
+    c = RopeCase(name)
+    assert torch.equal(_rope_through_kernel(ops, dev, c.q, c.cos, c.sin, c.mask, c.n_kv, c.hd), c.q_out)
+    assert torch.equal(_rope_through_kernel(ops, dev, c.k, c.cos, c.sin, c.mask, c.n_kv, c.hd), c.k_out)
+
+
+@pytest.mark.parametrize("name", [n for n in ROPE_CASES if n != "bf16_full"])
+def test_rope_masked_norm_golden(ops, dev, name):
+    """Qwen3 route: masked RMSNorm then rotation.  The fp32 sum of squares has no defined order in torch, so the
+    normalised value may differ in its last place on a few elements; the bar is <= 1 ulp of the dtype on < 1 % of
+    elements for the half types; for fp32 (where the rotation's sum can cancel, so ulps of the result say little)
+    |diff| <= 4 * 2^-23 * max|x|."""
+    c = RopeCase(name)
+    nq, nk = c.nq.transpose(1, 2), c.nk.transpose(1, 2)       # the reference's normed tensors, as [B, H, T, r]
+    want_q, want_k = O.apply_rotary_compressed(nq, nk, c.cos, c.sin, c.mask)
+    got_q = _rope_through_kernel(ops, dev, c.q, c.cos, c.sin, c.mask, c.n_kv, c.hd, c.norm_w)
+    got_k = _rope_through_kernel(ops, dev, c.k, c.cos, c.sin, c.mask, c.n_kv, c.hd, c.norm_w)
+    for got, want in ((got_q, want_q), (got_k, want_k)):
+        frac, ulps = _ulp_mismatch(got, want)
+        if c.dtype == torch.float32:
+            assert (got - want).abs().max().item() <= 4 * 2 ** -23 * want.abs().max().item(), (frac, ulps)
+        else:
+            assert ulps <= 1 and frac < 0.01, (frac, ulps)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("B,T,n_h,n_kv,hd,r,shared", [
+    (2, 100, 8, 2, 128, 88, True),     # Llama-3 style, r/2 = 44 -> 8-byte packs, T not a multiple of 16
+    (1, 33, 4, 4, 128, 90, True),      # r/2 = 45: scalar packs
+    (3, 16, 6, 3, 64, 44, False),      # r/2 = 22: 4-byte packs; per-batch cos/sin on the mask-free route below
+    (1, 1, 32, 8, 128, 128, True),     # decode step, nothing dropped
+    (2, 7, 2, 1, 256, 256, True),      # widest head the kernel takes
+    (1, 5, 2, 2, 16, 2, True),         # one pair kept
+])
+def test_rope_shapes(ops, dev, dt, B, T, n_h, n_kv, hd, r, shared):
+    gen = torch.Generator().manual_seed(B * 1000 + T)
+    q = torch.randn(B, n_h, T, r, generator=gen).to(dt)
+    ang = torch.rand(B, T, hd // 2, generator=gen) * 6.28
+    if shared:
+        ang = ang[:1].expand(B, T, hd // 2)
+    emb = torch.cat((ang, ang), -1)
+    cos, sin = emb.cos().to(dt), emb.sin().to(dt)
+    idx = torch.stack([torch.randperm(hd // 2, generator=gen)[:r // 2] for _ in range(n_kv)])
+    mask = torch.cat((idx, idx + hd // 2), dim=1)
+    kv_like = q[:, :n_kv]
+    want_q, want_k = O.apply_rotary_compressed(q, kv_like, cos, sin, mask)
+    assert torch.equal(_rope_through_kernel(ops, dev, q, cos, sin, mask, n_kv, hd), want_q)
+    assert torch.equal(_rope_through_kernel(ops, dev, kv_like, cos, sin, mask, n_kv, hd), want_k)
+    if r == hd:   # mask-free route honours per-batch tables
+        want_q, _ = O.apply_rotary_compressed(q, kv_like, cos, sin, None)
+        assert torch.equal(_rope_through_kernel(ops, dev, q, cos, sin, None, n_kv, hd), want_q)
+
+
+def test_rope_strided_input_and_errors(ops, dev):
+    """q/k/v often come out of one fused projection: the kernel reads a column slice of a wider row in place."""
+    gen = torch.Generator().manual_seed(3)
+    B, T, n_h, n_kv, hd, r = 2, 40, 4, 2, 32, 24
+    wide = torch.randn(B, T, n_h * r + 50, generator=gen).to(torch.bfloat16).to(dev)
+    x = wide[:, :, 10:10 + n_h * r]                       # 2-byte aligned only
+    emb = torch.rand(1, T, hd, generator=gen)
+    cos, sin = emb.cos().to(torch.bfloat16), emb.sin().to(torch.bfloat16)
+    idx = torch.stack([torch.randperm(hd // 2, generator=gen)[:r // 2] for _ in range(n_kv)])
+    mask = torch.cat((idx, idx + hd // 2), dim=1)
+    got = ops.rope_gather(x, cos.to(dev), sin.to(dev), mask.to(dev), n_h, n_kv, hd).cpu()
+    q = x.cpu().view(B, T, n_h, r).transpose(1, 2)
+    want, _ = O.apply_rotary_compressed(q, q[:, :n_kv], cos, sin, mask)
+    assert torch.equal(got, want)
+    with pytest.raises(ValueError):
+        ops.rope_gather(x, cos.to(dev), sin.to(dev), mask[:, :-2].to(dev), n_h, n_kv, hd)
+    with pytest.raises(RuntimeError, match="even"):
+        ops.rope_gather(wide[:, :, :n_h * 3], cos.to(dev), sin.to(dev), None, n_h, n_kv, hd)
+    with pytest.raises(RuntimeError, match="CPU tensor"):
+        ops.rope_gather(x.cpu(), cos, sin, mask, n_h, n_kv, hd)

@@ -135,3 +135,55 @@ def test_sharding_partition_and_record_roundtrip():
             assert torch.equal(out[k], v)
     recs = S.allgather_records([S.pack_layer(0, t, None)], 2, 1)
     assert len(recs) == 1 and S.unpack_layer(recs[0])[2] is None
+
+
+@pytest.mark.parametrize("kind", ["llama", "qwen3", "opt"])
+def test_checkpoint_loads_through_its_modeling_file(kind, tmp_path):
+    """SURVEY 8(f) rows 1+3 on the host: a checkpoint written by save_compressed_model carries this engine's
+    *Rebuild.py; AutoModelForCausalLM.from_pretrained(trust_remote_code=True) follows config.auto_map into it, gets the
+    per-layer compressed shapes from the config ranks, the rotary masks from config.mask_path, and the saved weights
+    back bit for bit.  (No forward here: the compressed attention runs on the GPU only.)"""
+    transformers = pytest.importorskip("transformers")
+    from modegpt_amd.adapters.model_adapter import ModelAdapter
+    from modegpt_amd.model_utils import save_compressed_model
+    from modegpt_amd.patchers.compressed_attention import _resize
+    torch.manual_seed(0)
+    if kind == "opt":
+        cfg = transformers.OPTConfig(hidden_size=64, ffn_dim=160, num_hidden_layers=2, num_attention_heads=4,
+                                     vocab_size=97, max_position_embeddings=32, word_embed_proj_dim=64)
+        model = transformers.OPTForCausalLM(cfg)
+    elif kind == "qwen3":
+        cfg = transformers.Qwen3Config(hidden_size=64, intermediate_size=160, num_hidden_layers=2, num_attention_heads=4,
+                                       num_key_value_heads=2, head_dim=16, vocab_size=97, max_position_embeddings=32)
+        model = transformers.Qwen3ForCausalLM(cfg)
+    else:
+        cfg = transformers.LlamaConfig(hidden_size=64, intermediate_size=160, num_hidden_layers=2, num_attention_heads=4,
+                                       num_key_value_heads=2, head_dim=16, vocab_size=97, max_position_embeddings=32)
+        model = transformers.LlamaForCausalLM(cfg)
+    model = model.to(torch.bfloat16).eval()
+    ad = ModelAdapter.from_model(model, None)
+    # stand-in for compress + convert_model (GPU work): per-layer shapes that DIFFER between layers
+    n_h, n_kv, hd = ad.n_heads, ad.n_kv_heads, ad.head_dim
+    masks = []
+    for i in range(ad.n_layers):
+        r_qk, r_vo, r_mlp = 8 + 2 * i, 9 + i, 100 + 7 * i
+        mk = lambda rows, cols: torch.nn.Linear(cols, rows, bias=False, dtype=torch.bfloat16)
+        ad.replace_attn_layers(i, mk(n_h * r_qk, 64), mk(n_kv * r_qk, 64), mk(n_kv * r_vo, 64), mk(64, n_h * r_vo))
+        ad.replace_mlp_layers(i, mk(r_mlp, 64), mk(64, r_mlp), None if kind == "opt" else mk(r_mlp, 64))
+        idx = torch.stack([torch.randperm(hd // 2)[:r_qk // 2] for _ in range(n_kv)])
+        masks.append(torch.cat((idx, idx + hd // 2), dim=1))
+    ad.patch_config()
+    out = str(tmp_path / "model")
+    save_compressed_model(ad, rotary_masks=masks if kind != "opt" else [], save_dir=out, source_model_name="none")
+    fname = {"llama": "LlamaRebuild.py", "qwen3": "DenseQwenRebuild.py", "opt": "OPTRebuild.py"}[kind]
+    assert os.path.exists(os.path.join(out, fname))
+    loaded = transformers.AutoModelForCausalLM.from_pretrained(out, trust_remote_code=True, dtype=torch.bfloat16)
+    assert type(loaded).__module__.endswith(fname[:-3]), type(loaded).__module__
+    want, got = model.state_dict(), loaded.state_dict()
+    assert set(want) == set(got)
+    for key in want:
+        assert want[key].shape == got[key].shape and torch.equal(want[key], got[key]), key
+    if kind != "opt":
+        for i, layer in enumerate(loaded.model.layers):
+            assert torch.equal(layer.self_attn.layer_rotary_mask.cpu(), masks[i])
+            assert "layer_rotary_mask" not in got

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import modegpt_oracle as O
-from tests.golden_util import CASES, Case, load_misc, vo_products
+from tests.golden_util import CASES, ROPE_CASES, Case, RopeCase, load_misc, vo_products
 
 F64 = torch.float64
 
@@ -105,3 +105,16 @@ def test_misc_allocate_and_ranks():
     s, si = O.sqrt_M(torch.from_numpy(z["rd_M"]), 1e-5, inverse_sqrt=True)
     assert rel(s, torch.from_numpy(z["rd_sqrt"])) < 1e-12
     assert rel(si, torch.from_numpy(z["rd_invsqrt"])) < 1e-9
+
+
+@pytest.mark.parametrize("name", list(ROPE_CASES))
+def test_compressed_rotary_and_masked_norm(name):
+    """G8: the oracle's restatement of the compressed checkpoint's attention semantics replays the reference's outputs
+    (LlamaRebuild.apply_rotary_pos_emb with a rotary mask, DenseQwenRebuild._masked_rms_norm) bit for bit."""
+    c = RopeCase(name)
+    q, k = O.apply_rotary_compressed(c.q, c.k, c.cos, c.sin, c.mask)
+    assert torch.equal(q, c.q_out) and torch.equal(k, c.k_out)
+    if c.has_norm:
+        nq = O.masked_rms_norm(c.q.transpose(1, 2), c.norm_w, 1e-6, c.mask, c.n_h // c.n_kv)
+        nk = O.masked_rms_norm(c.k.transpose(1, 2), c.norm_w, 1e-6, c.mask, 1)
+        assert torch.equal(nq, c.nq) and torch.equal(nk, c.nk)
