@@ -19,6 +19,19 @@
 namespace mdg {
 namespace {
 
+// Sum over the 16 lanes of a DPP row, every lane ending with the same value: two quad permutes, then the row's half mirror and
+// full mirror (fp32 addition commutes, so the two sides of every exchange compute identical sums).
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float s) {
+  s = s + dpp_f32<0xB1>(s);   // quad_perm [1,0,3,2]
+  s = s + dpp_f32<0x4E>(s);   // quad_perm [2,3,0,1]
+  s = s + dpp_f32<0x141>(s);  // row_half_mirror
+  s = s + dpp_f32<0x140>(s);  // row_mirror
+  return s;
+}
+
 __device__ __forceinline__ float mul_r(float a, float b) { return a * b; }
 __device__ __forceinline__ float add_r(float a, float b) { return a + b; }
 
@@ -26,21 +39,13 @@ template <int DT> struct Lp;
 template <> struct Lp<MDG_BF16> {
   typedef bf16_t T;
   static __device__ __forceinline__ float up(T v) { return __uint_as_float(((unsigned)v) << 16); }
-  static __device__ __forceinline__ T down(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (T)0x7fc0;
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (T)(u >> 16);
-  }
+  // v_cvt_pk_bf16_f32: round to nearest even in one instruction
+  static __device__ __forceinline__ T down(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 };
 template <> struct Lp<MDG_F16> {
   typedef f16_t T;
-  static __device__ __forceinline__ float up(T v) {
-    __half_raw r;
-    r.x = v;
-    return __half2float(__half(r));
-  }
-  static __device__ __forceinline__ T down(float f) { return __half_raw(__float2half_rn(f)).x; }
+  static __device__ __forceinline__ float up(T v) { return (float)__builtin_bit_cast(_Float16, v); }
+  static __device__ __forceinline__ T down(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
 };
 template <> struct Lp<MDG_F32> {
   typedef float T;
@@ -49,7 +54,8 @@ template <> struct Lp<MDG_F32> {
 };
 
 constexpr int GROUP = 16;      // lanes that share one (token, head) row
-constexpr int ROWS = 16;       // rows (= consecutive tokens of one head) per 256-thread workgroup
+constexpr int ROWS = 16;       // thread groups per 256-thread workgroup
+constexpr int UNITS = 4;       // rows in flight per thread group: HPT heads x TPT tokens
 constexpr int MAX_HALF = 128;  // r / 2 <= 128  (head_dim <= 256)
 constexpr int N_XCD = 8;
 
@@ -65,103 +71,243 @@ struct RopeArgs {
   const void* norm_w;
   float eps;
   void* out;
-  int64_t n_tiles;  // B * ceil(T / ROWS)
-  int t_tiles;
+  unsigned n_tiles; // B * t_tiles
+  int t_tiles;      // ceil(T / (ROWS * TPT))
+  int n_kv, chunks; // kv heads; head chunks per kv head = group / HPT
+  int cs_vec16;     // cos / sin rows are 16-byte aligned and a multiple of 16 bytes long
+  int nw_vec16;     // so is the norm weight
 };
 
 template <typename E, int VEC> struct alignas(sizeof(E) * VEC) Pack { E v[VEC]; };
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // 16-byte register quad (HIP's uint4 is a union: it ends up in scratch)
 
-// blockIdx -> (token tile, head).  Workgroups are dealt round-robin to the 8 XCDs; all heads of one token tile are given
-// to the same XCD, back to back, so the pieces of a token's row that share a 128-B line meet in one L2.
-template <int DT, int VEC, bool NORM>
+// One workgroup = 16 thread groups of 16 lanes.  A thread group owns UNITS = HPT x TPT rows: HPT query heads of one kv
+// head (they share the kv head's mask row, hence the gathered cos / sin) for each of TPT tokens, and has all of their
+// loads in flight before it computes -- an elementwise kernel at 8 TB/s needs ~16 MB outstanding, a single 176-byte row
+// per 16 lanes does not get there.  blockIdx -> (token tile, kv head, head chunk): workgroups are dealt round-robin to
+// the 8 XCDs, and every head of one token tile goes to the same XCD, back to back, so the pieces of a token's row that
+// share a 128-B line meet in one L2.
+template <int DT, int VEC, bool NORM, int HPT>
 __global__ __launch_bounds__(256) void rope_gather_kernel(RopeArgs a) {
   typedef typename Lp<DT>::T E;
   typedef Pack<E, VEC> P;
-  constexpr int ITMAX = MAX_HALF / (GROUP * VEC);
-  const int64_t id = blockIdx.x;
-  const int64_t seq = id / N_XCD;
-  const int64_t tile = (seq / a.n_heads) * N_XCD + (id % N_XCD);
-  const int h = (int)(seq % a.n_heads);
+  constexpr int TPT = UNITS / HPT;
+  // grid = (8 * n_kv, ceil(n_tiles / 8), chunks): the low 3 bits of blockIdx.x are the XCD the workgroup lands on
+  const unsigned tile = blockIdx.y * N_XCD + (blockIdx.x & (N_XCD - 1));
   if (tile >= a.n_tiles) return;
-  const int64_t b = tile / a.t_tiles;
-  const int64_t t = (tile % a.t_tiles) * ROWS + (threadIdx.x / GROUP);
-  if (t >= a.T) return;  // whole 16-lane groups leave together
+  const int hk = blockIdx.x >> 3;
+  const int h0 = hk * a.group + blockIdx.z * HPT;
+  const unsigned bu = tile / (unsigned)a.t_tiles;
+  const int64_t b = bu;
+  const int64_t t0 = (int64_t)(tile - bu * (unsigned)a.t_tiles) * (ROWS * TPT) + (threadIdx.x / GROUP);
   const int l = threadIdx.x % GROUP;
   const int half = a.r >> 1;
-  const int hk = h / a.group;
-
-  const E* xrow = (const E*)a.x + (b * a.T + t) * a.ld_x + (int64_t)h * a.r;
-  const E* crow = (const E*)a.cos + b * a.cs_bstride + t * a.hd;
-  const E* srow = (const E*)a.sin + b * a.cs_bstride + t * a.hd;
+  const int iters = (half + GROUP * VEC - 1) / (GROUP * VEC);
   const int64_t* mrow = a.mask ? a.mask + (int64_t)hk * a.r : nullptr;
-  E* orow = (E*)a.out + ((b * a.n_heads + h) * a.T + t) * a.r;
+  const E* nw = (const E*)a.norm_w;
 
-  float y1[ITMAX][VEC], y2[ITMAX][VEC];
-  int m1[ITMAX][VEC], m2[ITMAX][VEC];
-  float ss = 0.f;
+  // rows of this thread group: unit u = tt * HPT + hh
+  const E* xrow[UNITS];
+  E* orow[UNITS];
+  bool live[TPT];
 #pragma unroll
-  for (int it = 0; it < ITMAX; it++) {
-    const int j0 = (it * GROUP + l) * VEC;
-    if (j0 < half) {
-      const P p1 = *(const P*)(xrow + j0), p2 = *(const P*)(xrow + half + j0);
+  for (int tt = 0; tt < TPT; tt++) {
+    const int64_t t = t0 + tt * ROWS;
+    live[tt] = t < a.T;
+    const int64_t tc = live[tt] ? t : 0;
 #pragma unroll
-      for (int v = 0; v < VEC; v++) {
-        y1[it][v] = Lp<DT>::up(p1.v[v]);
-        y2[it][v] = Lp<DT>::up(p2.v[v]);
-        int64_t i1 = mrow ? mrow[j0 + v] : (int64_t)(j0 + v);
-        int64_t i2 = mrow ? mrow[half + j0 + v] : (int64_t)(half + j0 + v);
-        m1[it][v] = (int)min(max(i1, (int64_t)0), (int64_t)a.hd - 1);  // memory safety; the binding validates masks
-        m2[it][v] = (int)min(max(i2, (int64_t)0), (int64_t)a.hd - 1);
-        if (NORM) ss = add_r(ss, add_r(mul_r(y1[it][v], y1[it][v]), mul_r(y2[it][v], y2[it][v])));
-      }
+    for (int hh = 0; hh < HPT; hh++) {
+      xrow[tt * HPT + hh] = (const E*)a.x + (b * a.T + tc) * a.ld_x + (int64_t)(h0 + hh) * a.r;
+      orow[tt * HPT + hh] = (E*)a.out + ((b * a.n_heads + h0 + hh) * a.T + tc) * a.r;
     }
   }
-  float inv = 1.f;
-  if (NORM) {
+
+  float inv[UNITS];
 #pragma unroll
-    for (int o = GROUP / 2; o > 0; o >>= 1) ss = add_r(ss, __shfl_xor(ss, o, GROUP));
-    inv = __fdiv_rn(1.f, __fsqrt_rn(add_r(__fdiv_rn(ss, (float)a.r), a.eps)));
-  }
+  for (int u = 0; u < UNITS; u++) inv[u] = 1.f;
+  if (NORM && iters > 1) {  // wide heads / narrow packs: the row does not fit one pass, take the sums first
 #pragma unroll
-  for (int it = 0; it < ITMAX; it++) {
-    const int j0 = (it * GROUP + l) * VEC;
-    if (j0 < half) {
-      P o1, o2;
-#pragma unroll
-      for (int v = 0; v < VEC; v++) {
-        float a1 = y1[it][v], a2 = y2[it][v];
-        if (NORM) {  // (gathered_weight * (x_float * rsqrt(var + eps))).to(dtype)
-          const E* w = (const E*)a.norm_w;
-          a1 = Lp<DT>::up(Lp<DT>::down(mul_r(Lp<DT>::up(w[m1[it][v]]), mul_r(a1, inv))));
-          a2 = Lp<DT>::up(Lp<DT>::down(mul_r(Lp<DT>::up(w[m2[it][v]]), mul_r(a2, inv))));
+    for (int u = 0; u < UNITS; u++) {
+      float ss = 0.f;
+      if (live[u / HPT])
+        for (int j = l; j < a.r; j += GROUP) {
+          const float v = Lp<DT>::up(xrow[u][j]);
+          ss = add_r(ss, mul_r(v, v));
         }
-        const float c1 = Lp<DT>::up(crow[m1[it][v]]), s1 = Lp<DT>::up(srow[m1[it][v]]);
-        const float c2 = Lp<DT>::up(crow[m2[it][v]]), s2 = Lp<DT>::up(srow[m2[it][v]]);
-        // q * cos + rotate_half(q) * sin, rotate_half(q) = cat(-q[half:], q[:half])
-        const float u1 = Lp<DT>::up(Lp<DT>::down(mul_r(a1, c1)));
-        const float w1 = Lp<DT>::up(Lp<DT>::down(mul_r(-a2, s1)));
-        const float u2 = Lp<DT>::up(Lp<DT>::down(mul_r(a2, c2)));
-        const float w2 = Lp<DT>::up(Lp<DT>::down(mul_r(a1, s2)));
-        o1.v[v] = Lp<DT>::down(add_r(u1, w1));
-        o2.v[v] = Lp<DT>::down(add_r(u2, w2));
+      ss = row16_sum(ss);
+      inv[u] = 1.f / sqrtf(add_r(ss / (float)a.r, a.eps));
+    }
+  }
+
+  // cos / sin rows of this thread group's tokens (and the norm weight) -> LDS, so that the gather of the kept columns is
+  // an LDS read and costs no second trip to memory.  Common case (a row is 256 bytes: head_dim 128, half types): one
+  // 16-byte load per lane and row, issued here, written to LDS only after the first packs and the mask entries are in
+  // flight too.  Everything the kernel loads is addressed unconditionally (out-of-range tokens / columns are clamped, only
+  // the stores are predicated): a predicated load makes the compiler drain the memory queue at every branch.
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  E* cs_lds = (E*)lds_raw;
+  E* nw_lds = cs_lds + (size_t)ROWS * TPT * 2 * a.hd;
+  constexpr int PER16 = 16 / (int)sizeof(E);
+  const bool one_shot = a.cs_vec16 && a.hd == GROUP * PER16;
+  u32x4 creg[TPT], sreg[TPT], wreg;
+  if (one_shot) {
+#pragma unroll
+    for (int tt = 0; tt < TPT; tt++) {
+      const int64_t t = live[tt] ? t0 + tt * ROWS : 0;
+      creg[tt] = *(const u32x4*)((const E*)a.cos + b * a.cs_bstride + t * a.hd + l * PER16);
+      sreg[tt] = *(const u32x4*)((const E*)a.sin + b * a.cs_bstride + t * a.hd + l * PER16);
+    }
+    if (NORM && a.nw_vec16) wreg = *(const u32x4*)(nw + l * PER16);
+  } else {
+#pragma unroll
+    for (int tt = 0; tt < TPT; tt++) {
+      const int64_t t = live[tt] ? t0 + tt * ROWS : 0;
+      const E* crow = (const E*)a.cos + b * a.cs_bstride + t * a.hd;
+      const E* srow = (const E*)a.sin + b * a.cs_bstride + t * a.hd;
+      E* dst = cs_lds + (size_t)((threadIdx.x / GROUP) * TPT + tt) * 2 * a.hd;
+      for (int c = l; c < a.hd; c += GROUP) {
+        dst[c] = crow[c];
+        dst[a.hd + c] = srow[c];
       }
-      *(P*)(orow + j0) = o1;
-      *(P*)(orow + half + j0) = o2;
+    }
+  }
+  if (NORM && !(one_shot && a.nw_vec16))
+    for (int c = threadIdx.x; c < a.hd; c += 256) nw_lds[c] = nw[c];
+
+  for (int it = 0; it < iters; it++) {
+    const int j0 = (it * GROUP + l) * VEC;
+    const bool on = j0 < half;
+    const int jc = on ? j0 : 0;
+    // 1. every row's two packs, all in flight together
+    P p1[UNITS], p2[UNITS];
+#pragma unroll
+    for (int u = 0; u < UNITS; u++) {
+      p1[u] = *(const P*)(xrow[u] + jc);
+      p2[u] = *(const P*)(xrow[u] + half + jc);
+    }
+    // 2. mask entries of these columns (shared by all rows)
+    int m1[VEC], m2[VEC];
+    if (mrow) {
+      const Pack<int64_t, VEC> q1 = *(const Pack<int64_t, VEC>*)(mrow + jc), q2 = *(const Pack<int64_t, VEC>*)(mrow + half + jc);
+#pragma unroll
+      for (int v = 0; v < VEC; v++) {
+        m1[v] = min(max((int)q1.v[v], 0), a.hd - 1);  // memory safety only; the binding validates masks
+        m2[v] = min(max((int)q2.v[v], 0), a.hd - 1);
+      }
+    } else {
+#pragma unroll
+      for (int v = 0; v < VEC; v++) {
+        m1[v] = jc + v;
+        m2[v] = half + jc + v;
+      }
+    }
+    if (it == 0) {
+      if (one_shot) {
+#pragma unroll
+        for (int tt = 0; tt < TPT; tt++) {
+          E* dst = cs_lds + (size_t)((threadIdx.x / GROUP) * TPT + tt) * 2 * a.hd;
+          *(u32x4*)(dst + l * PER16) = creg[tt];
+          *(u32x4*)(dst + a.hd + l * PER16) = sreg[tt];
+        }
+        if (NORM && a.nw_vec16 && threadIdx.x < GROUP) *(u32x4*)(nw_lds + l * PER16) = wreg;
+      }
+      __syncthreads();  // staged rows visible
+    }
+    float w1[VEC], w2[VEC];
+    if (NORM) {
+#pragma unroll
+      for (int v = 0; v < VEC; v++) {
+        w1[v] = Lp<DT>::up(nw_lds[m1[v]]);
+        w2[v] = Lp<DT>::up(nw_lds[m2[v]]);
+      }
+    }
+    // 3. the sum of squares of a row that fits one pass comes from the registers.  The correctly rounded 1 / sqrt costs
+    //    as much as the whole rotation: lane u of the thread group does it for unit u and the others read its result.
+    if (NORM && iters == 1) {
+      float mine = 0.f;
+#pragma unroll
+      for (int u = 0; u < UNITS; u++) {
+        float ss = 0.f;
+        if (on) {
+#pragma unroll
+          for (int v = 0; v < VEC; v++) {
+            const float y1 = Lp<DT>::up(p1[u].v[v]), y2 = Lp<DT>::up(p2[u].v[v]);
+            ss = add_r(ss, add_r(mul_r(y1, y1), mul_r(y2, y2)));
+          }
+        }
+        ss = row16_sum(ss);
+        if ((l & (UNITS - 1)) == u) mine = ss;
+      }
+      mine = 1.f / sqrtf(add_r(mine / (float)a.r, a.eps));
+      inv[0] = dpp_f32<0x00>(mine);  // quad_perm broadcasts of lane 0..3 of each quad
+      inv[1] = dpp_f32<0x55>(mine);
+      inv[2] = dpp_f32<0xAA>(mine);
+      inv[3] = dpp_f32<0xFF>(mine);
+    }
+    // 4. token by token: cos / sin of the kept columns from the staged rows (shared by the token's HPT heads), rotate, store
+#pragma unroll
+    for (int tt = 0; tt < TPT; tt++) {
+      const E* crow = cs_lds + (size_t)((threadIdx.x / GROUP) * TPT + tt) * 2 * a.hd;
+      const E* srow = crow + a.hd;
+      float c1[VEC], s1[VEC], c2[VEC], s2[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; v++) {
+        c1[v] = Lp<DT>::up(crow[m1[v]]);
+        s1[v] = Lp<DT>::up(srow[m1[v]]);
+        c2[v] = Lp<DT>::up(crow[m2[v]]);
+        s2[v] = Lp<DT>::up(srow[m2[v]]);
+      }
+#pragma unroll
+      for (int hh = 0; hh < HPT; hh++) {
+        const int u = tt * HPT + hh;
+        P o1, o2;
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+          float a1 = Lp<DT>::up(p1[u].v[v]), a2 = Lp<DT>::up(p2[u].v[v]);
+          if (NORM) {  // (gathered_weight * (x_float * rsqrt(var + eps))).to(dtype)
+            a1 = Lp<DT>::up(Lp<DT>::down(mul_r(w1[v], mul_r(a1, inv[u]))));
+            a2 = Lp<DT>::up(Lp<DT>::down(mul_r(w2[v], mul_r(a2, inv[u]))));
+          }
+          // q * cos + rotate_half(q) * sin, rotate_half(q) = cat(-q[half:], q[:half])
+          const float u1 = Lp<DT>::up(Lp<DT>::down(mul_r(a1, c1[v])));
+          const float v1 = Lp<DT>::up(Lp<DT>::down(mul_r(-a2, s1[v])));
+          const float u2 = Lp<DT>::up(Lp<DT>::down(mul_r(a2, c2[v])));
+          const float v2 = Lp<DT>::up(Lp<DT>::down(mul_r(a1, s2[v])));
+          o1.v[v] = Lp<DT>::down(add_r(u1, v1));
+          o2.v[v] = Lp<DT>::down(add_r(u2, v2));
+        }
+        if (on && live[tt]) {
+          *(P*)(orow[u] + jc) = o1;
+          *(P*)(orow[u] + half + jc) = o2;
+        }
+      }
     }
   }
 }
 
-template <int DT, int VEC> void launch_rope(const RopeArgs& a, dim3 grid, hipStream_t st) {
-  if (a.norm_w)
-    hipLaunchKernelGGL((rope_gather_kernel<DT, VEC, true>), grid, dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL((rope_gather_kernel<DT, VEC, false>), grid, dim3(256), 0, st, a);
+template <int DT, int VEC, int HPT> hipError_t launch_rope(const RopeArgs& a, dim3 grid, hipStream_t st) {
+  const size_t lds = ((size_t)ROWS * (UNITS / HPT) * 2 + 1) * a.hd * sizeof(typename Lp<DT>::T);
+  auto launch = [&](auto kernel) -> hipError_t {
+    if (lds > 64 * 1024) {  // fp32 tables of a 256-wide head with one head per thread group: above the default window
+      hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, a);
+    return hipSuccess;
+  };
+  return a.norm_w ? launch(rope_gather_kernel<DT, VEC, true, HPT>) : launch(rope_gather_kernel<DT, VEC, false, HPT>);
 }
 
-template <int DT> void launch_rope_vec(const RopeArgs& a, int vec, dim3 grid, hipStream_t st) {
-  if (vec == 4) launch_rope<DT, 4>(a, grid, st);
-  else if (vec == 2) launch_rope<DT, 2>(a, grid, st);
-  else launch_rope<DT, 1>(a, grid, st);
+template <int DT, int VEC> hipError_t launch_rope_hpt(const RopeArgs& a, int hpt, dim3 grid, hipStream_t st) {
+  if (hpt == 4) return launch_rope<DT, VEC, 4>(a, grid, st);
+  if (hpt == 2) return launch_rope<DT, VEC, 2>(a, grid, st);
+  return launch_rope<DT, VEC, 1>(a, grid, st);
+}
+
+template <int DT> hipError_t launch_rope_vec(const RopeArgs& a, int vec, int hpt, dim3 grid, hipStream_t st) {
+  if (vec == 4) return launch_rope_hpt<DT, 4>(a, hpt, grid, st);
+  if (vec == 2) return launch_rope_hpt<DT, 2>(a, hpt, grid, st);
+  return launch_rope_hpt<DT, 1>(a, hpt, grid, st);
 }
 
 }  // namespace
@@ -190,19 +336,31 @@ extern "C" int mdg_rope_gather(const void* x, int dtype, int64_t ld_x, int64_t B
   RopeArgs a;
   a.x = x; a.ld_x = ld_x; a.B = B; a.T = T; a.n_heads = n_heads; a.group = n_heads / n_kv; a.r = r; a.hd = hd;
   a.cos = cos; a.sin = sin; a.cs_bstride = cs_batch_stride; a.mask = mask; a.norm_w = norm_w; a.eps = (float)eps; a.out = out;
-  a.t_tiles = (int)ceil_div(T, ROWS);
-  a.n_tiles = B * a.t_tiles;
-  const int64_t blocks = ceil_div(a.n_tiles, N_XCD) * N_XCD * n_heads;
-  MDG_CHECK_ARG(blocks < (int64_t)1 << 31, "mdg_rope_gather: %lld workgroups exceed the grid limit", (long long)blocks);
+  const int hpt = a.group % 4 == 0 ? 4 : a.group % 2 == 0 ? 2 : 1;  // query heads of one kv head per thread group
+  a.n_kv = n_kv;
+  a.chunks = a.group / hpt;
+  a.t_tiles = (int)ceil_div(T, ROWS * (UNITS / hpt));
+  a.n_tiles = (unsigned)(B * a.t_tiles);
+  const int64_t tiles8 = ceil_div(B * a.t_tiles, N_XCD);
+  MDG_CHECK_ARG(tiles8 <= 65535 && (int64_t)n_kv * N_XCD <= 0x7fffffff && a.chunks <= 65535,
+                "mdg_rope_gather: B*T = %lld tokens exceed one launch (%d tokens per workgroup row, 65535 * 8 rows)",
+                (long long)(B * T), ROWS * (UNITS / hpt));
   const size_t es = dtype_size(dtype);
+  a.cs_vec16 = ((uintptr_t)cos % 16 == 0 && (uintptr_t)sin % 16 == 0 && (hd * es) % 16 == 0 &&
+                (cs_batch_stride * es) % 16 == 0)
+                   ? 1
+                   : 0;
+  a.nw_vec16 = norm_w && (uintptr_t)norm_w % 16 == 0;
   const int half = r / 2;
   int vec = 4;
-  while (vec > 1 && (half % vec || ld_x % vec || ((uintptr_t)x | (uintptr_t)out) % (es * vec))) vec >>= 1;
+  while (vec > 1 && (half % vec || ld_x % vec || ((uintptr_t)x | (uintptr_t)out) % (es * vec) ||
+                     (mask && (uintptr_t)mask % (8 * vec))))
+    vec >>= 1;
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((unsigned)blocks);
-  if (dtype == MDG_BF16) launch_rope_vec<MDG_BF16>(a, vec, grid, st);
-  else if (dtype == MDG_F16) launch_rope_vec<MDG_F16>(a, vec, grid, st);
-  else launch_rope_vec<MDG_F32>(a, vec, grid, st);
+  const dim3 grid((unsigned)(N_XCD * n_kv), (unsigned)tiles8, (unsigned)a.chunks);
+  if (dtype == MDG_BF16) MDG_HIP(launch_rope_vec<MDG_BF16>(a, vec, hpt, grid, st));
+  else if (dtype == MDG_F16) MDG_HIP(launch_rope_vec<MDG_F16>(a, vec, hpt, grid, st));
+  else MDG_HIP(launch_rope_vec<MDG_F32>(a, vec, hpt, grid, st));
   MDG_LAUNCH_CHECK();
   return MDG_OK;
 }

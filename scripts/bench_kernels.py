@@ -75,3 +75,27 @@ if "sqrt" in which:
     X = acts(16384, 4096).double(); M = X.T @ X / 16384
     t0 = time.time(); r, ri, lam = ops.sqrt_psd_large(M, 1e-5, False, True); torch.cuda.synchronize()
     print(f"sqrt_psd_large n=4096: {time.time()-t0:.2f} s; check ||r r - (M + rho I)||/||M|| = {((r @ r - M - 1e-5*torch.eye(4096, device=dev, dtype=F64)).norm()/M.norm()).item():.2e}")
+if "rope" in which:
+    # compressed Llama-3-8B attention, one calibration-sized batch: 16 x 2048 tokens, 32 q heads / 8 kv heads, 88 of 128 kept
+    B, Tt = 16, 2048
+    for name, heads, norm, r in (("q", nh, False, 88), ("k", nkv, False, 88), ("q+norm", nh, True, 88),
+                                 ("q r=76", nh, False, 76), ("q r=102", nh, False, 102), ("q r=128", nh, False, 128)):
+        x = torch.randn(B, Tt, heads * r, device=dev, generator=g).to(torch.bfloat16)
+        ang = torch.rand(1, Tt, hd // 2, device=dev, generator=g) * 6.28
+        emb = torch.cat((ang, ang), -1)
+        cos, sin = emb.cos().to(torch.bfloat16), emb.sin().to(torch.bfloat16)
+        idx = torch.stack([torch.randperm(hd // 2, device=dev)[:r // 2] for _ in range(nkv)])
+        mask = torch.cat((idx, idx + hd // 2), dim=1)
+        w = torch.ones(hd, device=dev, dtype=torch.bfloat16) if norm else None
+        t = timeit(lambda: ops.rope_gather(x, cos, sin, mask, heads, nkv if heads == nh else heads, hd, norm_weight=w), n=20, warm=3)
+        nbytes = 2 * x.numel() * 2
+        print(f"rope_gather {name:7s} [{B},{Tt},{heads}x{r}] bf16: {t*1e6:.1f} us  {nbytes/t/1e9:.0f} GB/s (algorithmic: read + write once)")
+        if not norm:   # the eager chain of the reference's modeling file on the same GPU, for scale
+            mq = mask.repeat_interleave(heads // mask.shape[0], 0) if heads == nh else mask[:heads]
+            def eager():
+                q = x.view(B, Tt, heads, r).transpose(1, 2)
+                c = cos[:, :, mq].permute(0, 2, 1, 3); s = sin[:, :, mq].permute(0, 2, 1, 3)
+                h2 = r // 2
+                return q * c + torch.cat((-q[..., h2:], q[..., :h2]), -1) * s
+            te = timeit(eager, n=10, warm=2)
+            print(f"   torch eager chain: {te*1e6:.1f} us  ({te/t:.1f}x)")

@@ -455,6 +455,7 @@ def test_rope_masked_norm_golden(ops, dev, name):
     (1, 1, 32, 8, 128, 128, True),     # decode step, nothing dropped
     (2, 7, 2, 1, 256, 256, True),      # widest head the kernel takes
     (1, 5, 2, 2, 16, 2, True),         # one pair kept
+    (1, 20, 3, 3, 256, 200, True),     # MHA, wide head: four tokens per thread group, fp32 tables above 64 KB of LDS
 ])
 def test_rope_shapes(ops, dev, dt, B, T, n_h, n_kv, hd, r, shared):
     gen = torch.Generator().manual_seed(B * 1000 + T)
