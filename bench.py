@@ -35,6 +35,7 @@ sys.path.insert(0, ROOT)
 from modegpt_amd import engine, ops, sharding  # noqa: E402
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X public fp64-matrix spec; bench also reports the measured issue rate
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
 class LaunchTimer:
@@ -115,6 +116,36 @@ def cpu_baseline(shape, weights, covs_dev, sample_tokens, n_tokens_full, keep, r
                    f"in full = {t_dec:.2f} s"),
         "full_size_parity_vs_oracle": parity,
     }
+
+
+def rope_gather_roofline(shape, keep, dev, launches=20):
+    """SURVEY 8(f) row 3, measured beside the headline: the compressed model's rotary kernel (HBM bound) on one
+    calibration-sized batch (16 x 2048 tokens) of q projections at this shape's compressed head width."""
+    from modegpt_amd.compression.compress_qk import qk_rank_rule
+    B, T, n_h, n_kv, hd = 16, 2048, shape["n_heads"], shape["n_kv_heads"], shape["head_dim"]
+    r = qk_rank_rule(hd, keep, shape["arch"])
+    g = torch.Generator(device=dev).manual_seed(7)
+    x = torch.randn(B, T, n_h * r, device=dev, generator=g).to(torch.bfloat16)
+    ang = torch.rand(1, T, hd // 2, device=dev, generator=g) * 6.28
+    emb = torch.cat((ang, ang), -1)
+    cos, sin = emb.cos().to(torch.bfloat16), emb.sin().to(torch.bfloat16)
+    idx = torch.stack([torch.randperm(hd // 2, device=dev)[:r // 2] for _ in range(n_kv)])
+    mask = torch.cat((idx, idx + hd // 2), dim=1)
+    for _ in range(3):
+        ops.rope_gather(x, cos, sin, mask, n_h, n_kv, hd)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(launches):
+        ops.rope_gather(x, cos, sin, mask, n_h, n_kv, hd)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / launches * 1e3
+    nbytes = 2 * x.numel() * x.element_size()            # every element read once and written once
+    gbs = nbytes / (us * 1e-6) / 1e9
+    return {"kernel": "rope_gather_kernel (compressed-head RoPE: cos/sin gathered by the rotary mask, fused transpose)",
+            "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "avg_launch_us": us, "bytes_per_launch": nbytes, "launches": launches, "dtype": "bf16",
+            "workload": f"q projection [16, 2048, {n_h} x {r}] of {hd}-wide heads, {n_kv} kv masks"}
 
 
 def main():
@@ -207,6 +238,8 @@ def main():
         gpu_out["mlp_idx"] = ops.select_smallest_sorted(sc, int(shape["d_ff"] * a.keep))
         out["roofline"]["measured_mfma_f64_issue_rate_tflops"] = ops.probe_mfma_f64(4096)
         out["cpu_baseline"] = cpu_baseline(shape, layers[li], covs, 2048, n_texts * 2048, a.keep, ridges, gpu_out)
+        if shape["arch"] != "opt":
+            out["next_rows"] = {"rope_gather": rope_gather_roofline(shape, a.keep, dev)}
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
