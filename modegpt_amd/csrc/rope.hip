@@ -285,6 +285,208 @@ __global__ __launch_bounds__(256) void rope_gather_kernel(RopeArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------- widths whose half is odd (or operands the packs cannot address)
+// The kernel above moves 8-byte packs of the two rotate_half partners; when r/2 is not a multiple of 4 its packs shrink to 4
+// or 2 bytes and partial-line stores are amplified (WRITE_SIZE 1.3x / 2.3x the payload at r = 76 / 102).  For 2-byte packs
+// this one goes through LDS instead: a workgroup copies the [tokens][CH heads * r] slab of its tile in with the widest chunks the
+// addresses allow (the CH heads of a token are one contiguous run), rotates pair by pair out of LDS with every lane busy
+// (flat pair index, no 16-lane padding), writes the result transposed to [head][token][r] in LDS and copies each head's
+// run of tokens out, again in wide chunks.  More LDS instructions per element, but memory sees full lines.
+struct TileArgs {
+  RopeArgs a;
+  int ch, tt;              // heads per workgroup (1, 2, 4: query heads of one kv head), tokens per workgroup
+  int wi, wo;              // chunk bytes of the copies in / out
+  unsigned half_magic;     // floor(2^32 / hp) + 1, hp = ceil(half / 2): item / hp == umulhi(item, half_magic) for item < 2^16
+};
+
+__host__ __device__ __forceinline__ size_t al16(size_t n) { return (n + 15) & ~(size_t)15; }
+static size_t tile_lds_bytes(int tt, int ch, int r, int hd, size_t es) {
+  return 2 * al16((size_t)tt * ch * r * es) + al16((size_t)tt * 2 * hd * es) + al16((size_t)hd * es) +
+         al16((size_t)tt * ch * sizeof(float)) + al16((size_t)r * sizeof(short));
+}
+
+template <int W> struct ChunkT;
+template <> struct ChunkT<16> { typedef u32x4 type; };
+template <> struct ChunkT<8> { typedef unsigned long long type; };
+template <> struct ChunkT<4> { typedef unsigned type; };
+template <> struct ChunkT<2> { typedef unsigned short type; };
+
+// `segs` runs of `seg_bytes` bytes: run s starts at src + s * src_stride (bytes) and lands at dst + s * dst_stride
+template <int W>
+__device__ __forceinline__ void copy_runs(unsigned char* dst, size_t dst_stride, const unsigned char* src, size_t src_stride,
+                                          int segs, int seg_bytes) {
+  typedef typename ChunkT<W>::type C;
+  const int cps = seg_bytes / W, total = segs * cps;
+  for (int c = threadIdx.x; c < total; c += 256) {
+    const int sidx = c / cps, k = c - sidx * cps;
+    *(C*)(dst + sidx * dst_stride + (size_t)k * W) = *(const C*)(src + sidx * src_stride + (size_t)k * W);
+  }
+}
+__device__ __forceinline__ void copy_runs_w(int w, unsigned char* dst, size_t dst_stride, const unsigned char* src,
+                                            size_t src_stride, int segs, int seg_bytes) {
+  if (w == 16) copy_runs<16>(dst, dst_stride, src, src_stride, segs, seg_bytes);
+  else if (w == 8) copy_runs<8>(dst, dst_stride, src, src_stride, segs, seg_bytes);
+  else if (w == 4) copy_runs<4>(dst, dst_stride, src, src_stride, segs, seg_bytes);
+  else copy_runs<2>(dst, dst_stride, src, src_stride, segs, seg_bytes);
+}
+
+template <int DT, bool NORM, bool HALF_EVEN>
+__global__ __launch_bounds__(256) void rope_tile_kernel(TileArgs ta) {
+  typedef typename Lp<DT>::T E;
+  typedef Pack<E, 2> P2;
+  typedef Pack<short, 2> M2;
+  const RopeArgs& a = ta.a;
+  const unsigned tile = blockIdx.y * N_XCD + (blockIdx.x & (N_XCD - 1));
+  if (tile >= a.n_tiles) return;
+  const int hk = blockIdx.x >> 3;
+  const int CH = ta.ch, TT = ta.tt;
+  const int h0 = hk * a.group + blockIdx.z * CH;
+  const unsigned bu = tile / (unsigned)a.t_tiles;
+  const int64_t b = bu;
+  const int64_t t0 = (int64_t)(tile - bu * (unsigned)a.t_tiles) * TT;
+  const int tv = (int)min((int64_t)TT, a.T - t0);  // tokens of this tile that exist
+  const int r = a.r, half = r >> 1, hd = a.hd;
+  const int rows = tv * CH;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const size_t slab = al16((size_t)TT * CH * r * sizeof(E));
+  E* xin = (E*)lds_raw;                                                      // [TT][CH * r]
+  E* xout = (E*)(lds_raw + slab);                                            // [CH][TT][r]
+  P2* cs = (P2*)(lds_raw + 2 * slab);                                        // [TT][hd] of (cos, sin): one read per gather
+  E* nw = (E*)((unsigned char*)cs + al16((size_t)TT * 2 * hd * sizeof(E)));  // [hd]
+  float* inv = (float*)((unsigned char*)nw + al16((size_t)hd * sizeof(E)));  // [TT * CH]
+  short* msk = (short*)((unsigned char*)inv + al16((size_t)TT * CH * sizeof(float)));  // [r]
+
+  // ---- in: the tile's slab, its tokens' cos / sin rows (interleaved), the mask row, the norm weight; one barrier
+  copy_runs_w(ta.wi, (unsigned char*)xin, (size_t)CH * r * sizeof(E),
+              (const unsigned char*)((const E*)a.x + (b * a.T + t0) * a.ld_x + (int64_t)h0 * r), (size_t)a.ld_x * sizeof(E), tv,
+              CH * r * (int)sizeof(E));
+  {
+    const E* cg = (const E*)a.cos + b * a.cs_bstride + t0 * hd;
+    const E* sg = (const E*)a.sin + b * a.cs_bstride + t0 * hd;
+    for (int c = threadIdx.x; c < tv * hd; c += 256) {
+      P2 v;
+      v.v[0] = cg[c];
+      v.v[1] = sg[c];
+      cs[c] = v;
+    }
+  }
+  for (int j = threadIdx.x; j < r; j += 256) {
+    const int m = a.mask ? (int)a.mask[(int64_t)hk * r + j] : j;
+    msk[j] = (short)min(max(m, 0), hd - 1);  // memory safety only; the binding validates masks
+  }
+  if (NORM)
+    for (int c = threadIdx.x; c < hd; c += 256) nw[c] = ((const E*)a.norm_w)[c];
+  __syncthreads();
+
+  if (NORM) {  // four lanes per row
+    for (int row = threadIdx.x >> 2; row < rows; row += 64) {
+      const E* xr = xin + (size_t)row * r;
+      float ss = 0.f;
+      for (int j = threadIdx.x & 3; j < r; j += 4) {
+        const float v = Lp<DT>::up(xr[j]);
+        ss = add_r(ss, mul_r(v, v));
+      }
+      ss = ss + dpp_f32<0xB1>(ss);
+      ss = ss + dpp_f32<0x4E>(ss);
+      if ((threadIdx.x & 3) == 0) inv[row] = 1.f / sqrtf(add_r(ss / (float)r, a.eps));
+    }
+    __syncthreads();
+  }
+
+  // ---- rotate: one (row, two adjacent pairs) item per lane and step; row = token * CH + head
+  const int hp = (half + 1) >> 1;
+  const int items = rows * hp;
+  const int ch_shift = CH == 4 ? 2 : CH == 2 ? 1 : 0;
+  for (int item = threadIdx.x; item < items; item += 256) {
+    const int row = hp == 1 ? item : (int)__umulhi((unsigned)item, ta.half_magic);  // 2^32 / 1 does not fit the magic
+    const int j = (item - row * hp) * 2;
+    const bool two = HALF_EVEN || j + 1 < half;
+    const int tok = row >> ch_shift, hh = row & (CH - 1);
+    const E* xr = xin + (size_t)row * r;
+    E e1[2], e2[2];
+    short m1[2], m2[2];
+    {
+      const P2 p = *(const P2*)(xr + j);  // j is even and rows are even: aligned; the second element may be the partner half
+      e1[0] = p.v[0];
+      e1[1] = p.v[1];
+      const M2 q = *(const M2*)(msk + j);
+      m1[0] = q.v[0];
+      m1[1] = q.v[1];
+    }
+    if (HALF_EVEN) {
+      const P2 p = *(const P2*)(xr + half + j);
+      e2[0] = p.v[0];
+      e2[1] = p.v[1];
+      const M2 q = *(const M2*)(msk + half + j);
+      m2[0] = q.v[0];
+      m2[1] = q.v[1];
+    } else {
+      e2[0] = xr[half + j];
+      m2[0] = msk[half + j];
+      e2[1] = two ? xr[half + j + 1] : e2[0];
+      m2[1] = two ? msk[half + j + 1] : m2[0];
+    }
+    if (!two) m1[1] = m1[0];
+    const P2* cr = cs + (size_t)tok * hd;
+    E o1[2], o2[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      float a1 = Lp<DT>::up(e1[k]), a2 = Lp<DT>::up(e2[k]);
+      if (NORM) {
+        const float iv = inv[row];
+        a1 = Lp<DT>::up(Lp<DT>::down(mul_r(Lp<DT>::up(nw[m1[k]]), mul_r(a1, iv))));
+        a2 = Lp<DT>::up(Lp<DT>::down(mul_r(Lp<DT>::up(nw[m2[k]]), mul_r(a2, iv))));
+      }
+      const P2 t1 = cr[m1[k]], t2 = cr[m2[k]];
+      const float u1 = Lp<DT>::up(Lp<DT>::down(mul_r(a1, Lp<DT>::up(t1.v[0]))));
+      const float v1 = Lp<DT>::up(Lp<DT>::down(mul_r(-a2, Lp<DT>::up(t1.v[1]))));
+      const float u2 = Lp<DT>::up(Lp<DT>::down(mul_r(a2, Lp<DT>::up(t2.v[0]))));
+      const float v2 = Lp<DT>::up(Lp<DT>::down(mul_r(a1, Lp<DT>::up(t2.v[1]))));
+      o1[k] = Lp<DT>::down(add_r(u1, v1));
+      o2[k] = Lp<DT>::down(add_r(u2, v2));
+    }
+    E* orow = xout + ((size_t)hh * TT + tok) * r;
+    if (two) {
+      P2 w;
+      w.v[0] = o1[0];
+      w.v[1] = o1[1];
+      *(P2*)(orow + j) = w;
+    } else {
+      orow[j] = o1[0];
+    }
+    if (HALF_EVEN) {
+      P2 w;
+      w.v[0] = o2[0];
+      w.v[1] = o2[1];
+      *(P2*)(orow + half + j) = w;
+    } else {
+      orow[half + j] = o2[0];
+      if (two) orow[half + j + 1] = o2[1];
+    }
+  }
+  __syncthreads();
+
+  // ---- out: per head one contiguous run of tv * r elements
+  copy_runs_w(ta.wo, (unsigned char*)((E*)a.out + ((b * a.n_heads + h0) * a.T + t0) * r), (size_t)a.T * r * sizeof(E),
+              (const unsigned char*)xout, (size_t)TT * r * sizeof(E), CH, tv * r * (int)sizeof(E));
+}
+
+template <int DT> hipError_t launch_rope_tile(const TileArgs& ta, dim3 grid, size_t lds, hipStream_t st) {
+  auto launch = [&](auto kernel) -> hipError_t {
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, ta);
+    return hipSuccess;
+  };
+  const bool even = (ta.a.r / 2) % 2 == 0;
+  if (ta.a.norm_w) return even ? launch(rope_tile_kernel<DT, true, true>) : launch(rope_tile_kernel<DT, true, false>);
+  return even ? launch(rope_tile_kernel<DT, false, true>) : launch(rope_tile_kernel<DT, false, false>);
+}
+
 template <int DT, int VEC, int HPT> hipError_t launch_rope(const RopeArgs& a, dim3 grid, hipStream_t st) {
   const size_t lds = ((size_t)ROWS * (UNITS / HPT) * 2 + 1) * a.hd * sizeof(typename Lp<DT>::T);
   auto launch = [&](auto kernel) -> hipError_t {
@@ -304,10 +506,10 @@ template <int DT, int VEC> hipError_t launch_rope_hpt(const RopeArgs& a, int hpt
   return launch_rope<DT, VEC, 1>(a, grid, st);
 }
 
+
 template <int DT> hipError_t launch_rope_vec(const RopeArgs& a, int vec, int hpt, dim3 grid, hipStream_t st) {
   if (vec == 4) return launch_rope_hpt<DT, 4>(a, hpt, grid, st);
-  if (vec == 2) return launch_rope_hpt<DT, 2>(a, hpt, grid, st);
-  return launch_rope_hpt<DT, 1>(a, hpt, grid, st);
+  return launch_rope_hpt<DT, 2>(a, hpt, grid, st);
 }
 
 }  // namespace
@@ -352,15 +554,43 @@ extern "C" int mdg_rope_gather(const void* x, int dtype, int64_t ld_x, int64_t B
                    : 0;
   a.nw_vec16 = norm_w && (uintptr_t)norm_w % 16 == 0;
   const int half = r / 2;
-  int vec = 4;
+  hipStream_t st = (hipStream_t)stream;
+  int vec = 4;  // elements per pack of the direct kernel
   while (vec > 1 && (half % vec || ld_x % vec || ((uintptr_t)x | (uintptr_t)out) % (es * vec) ||
                      (mask && (uintptr_t)mask % (8 * vec))))
     vec >>= 1;
-  hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((unsigned)(N_XCD * n_kv), (unsigned)tiles8, (unsigned)a.chunks);
-  if (dtype == MDG_BF16) MDG_HIP(launch_rope_vec<MDG_BF16>(a, vec, hpt, grid, st));
-  else if (dtype == MDG_F16) MDG_HIP(launch_rope_vec<MDG_F16>(a, vec, hpt, grid, st));
-  else MDG_HIP(launch_rope_vec<MDG_F32>(a, vec, hpt, grid, st));
+  if (vec > 1) {  // packs of the rotate_half partners straight from / to memory (measured: 4-byte packs at r = 76 still
+                  // beat the LDS route, 97 vs 108 us; 2-byte packs at r = 102 do not, 199 vs 162 us)
+    const dim3 grid((unsigned)(N_XCD * n_kv), (unsigned)tiles8, (unsigned)a.chunks);
+    if (dtype == MDG_BF16) MDG_HIP(launch_rope_vec<MDG_BF16>(a, vec, hpt, grid, st));
+    else if (dtype == MDG_F16) MDG_HIP(launch_rope_vec<MDG_F16>(a, vec, hpt, grid, st));
+    else MDG_HIP(launch_rope_vec<MDG_F32>(a, vec, hpt, grid, st));
+  } else {       // through LDS (see rope_tile_kernel)
+    TileArgs ta;
+    int tt = 64 / hpt;
+    while (tt > 1 && tile_lds_bytes(tt, hpt, r, hd, es) > 64 * 1024) tt >>= 1;
+    const size_t lds = tile_lds_bytes(tt, hpt, r, hd, es);
+    a.t_tiles = (int)ceil_div(T, tt);
+    a.n_tiles = (unsigned)(B * a.t_tiles);
+    const int64_t t8 = ceil_div(B * a.t_tiles, N_XCD);
+    MDG_CHECK_ARG(t8 <= 65535, "mdg_rope_gather: B*T = %lld tokens exceed one launch (%d tokens per workgroup, 65535 * 8)",
+                  (long long)(B * T), tt);
+    auto widest = [&](uintptr_t base, size_t stride_a, size_t stride_b) {
+      int w = 16;
+      while (w > (int)es && (base % w || stride_a % w || stride_b % w)) w >>= 1;
+      return w;
+    };
+    ta.a = a;
+    ta.ch = hpt;
+    ta.tt = tt;
+    ta.wi = widest((uintptr_t)x, (size_t)ld_x * es, (size_t)hpt * r * es);
+    ta.wo = widest((uintptr_t)out, (size_t)T * r * es, (size_t)tt * r * es);
+    ta.half_magic = (unsigned)((1ull << 32) / (unsigned)((half + 1) / 2)) + 1u;   // items index (row, pair of pairs)
+    const dim3 grid((unsigned)(N_XCD * n_kv), (unsigned)t8, (unsigned)a.chunks);
+    if (dtype == MDG_BF16) MDG_HIP(launch_rope_tile<MDG_BF16>(ta, grid, lds, st));
+    else if (dtype == MDG_F16) MDG_HIP(launch_rope_tile<MDG_F16>(ta, grid, lds, st));
+    else MDG_HIP(launch_rope_tile<MDG_F32>(ta, grid, lds, st));
+  }
   MDG_LAUNCH_CHECK();
   return MDG_OK;
 }
