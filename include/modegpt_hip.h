@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MDG_ABI_VERSION 1
+#define MDG_ABI_VERSION 2 /* 2: w_dtype on mdg_nystrom_down / mdg_vo_compress, mdg_rope_gather added */
 
 enum mdg_status {
   MDG_OK = 0,

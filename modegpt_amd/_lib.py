@@ -27,6 +27,8 @@ class CovProblem(C.Structure):
                 ("ld_sigma", _i64), ("sigma_batch_stride", _i64)]
 
 
+ABI_VERSION = 2   # include/modegpt_hip.h MDG_ABI_VERSION this binding table was written against
+
 # name -> (restype, argtypes); must list every symbol the header declares (tests/test_abi.py checks it)
 SIGNATURES = {
     "mdg_abi_version": (_i32, []),
@@ -93,7 +95,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.mdg_abi_version() != 1:
+    if lib.mdg_abi_version() != ABI_VERSION:
         raise ModeGPTLibraryError("libmodegpt_hip.so ABI version mismatch")
     _lib = lib
     return lib
