@@ -174,10 +174,13 @@ int mdg_vo_compress(const double* cov_x, int64_t d, int64_t ldc, const void* Wv,
 int mdg_sqrt_psd_small(const double* M, int64_t n, int64_t batch, double ridge, int scaled, double* root,
                        double* inv_root, double* evals_out, void* ws, size_t ws_bytes, void* stream);
 size_t mdg_sqrt_psd_small_ws_bytes(int64_t n, int64_t batch);
-/* The same function for one n x n matrix of any size (the d_model-sized call of compress_vo.py:44): two-sided block
- * Jacobi on 64-wide blocks -- 128x128 pair sub-problems through the LDS Jacobi kernel, rotations applied by batched
- * fp64-MFMA GEMMs, blocks rotated round-robin.  evals_out optional [n], UNSORTED (pre-ridge).  Not used by this
- * engine's own VO stage (DESIGN.md "Identities").  SYNCHRONISES once per sweep. */
+/* The same function for one n x n matrix of any size (the d_model-sized call of compress_vo.py:44).
+ * evals_out == NULL and scaled == 0 (the plain sqrt_M(M, ridge) call): sqrt(M + ridge I) and its inverse by the coupled
+ * Newton-Schulz iteration -- three n^3 fp64-MFMA GEMMs per step, ~25 steps at n = 4096 -- valid because the reference's
+ * clamps never bind on a PSD input; an input it cannot certify (indefinite) falls through to the eigen route.
+ * Otherwise: two-sided block Jacobi on 64-wide blocks -- 128x128 pair sub-problems through the LDS Jacobi kernel,
+ * rotations applied by batched fp64-MFMA GEMMs, blocks rotated round-robin; evals_out [n], UNSORTED (pre-ridge).
+ * Not used by this engine's own VO stage (DESIGN.md "Identities").  SYNCHRONISES once per step / sweep. */
 size_t mdg_sqrt_psd_large_ws_bytes(int64_t n);
 int mdg_sqrt_psd_large(const double* M, int64_t n, int64_t ld, double ridge, int scaled, double* root,
                        double* inv_root, double* evals_out, void* ws, size_t ws_bytes, void* stream);

@@ -20,19 +20,25 @@ def sqrt_M(M: Tensor, ridge_lambda=1e-4, scaled=False, debug: str = "", inverse_
     """Symmetric square root with an eigenvalue ridge (compression_utils.py:15-55): eigh, lambda += ridge *
     (max lambda if scaled else 1), sqrt(clamp >= 0), V diag V^T; optionally the inverse root with the 1e-12 clamp.
     M may be [n, n] or [batch, n, n].  Head-sized inputs (even n <= 128) run the batched LDS Jacobi solver
-    (mdg_sqrt_psd_small); anything else goes through the block-Jacobi solver (mdg_sqrt_psd_large), one matrix at a
-    time.  The d_model-sized call the reference makes from compress_vo (compress_vo.py:44) is supported but this
-    engine's own compress_vo never makes it (DESIGN.md "Identities")."""
+    (mdg_sqrt_psd_small).  Anything larger goes through mdg_sqrt_psd_large, one matrix at a time: when no eigenvalue
+    is needed (no `debug` report, ridge not scaled by lambda_max) that is a GEMM-only Newton-Schulz iteration for
+    sqrt(M + ridge I) -- the clamps above never bind on a PSD input -- else block Jacobi.  On the Newton route the
+    reference's "Negative eigenvalues found" notice (round-off noise of a rank-deficient sigma) is not printed.
+    The d_model-sized call the reference makes from compress_vo (compress_vo.py:44) is supported but this engine's own
+    compress_vo never makes it (DESIGN.md "Identities")."""
     n = M.shape[-1]
+    lam = None
     if n <= 128 and n % 2 == 0:
         root, inv_root, lam = ops.sqrt_psd_small(M, ridge_lambda, scaled, inverse_sqrt)
     else:
         mats = M.reshape(-1, n, n)
-        parts = [ops.sqrt_psd_large(m, ridge_lambda, scaled, inverse_sqrt) for m in mats]
+        want_evals = bool(debug) or bool(scaled)
+        parts = [ops.sqrt_psd_large(m, ridge_lambda, scaled, inverse_sqrt, want_evals) for m in mats]
         root = torch.stack([p[0] for p in parts]).reshape(M.shape)
         inv_root = torch.stack([p[1] for p in parts]).reshape(M.shape) if inverse_sqrt else None
-        lam = torch.stack([p[2].sort(descending=True).values for p in parts])
-    if debug or bool((lam[..., -1] < 0).any()):
+        if want_evals:
+            lam = torch.stack([p[2].sort(descending=True).values for p in parts])
+    if lam is not None and (debug or bool((lam[..., -1] < 0).any())):
         lam_h = lam.reshape(-1, n).cpu()
         for row in lam_h:
             mx, mn = row[0].item(), row[-1].item()

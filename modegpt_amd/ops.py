@@ -208,8 +208,10 @@ def sqrt_psd_small(M: torch.Tensor, ridge: float, scaled: bool, want_inverse: bo
     return root.reshape(M.shape), (None if inv_root is None else inv_root.reshape(M.shape)), evals
 
 
-def sqrt_psd_large(M: torch.Tensor, ridge: float, scaled: bool, want_inverse: bool):
-    """sqrt_M for one symmetric matrix of any size (block Jacobi): returns (root, inv_root or None, evals unsorted)."""
+def sqrt_psd_large(M: torch.Tensor, ridge: float, scaled: bool, want_inverse: bool, want_evals: bool = True):
+    """sqrt_M for one symmetric matrix of any size: returns (root, inv_root or None, evals unsorted or None).
+    With want_evals=False and scaled=False the library takes the GEMM-only Newton-Schulz route for sqrt(M + ridge I)
+    (falling back to block Jacobi by itself when the input is not positive definite); eigenvalues need block Jacobi."""
     _need_gpu(M)
     lib = _lib.load()
     if M.dim() != 2 or M.shape[0] != M.shape[1]:
@@ -218,12 +220,12 @@ def sqrt_psd_large(M: torch.Tensor, ridge: float, scaled: bool, want_inverse: bo
     n = M2.shape[0]
     root = torch.empty(n, n, dtype=torch.float64, device=M.device)
     inv_root = torch.empty(n, n, dtype=torch.float64, device=M.device) if want_inverse else None
-    evals = torch.empty(n, dtype=torch.float64, device=M.device)
+    evals = torch.empty(n, dtype=torch.float64, device=M.device) if want_evals else None
     nbytes = lib.mdg_sqrt_psd_large_ws_bytes(n)
     ws, wsp = _ws(nbytes, M.device)
     with torch.cuda.device(M.device):
         check(lib.mdg_sqrt_psd_large(M2.data_ptr(), n, M2.stride(0), float(ridge), int(scaled), root.data_ptr(),
-                                     _p(inv_root), evals.data_ptr(), wsp, nbytes, _stream(M)), "mdg_sqrt_psd_large")
+                                     _p(inv_root), _p(evals), wsp, nbytes, _stream(M)), "mdg_sqrt_psd_large")
     return root, inv_root, evals
 
 

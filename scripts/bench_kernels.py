@@ -99,3 +99,14 @@ if "rope" in which:
                 return q * c + torch.cat((-q[..., h2:], q[..., :h2]), -1) * s
             te = timeit(eager, n=10, warm=2)
             print(f"   torch eager chain: {te*1e6:.1f} us  ({te/t:.1f}x)")
+if "sqrt" in which:
+    n = 4096
+    X = acts(4 * n, n).double()
+    M = X.T @ X / (4 * n)
+    for ev in (False, True):
+        t0 = time.time(); r = ops.sqrt_psd_large(M, 1e-5, False, True, want_evals=ev); torch.cuda.synchronize()
+        t = time.time() - t0
+        err = ((r[0] @ r[0] - M - 1e-5 * torch.eye(n, dtype=F64, device=dev)).abs().max() / M.abs().max()).item()
+        ierr = ((r[0] @ r[1] - torch.eye(n, dtype=F64, device=dev)).abs().max()).item()
+        print(f"sqrt_psd_large n={n} {'block Jacobi (eigenvalues)' if ev else 'Newton-Schulz (GEMM only)'}: {t:.3f} s  "
+              f"|R R - A|/|A| = {err:.1e}  |R R^-1 - I| = {ierr:.1e}")

@@ -334,6 +334,36 @@ def test_sqrt_psd_large(ops, dev, n):
     assert rel(root2, want_sc) < 1e-10
 
 
+@pytest.mark.parametrize("n", [130, 200, 384, 1024])
+def test_sqrt_psd_large_newton(ops, dev, n):
+    """The GEMM-only route (no eigenvalues requested) against the oracle's eigh route: same sqrt(M + ridge I) and inverse,
+    incl. the rank-deficient sigma (n == 200), whose smallest eigenvalue is the ridge itself."""
+    gen = torch.Generator().manual_seed(n)
+    t = n // 2 if n == 200 else 3 * n
+    X = acts(gen, t, n).double()
+    M = X.T @ X / t
+    want_s, want_i = O.sqrt_M(M, 1e-5, inverse_sqrt=True)
+    root, inv, lam = ops.sqrt_psd_large(M.to(dev), 1e-5, False, True, want_evals=False)
+    assert lam is None
+    assert rel(root, want_s) < 1e-10
+    assert rel(inv, want_i) < 1e-7
+    assert rel(root @ root, M.to(dev) + 1e-5 * torch.eye(n, dtype=F64, device=dev)) < 1e-11
+
+
+def test_sqrt_psd_large_newton_falls_back_on_indefinite_input(ops, dev):
+    """An eigenvalue below -ridge: there is no real square root of M + ridge I; the reference clamps (sqrt of
+    max(lambda + ridge, 0)).  The Newton iteration must notice and hand over to the eigen route."""
+    gen = torch.Generator().manual_seed(2)
+    Q, _ = torch.linalg.qr(torch.randn(160, 160, generator=gen, dtype=F64))
+    lam = torch.linspace(0.01, 3.0, 160, dtype=F64)
+    lam[0] = -0.5
+    M = (Q * lam) @ Q.T
+    M = (M + M.T) / 2
+    want = O.sqrt_M(M, 1e-4)
+    root, _, _ = ops.sqrt_psd_large(M.to(dev), 1e-4, False, False, want_evals=False)
+    assert rel(root, want) < 1e-9
+
+
 def test_sqrt_M_surface_dispatch(dev):
     """compression_utils.sqrt_M keeps the reference's full domain: batched head-size and d_model-size inputs."""
     from modegpt_amd.compression_utils import sqrt_M
