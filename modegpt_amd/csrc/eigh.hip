@@ -490,11 +490,6 @@ extern "C" int mdg_sqrt_psd_large(const double* M, int64_t n, int64_t ld, double
   return MDG_OK;
 }
 
-namespace mdg {
-}  // namespace mdg
-
-using namespace mdg;
-
 extern "C" int mdg_syevj_batched(double* A, int64_t n, int64_t batch, double* evals, double* evecs, void* stream) {
   MDG_CLEAR();
   MDG_CHECK_ARG(A && evals && evecs, "mdg_syevj_batched: null pointer");

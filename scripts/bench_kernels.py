@@ -110,3 +110,13 @@ if "sqrt" in which:
         ierr = ((r[0] @ r[1] - torch.eye(n, dtype=F64, device=dev)).abs().max()).item()
         print(f"sqrt_psd_large n={n} {'block Jacobi (eigenvalues)' if ev else 'Newton-Schulz (GEMM only)'}: {t:.3f} s  "
               f"|R R - A|/|A| = {err:.1e}  |R R^-1 - I| = {ierr:.1e}")
+if "cov64" in which:
+    # is the in-loop bf16 -> fp64 conversion worth hoisting into a pre-pass?  same problem, operands already fp64 in HBM
+    H = acts(T, d_ff); S = torch.zeros(d_ff, d_ff, dtype=F64, device=dev)
+    t = timeit(lambda: ops.cov_accum(S, H), n=3)
+    fl = T * d_ff * (d_ff + 1)
+    print(f"cov mlp bf16 input {T}x{d_ff}: {t*1e3:.1f} ms  {fl/t/1e12:.1f} TF")
+    t0 = timeit(lambda: H.double(), n=3)
+    H64 = H.double()
+    t = timeit(lambda: ops.cov_accum(S, H64), n=3)
+    print(f"cov mlp fp64 input {T}x{d_ff}: {t*1e3:.1f} ms  {fl/t/1e12:.1f} TF   (+ torch bf16->fp64 pre-pass {t0*1e3:.2f} ms)")
