@@ -67,6 +67,16 @@ class LlamaAdapter(ModelAdapter):
         return hook
 
     @staticmethod
+    def _make_proj_hook(layer_idx, cov_list, n_heads, head_dim, d_model):
+        """sigma_q / sigma_k += per-head Gram of a projection's pre-RoPE output (LlamaAdapter.py:115-125).  register_hooks
+        above parks the projection outputs and flushes them in one fused launch instead; this stand-alone hook does the
+        same accumulation for callers that register it themselves."""
+        @torch.no_grad()
+        def hook(module, inp, out):
+            ops.cov_accum(cov_list[layer_idx], out, n_heads=n_heads)
+        return hook
+
+    @staticmethod
     def _input_hook(layer_idx, cov_list):
         """sigma_x += sum_b X_b^T X_b, X = input_layernorm's output (LlamaAdapter.py:138-147)."""
         @torch.no_grad()

@@ -24,10 +24,10 @@ from .components import (AttentionComponents, MLPComponents, MLPTensors, QKCompo
                          VOComponents, VOTensors)
 
 
-def build_metrics(all_metrics: dict) -> dict:
+def build_metrics(_all_metrics: dict) -> dict:
     """Kept for callers of the reference's helper; the store itself lives in adapters/metrics.py."""
     m = _metrics.new_run()
-    all_metrics[m["RunName"]] = m
+    _all_metrics[m["RunName"]] = m
     return m
 
 
@@ -103,6 +103,54 @@ class ModelAdapter(ABC):
                 elif suffix == "vo":
                     self.replace_attn_layers(i, new_q=None, new_k=None, new_v=linear_of(art["v_proj"]),
                                              new_o=linear_of(art["o_proj"]))
+
+    # ---- in-place slicing (model_adapter.py:394-542; upstream's call sites are commented out in favour of the
+    #      save_layer -> convert_model route, the methods stay part of the adapter surface) ----
+    @staticmethod
+    def _swap_in(weight: Tensor, bias_from=None, bias_values: Optional[Tensor] = None) -> nn.Linear:
+        """bf16 Linear on the GPU holding `weight` [out, in]; carries a bias only when `bias_from` (the module it
+        replaces) has one, initialised from `bias_values` when given."""
+        has_bias = bias_from is not None and getattr(bias_from, "bias", None) is not None
+        lin = nn.Linear(weight.shape[1], weight.shape[0], bias=has_bias, device="cuda", dtype=torch.bfloat16)
+        lin.weight.data.copy_(weight.to(torch.bfloat16))
+        if has_bias and bias_values is not None:
+            lin.bias.data.copy_(bias_values)
+        return lin
+
+    @torch.no_grad()
+    def slice_gate_dims(self, layer_idx: int, up_weights: Tensor, down_weights: Tensor, gate_weights: Optional[Tensor],
+                        new_bias_u: Optional[Tensor], new_bias_g: Optional[Tensor], bias: bool = True,
+                        expert_idx: Optional[int] = None):
+        """Put compressed MLP weights ([out, in] each) straight into the block.  up/gate biases come from the caller
+        (they were sliced with the kept rows), down keeps the module's own bias."""
+        comps = self.get_mlp_components(layer_idx, expert_idx=expert_idx)
+        keep = (lambda m: m) if bias else (lambda m: None)
+        up = self._swap_in(up_weights, keep(comps.up_proj), new_bias_u)
+        gate = None if gate_weights is None else self._swap_in(gate_weights, keep(comps.gate_proj), new_bias_g)
+        down_bias = None if comps.down_proj.bias is None else comps.down_proj.bias.data
+        down = self._swap_in(down_weights, keep(comps.down_proj), down_bias)
+        self.replace_mlp_layers(layer_idx, up, down, gate, expert_idx=expert_idx)
+
+    @torch.no_grad()
+    def slice_qk_dims(self, layer_idx: int, new_heads_Q: List[Tensor], new_heads_K: List[Tensor],
+                      new_bias_Q: List[Tensor] = [], new_bias_K: List[Tensor] = [], bias: bool = True):
+        """Per-head row blocks -> one q_proj / k_proj; a bias survives only if the original had one, `bias` is set and
+        per-head biases were passed."""
+        comps = self.get_attn_components(layer_idx)
+        bq = torch.cat(list(new_bias_Q), dim=0) if len(new_bias_Q) > 0 else None
+        bk = torch.cat(list(new_bias_K), dim=0) if len(new_bias_K) > 0 else None
+        q = self._swap_in(torch.cat(list(new_heads_Q), dim=0), comps.q_proj if (bias and bq is not None) else None, bq)
+        k = self._swap_in(torch.cat(list(new_heads_K), dim=0), comps.k_proj if (bias and bk is not None) else None, bk)
+        self.replace_attn_layers(layer_idx, new_q=q, new_k=k, new_v=None, new_o=None)
+
+    @torch.no_grad()
+    def slice_vo_dims(self, layer_idx: int, new_heads_V: List[Tensor], new_heads_O: List[Tensor], bias: bool):
+        """Per-head V row blocks / O column blocks -> v_proj (never biased) and o_proj (keeps the original bias)."""
+        comps = self.get_attn_components(layer_idx)
+        v = self._swap_in(torch.cat(list(new_heads_V), dim=0))
+        o_bias = None if comps.o_proj.bias is None else comps.o_proj.bias.data
+        o = self._swap_in(torch.cat(list(new_heads_O), dim=1), comps.o_proj if bias else None, o_bias)
+        self.replace_attn_layers(layer_idx, new_q=None, new_k=None, new_v=v, new_o=o)
 
     # ---- shape properties (model_adapter.py:253-307) ----
     @property

@@ -60,6 +60,70 @@ def compress_layer(adapter: ModelAdapter, layer_idx: int, rank: int, cov_q_list:
     return mask
 
 
+def _kept_rows(head: Tensor, rows: Tensor, slice_dims: bool) -> Tensor:
+    """head[rows] when slicing; otherwise a zero matrix of the head's shape with those rows copied (the reference's
+    slice_dims=False convention: same shape, dropped rows zeroed)."""
+    if slice_dims:
+        return head[rows]
+    out = torch.zeros_like(head)
+    out[rows] = head[rows]
+    return out
+
+
+@torch.no_grad()
+def compress_head_llama_grouped(kv_head_idx: int, kv_head_ratio: int, cov_q_layer, cov_k_layer, Wq_heads: Tensor,
+                                Wk_heads: Tensor, Q_heads_out: list, K_heads_out: list, layer_rotary_mask: list, rank: int,
+                                slice_dims=True, ridge_lambda=1e-4):
+    """One kv head of a GQA layer (compress_qk.py:320-382): score the RoPE pairs over the group's query heads
+    (K statistics with `ridge_lambda`, Q with sqrt_M's default), keep rank/2 pairs in score order, append the kept
+    rows of K and of every query head of the group, and the mask.  Same kernel as compress_layer, one head at a time."""
+    q0 = kv_head_idx * kv_head_ratio
+    cq = torch.stack([c.to(device=d2, dtype=dtype_p) for c in cov_q_layer[q0:q0 + kv_head_ratio]])
+    ck = cov_k_layer[kv_head_idx].to(device=d2, dtype=dtype_p)[None]
+    mask, _, _ = ops.qk_select(cq, ck, rank, _lib.MDG_QK_ROPE_GROUPED, _SQRT_M_DEFAULT_RIDGE, ridge_lambda)
+    rows = mask[0]
+    K_heads_out.append(_kept_rows(Wk_heads[kv_head_idx], rows.to(Wk_heads.device), slice_dims))
+    for Q_head in Wq_heads[q0:q0 + kv_head_ratio]:
+        Q_heads_out.append(_kept_rows(Q_head, rows.to(Q_head.device), slice_dims))
+    layer_rotary_mask.append(rows)
+
+
+@torch.no_grad()
+def compress_head_llama(C_q: Tensor, C_k: Tensor, Q_head: Tensor, K_head: Tensor, Q_heads_out: list, K_heads_out: list,
+                        layer_rotary_mask: list, rank: int, slice_dims=True):
+    """One head of an MHA Llama layer (compress_qk.py:387-436): default ridges for both statistics; the kept rows go
+    to the lists as CPU bf16 tensors, as upstream."""
+    cq = C_q.to(device=d2, dtype=dtype_p)[None]
+    ck = C_k.to(device=d2, dtype=dtype_p)[None]
+    mask, _, _ = ops.qk_select(cq, ck, rank, _lib.MDG_QK_ROPE_MHA, _SQRT_M_DEFAULT_RIDGE, _SQRT_M_DEFAULT_RIDGE)
+    rows = mask[0]
+    Q_heads_out.append(_kept_rows(Q_head, rows.to(Q_head.device), slice_dims).to(device="cpu", dtype=torch.bfloat16))
+    K_heads_out.append(_kept_rows(K_head, rows.to(K_head.device), slice_dims).to(device="cpu", dtype=torch.bfloat16))
+    layer_rotary_mask.append(rows)
+
+
+@torch.no_grad()
+def compress_head_opt(C_q: Tensor, C_k: Tensor, Q_head: Tensor, K_head: Tensor, bias_Q_head: Tensor, bias_K_head: Tensor,
+                      out_Q_heads: list, out_K_heads: list, out_Q_bias: list, out_K_bias: list, rank: int):
+    """One OPT head (compress_qk.py:439-476): score_j = |sqrt(Cq)[:, j]| * |sqrt(Ck)[:, j]|, top-`rank` columns in score
+    order; rows (to the CPU, as upstream) and the matching bias entries are appended."""
+    cq = C_q.to(device=d2, dtype=dtype_p)[None]
+    ck = C_k.to(device=d2, dtype=dtype_p)[None]
+    mask, _, _ = ops.qk_select(cq, ck, rank, _lib.MDG_QK_OPT, _SQRT_M_DEFAULT_RIDGE, _SQRT_M_DEFAULT_RIDGE)
+    rows = mask[0]
+    out_Q_heads.append(Q_head[rows.to(Q_head.device)].to(device="cpu"))
+    out_K_heads.append(K_head[rows.to(K_head.device)].to(device="cpu"))
+    out_Q_bias.append(bias_Q_head[rows.to(bias_Q_head.device)])
+    out_K_bias.append(bias_K_head[rows.to(bias_K_head.device)])
+
+
+def compress_qk_svd(adapter, cov_x, keep_ratios, rank=None, ridge_lambda=1, slice_dims=True):
+    """Present upstream (compress_qk.py:16-150) but unreachable there: nothing calls it and its body ends in a call to
+    an undefined name (`slice_QK_dims`), so it cannot run.  Not reproduced."""
+    raise NotImplementedError("compress_qk_svd is dead code in the reference (calls the undefined slice_QK_dims); "
+                              "use compress_qk")
+
+
 @torch.no_grad()
 def compress_qk(adapter: ModelAdapter, cov, keep_ratios, rank=None, slice_dims=True,
                 target_layers: Optional[List[int]] = None):

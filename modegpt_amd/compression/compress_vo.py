@@ -24,6 +24,67 @@ def vo_rank_rule(head_dim: int, keep_ratio: float, arch: str) -> int:
     return min(r, head_dim)
 
 
+def _regularised_cov(sqrt_C: Tensor) -> Tensor:
+    """The per-head functions of the reference receive sqrt(C + ridge I) (and its inverse) from their caller; the kernel
+    works from C + ridge I itself: one fp64-MFMA product recovers it."""
+    S = sqrt_C.to(device=d2, dtype=dtype_p).contiguous()
+    C = torch.empty_like(S)
+    ops.gemm(S, S, C)
+    return C
+
+
+@torch.no_grad()
+def compress_head_grouped(kv_head_idx: int, kv_head_ratio: int, head_dim: int, rank: int, W_v: Tensor, W_o: Tensor,
+                          sqrt_C: Tensor, inv_sqrt_C: Tensor, new_heads_V: list, new_heads_O: list, slice_dims=True,
+                          arch="opt"):
+    """One kv head of a GQA layer (compress_vo.py:112-159): thin SVD of sqrt(C) W_v,h^T = U S Vh; appends
+    W_v' = (C^-1/2 U_r)^T  [rank, d] and, for every query head j of the group, W_o'[j] = (S_r Vh_r W_o[:, j]^T)^T
+    [d, rank], fp64 (factors are unique up to a sign per component).  `inv_sqrt_C` is accepted for signature
+    compatibility; the Gram route does not need it."""
+    if kv_head_ratio < 2:
+        raise NotImplementedError("a group of one query head is the MHA case: use compress_head")
+    r0, c0 = kv_head_idx * head_dim, kv_head_idx * kv_head_ratio * head_dim
+    Wv_h = W_v[r0:r0 + head_dim, :].detach().to(d2)
+    Wo_g = W_o[:, c0:c0 + kv_head_ratio * head_dim].detach().to(d2)
+    _, _, v64, o64 = ops.vo_compress(_regularised_cov(sqrt_C), Wv_h, Wo_g, kv_head_ratio, 1, head_dim, rank, 0.0,
+                                     want_f64=True)
+    if slice_dims:
+        new_heads_V.append(v64)
+        for j in range(kv_head_ratio):
+            new_heads_O.append(o64[:, j * rank:(j + 1) * rank])
+        return
+    # upstream's slice_dims=False branch writes the zero-padded V through W_v[:, kv_start:kv_end] (compress_vo.py:135),
+    # a column slice of a [n_kv*hd, d] matrix -- shape-inconsistent as written; the row slice is what is meant
+    Vp = torch.zeros(head_dim, W_v.shape[1], dtype=W_v.dtype, device=W_v.device)
+    Vp[:rank] = v64.to(dtype=W_v.dtype, device=W_v.device)
+    W_v[r0:r0 + head_dim, :].data.copy_(Vp)
+    for j in range(kv_head_ratio):
+        Op = torch.zeros(W_o.shape[0], head_dim, dtype=W_o.dtype, device=W_o.device)
+        Op[:, :rank] = o64[:, j * rank:(j + 1) * rank].to(dtype=W_o.dtype, device=W_o.device)
+        W_o[:, c0 + j * head_dim:c0 + (j + 1) * head_dim].data.copy_(Op)
+
+
+@torch.no_grad()
+def compress_head(head_idx: int, head_dim: int, rank_i: int, W_v: Tensor, W_o: Tensor, sqrt_C: Tensor, inv_sqrt_C: Tensor,
+                  new_heads_V: list, new_heads_O: list, slice_dims=True, arch="opt"):
+    """One head of an MHA layer (compress_vo.py:162-223): the two-SVD variant; appends W_v' [rank, d] and W_o' [d, rank]
+    (fp64), or with slice_dims=False writes them zero-padded into W_v / W_o in place."""
+    s0 = head_idx * head_dim
+    Wv_h = W_v[s0:s0 + head_dim, :].detach().to(d2)
+    Wo_h = W_o[:, s0:s0 + head_dim].detach().to(d2)
+    _, _, v64, o64 = ops.vo_compress(_regularised_cov(sqrt_C), Wv_h, Wo_h, 1, 1, head_dim, rank_i, 0.0, want_f64=True)
+    if slice_dims:
+        new_heads_V.append(v64)
+        new_heads_O.append(o64)
+        return
+    Vp = torch.zeros(head_dim, W_v.shape[1], dtype=W_v.dtype, device=W_v.device)
+    Vp[:rank_i] = v64.to(dtype=W_v.dtype, device=W_v.device)
+    Op = torch.zeros(W_o.shape[0], head_dim, dtype=W_o.dtype, device=W_o.device)
+    Op[:, :rank_i] = o64.to(dtype=W_o.dtype, device=W_o.device)
+    W_v[s0:s0 + head_dim, :].data.copy_(Vp)
+    W_o[:, s0:s0 + head_dim].data.copy_(Op)
+
+
 @torch.no_grad()
 def compress_vo(adapter: ModelAdapter, cov: List[Tensor], keep_ratios=None, slice_dims=True,
                 target_layers: Optional[List[int]] = None):

@@ -58,6 +58,22 @@ def sqrt_M(M: Tensor, ridge_lambda=1e-4, scaled=False, debug: str = "", inverse_
     return root, inv_root.to(dtype=M.dtype)
 
 
+def get_gate_projs(model, layer_idx):
+    """(block, up, down, gate or None, family) of one decoder layer by probing the module tree
+    (compression_utils.py:58-76): OPT (fc1 / fc2), GPT-2 style (mlp.c_fc / mlp.c_proj), else Llama style."""
+    probes = (("opt", lambda m: m.model.decoder.layers[layer_idx], lambda b: (b.fc1, b.fc2, None)),
+              ("gpt", lambda m: m.transformer.h[layer_idx], lambda b: (b.mlp.c_fc, b.mlp.c_proj, None)))
+    for family, find_block, parts in probes:
+        try:
+            block = find_block(model)
+            up, down, gate = parts(block)
+            return block, up, down, gate, family
+        except AttributeError:
+            continue
+    block = model.model.layers[layer_idx]
+    return block, block.mlp.up_proj, block.mlp.down_proj, block.mlp.gate_proj, "llama"
+
+
 def allocate_global_sparsity(bi_scores, compression_ratio: float, smoothing: float = 0.015, max_sparsity: float = 0.8,
                              adapter=None, invert=False):
     """Block-Influence scores -> per-layer keep ratios (compression_utils.py:79-124).  Host arithmetic on purpose:

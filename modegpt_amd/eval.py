@@ -84,33 +84,111 @@ def load_calibration_texts(calib_size, model, tokenizer, batch_size: int, datase
     return _batches(chunks[pick], batch_size)
 
 
+def load_c4(tokenizer, texts, n_samples):
+    """n_samples random 2048-token windows, each from a randomly drawn document longer than 2048 tokens
+    (eval.py:17-30; random.seed(1234) fixes the draw)."""
+    random.seed(1234)
+    seqlen = 2048
+    windows = []
+    while len(windows) < n_samples:
+        while True:
+            ids = tokenizer(texts[random.randint(0, len(texts) - 1)], return_tensors="pt").input_ids
+            if ids.shape[1] > seqlen:
+                break
+        start = random.randint(0, ids.shape[1] - seqlen - 1)
+        windows.append(ids[:, start:start + seqlen].to(device="cuda"))
+    return windows
+
+
+def _alpaca_prompt(example, with_output: bool) -> str:
+    head = "Below is an instruction that describes a task"
+    tail = example["output"] if with_output else ""
+    if example.get("input", ""):
+        return (f"{head}, paired with an input that provides further context. Write a response that appropriately "
+                f"completes the request.\n\n### Instruction:\n{example['instruction']}\n\n### Input:\n{example['input']}"
+                f"\n\n### Response:\n{tail}")
+    return (f"{head}. Write a response that appropriately completes the request.\n\n### Instruction:\n"
+            f"{example['instruction']}\n\n### Response:\n{tail}")
+
+
+def get_alpaca_eval_data(n_samples: int = 500):
+    """The last n_samples examples of tatsu-lab/alpaca's only split, formatted with their outputs (eval.py:228-255)."""
+    from datasets import load_dataset
+    ds = load_dataset("tatsu-lab/alpaca", split="train")
+    ds = ds.select(range(len(ds) - n_samples, len(ds)))
+    return [_alpaca_prompt(ex, with_output=True) for ex in ds]
+
+
+def _eval_token_stream(tokenizer, dataset: str) -> torch.Tensor:
+    """[1, n_tokens] ids of the evaluation text of `dataset`, tokenised in one call as upstream does (eval.py:141-160)."""
+    from datasets import load_dataset
+    if dataset == "wikitext":
+        text = "\n\n".join(load_dataset("wikitext", "wikitext-2-raw-v1", split="test")["text"])
+    elif dataset == "c4":
+        raw = load_dataset("json", data_files={
+            "validation": "https://huggingface.co/datasets/allenai/c4/resolve/main/en/c4-validation.00000-of-00008.json.gz"})
+        text = "\n\n".join([t for t in raw["validation"]["text"] if len(t.strip()) > 0][:5000])
+    elif dataset == "alpaca":
+        text = "\n\n".join(get_alpaca_eval_data())
+    else:
+        raise ValueError(f"Unknown dataset: {dataset}. Must be 'wikitext', 'c4', or 'alpaca'")
+    return tokenizer(text, return_tensors="pt").input_ids
+
+
 @torch.no_grad()
-def compute_perplexity(model, tokenizer, dataset="wikitext", adapter=None, batch_size: int = 4, device="cuda"):
-    """Token-level perplexity over the dataset's test split in max_length windows (eval.py:135-225); records
-    throughput_tok/s in adapter.metrics."""
-    L = _seq_len(model)
+def compute_perplexity(model, tokenizer, bs=16, device="cuda", dataset="wikitext", adapter=None):
+    """Perplexity over consecutive 2048-token windows of the evaluation stream, at most 512 of them, `bs` per forward:
+    exp(sum of token NLLs / (windows * 2047))  (eval.py:135-225).  Records throughput_tok/s and throughput_ktok/s in
+    adapter.metrics.  Differences: `dataset="synthetic"` (seeded random ids, no network) and a window shorter than
+    2048 for models whose max_position_embeddings is smaller (the tiny test models)."""
+    model.eval()
+    seqlen = _seq_len(model)
     if dataset == "synthetic":
         g = torch.Generator().manual_seed(4321)
-        ids = torch.randint(0, model.config.vocab_size, (8, L), generator=g)
+        stream = torch.randint(0, model.config.vocab_size, (1, 8 * seqlen), generator=g)
     else:
-        from datasets import load_dataset
-        if dataset == "c4":
-            raw = load_dataset("json", data_files={
-                "validation": "https://huggingface.co/datasets/allenai/c4/resolve/main/en/c4-validation.00000-of-00008.json.gz"})
-            text = "\n\n".join(raw["validation"]["text"][:1100])
-        else:
-            text = "\n\n".join(load_dataset("wikitext", "wikitext-2-raw-v1", split="test")["text"])
-        ids = chunk_text(model, tokenizer, text, min_threshold=L)
-    model.eval()
-    nll, count, t0 = 0.0, 0, time.time()
-    for i in range(0, ids.shape[0], batch_size):
-        b = ids[i:i + batch_size].to(device)
-        logits = model(b).logits[:, :-1].float()
-        loss = torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]), b[:, 1:].reshape(-1),
-                                                 reduction="sum")
-        nll += loss.item()
-        count += b[:, 1:].numel()
-    ppl = math.exp(nll / max(count, 1))
-    if adapter is not None:
-        adapter.metrics["throughput_tok/s"] = ids.numel() / max(time.time() - t0, 1e-9)
+        stream = _eval_token_stream(tokenizer, dataset)
+    nsamples = min(stream.numel() // seqlen, 512)
+    print(f"nsamples {nsamples}")
+    nll_sum = torch.zeros((), dtype=torch.float32, device=device)
+    tokens_done = 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(0, nsamples, bs):
+        j = min(i + bs, nsamples)
+        inputs = stream[:, i * seqlen:j * seqlen].to(device).reshape(j - i, seqlen)
+        logits = model(inputs).logits
+        loss = torch.nn.functional.cross_entropy(logits[:, :-1, :].reshape(-1, logits.size(-1)), inputs[:, 1:].reshape(-1))
+        nll_sum += loss.float() * (seqlen - 1) * (j - i)          # mean over the batch's predicted tokens, re-weighted
+        tokens_done += (j - i) * seqlen
+        if i:
+            print(f"\rsample {i}/{nsamples} | ppl: {math.exp(nll_sum.item() / (i * (seqlen - 1))):.2f}", end="", flush=True)
+    torch.cuda.synchronize()
+    elapsed = max(time.perf_counter() - t0, 1e-9)
+    print(f"\nThroughput: {tokens_done:,} tokens in {elapsed:.2f} s = {tokens_done / elapsed:,.0f} tok/s")
+    if adapter:
+        adapter.metrics["throughput_tok/s"] = tokens_done / elapsed
+        adapter.metrics["throughput_ktok/s"] = tokens_done / elapsed / 1000
+    ppl = math.exp(nll_sum.item() / max(nsamples * (seqlen - 1), 1))
+    torch.cuda.empty_cache()
     return ppl
+
+
+@torch.no_grad()
+def evaluate_perplexity_alpaca(model, tokenizer, device="cuda"):
+    """Per-example perplexity on the alpaca hold-out: every formatted example truncated to 2048 tokens, loss from the
+    model's own label shift, token-weighted mean, non-finite losses skipped (eval.py:258-300)."""
+    texts = get_alpaca_eval_data()
+    model.eval()
+    total, n_tok = 0.0, 0
+    print(f"Evaluating Perplexity on {len(texts)} samples...")
+    for text in texts:
+        enc = tokenizer(text, return_tensors="pt", truncation=True, max_length=2048).to(device)
+        loss = model(**enc, labels=enc["input_ids"].clone()).loss
+        if not torch.isfinite(loss):
+            print("Warning: Non-finite loss detected")
+            continue
+        n = enc["input_ids"].size(1)
+        total += loss.item() * n
+        n_tok += n
+    return float("inf") if n_tok == 0 else math.exp(total / n_tok)

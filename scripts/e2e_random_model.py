@@ -62,7 +62,7 @@ print(f"convert_model + patch_config: {t_cv:.1f} s; gate_ranks[:4] {cfg.gate_ran
 from modegpt_amd.patchers import install_compressed_attention
 from modegpt_amd.eval import compute_perplexity
 install_compressed_attention(ad, masks)
-t0 = time.time(); ppl = compute_perplexity(model, None, dataset="synthetic", adapter=ad, batch_size=4); t_ppl = time.time() - t0
+t0 = time.time(); ppl = compute_perplexity(model, None, bs=4, dataset="synthetic", adapter=ad); t_ppl = time.time() - t0
 print(f"compressed model, in-process compressed attention: synthetic-token perplexity {ppl:.1f} (random weights; vocab 32000) in {t_ppl:.1f} s")
 print(f"TOTAL {t_cal + t_mlp + t_qk + t_vo:.1f} s for {L} layers = {L / (t_cal + t_mlp + t_qk + t_vo):.3f} layers/s (model forward and artefact IO included)")
 shutil.rmtree(tmp, ignore_errors=True)

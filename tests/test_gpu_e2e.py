@@ -577,3 +577,78 @@ def test_compressed_attention_kernel_vs_eager_and_reload(dev, kind, tmp_path):
         eager = model(ids).logits.float()
     err = (live - eager).abs().max().item() / eager.abs().max().item()
     assert err < 2e-2, f"HIP compressed attention vs eager restatement: {err:.3e}"
+
+
+# ---------------------------------------------------------------- per-head entry points of the reference (8(a) rows a14-a19)
+@pytest.mark.parametrize("name", ["tiny_gqa", "tiny_mha", "tiny_opt"])
+def test_per_head_qk_functions_match_the_layer_goldens(dev, name):
+    """compress_head_llama_grouped / compress_head_llama / compress_head_opt called head by head, the way the
+    reference's compress_layer does, reproduce the golden mask and gathered rows of the whole layer."""
+    from modegpt_amd.compression import compress_qk as Q
+    c = Case(name)
+    Wq = c.W["q"].to(dev).view(c.n_h, c.hd, -1)
+    Wk = c.W["k"].to(dev).view(c.n_kv, c.hd, -1)
+    cq, ck = c.f64["sigma_q"].to(dev), c.f64["sigma_k"].to(dev)
+    q_out, k_out, masks = [], [], []
+    for h in range(c.n_kv):
+        if c.arch == "opt":
+            bq = torch.arange(c.hd, dtype=torch.float32, device=dev)
+            qb, kb = [], []
+            Q.compress_head_opt(cq[h], ck[h], Wq[h], Wk[h], bq, -bq, q_out, k_out, qb, kb, rank=c.qk_rank)
+            masks.append(qb[-1].long())                              # the bias entries ARE the kept indices here
+            assert torch.equal(kb[-1], -qb[-1])
+        elif c.n_kv != c.n_h:
+            Q.compress_head_llama_grouped(h, c.n_h // c.n_kv, cq, ck, Wq, Wk, q_out, k_out, masks, rank=c.qk_rank,
+                                          ridge_lambda=c.ridges["ridge_qk"])
+        else:
+            Q.compress_head_llama(cq[h], ck[h], Wq[h], Wk[h], q_out, k_out, masks, rank=c.qk_rank)
+    assert torch.equal(torch.stack([m.cpu() for m in masks]), c.qk_mask)
+    assert torch.equal(torch.cat([t.cpu() for t in q_out]).to(torch.bfloat16), c.bf["qk_q"])
+    assert torch.equal(torch.cat([t.cpu() for t in k_out]).to(torch.bfloat16), c.bf["qk_k"])
+
+
+@pytest.mark.parametrize("name", ["tiny_gqa", "tiny_mha"])
+def test_per_head_vo_functions_match_the_layer_goldens(dev, name):
+    """compress_head_grouped / compress_head fed sqrt(C + ridge I) and its inverse, as the reference's compress_vo feeds
+    them, reproduce the layer's golden factors (per-head products; the factors up to sign)."""
+    from modegpt_amd.compression import compress_vo as V
+    c = Case(name)
+    sC, isC = c.f64["sqrt_x"].to(dev), c.f64["invsqrt_x"].to(dev)
+    Wv, Wo = c.W["v"].to(dev), c.W["o"].to(dev)
+    vs, os_ = [], []
+    g = c.n_h // c.n_kv
+    for h in range(c.n_kv):
+        if g > 1:
+            V.compress_head_grouped(h, g, c.hd, c.vo_rank, Wv, Wo, sC, isC, vs, os_, slice_dims=True, arch=c.arch)
+        else:
+            V.compress_head(h, c.hd, c.vo_rank, Wv, Wo, sC, isC, vs, os_, slice_dims=True, arch=c.arch)
+    v64, o64 = torch.cat(vs, dim=0).cpu(), torch.cat(os_, dim=1).cpu()
+    assert v64.dtype == torch.float64 and v64.shape == c.f64["vo_v_f64"].shape and o64.shape == c.f64["vo_o_f64"].shape
+    got = vo_products(v64, o64, c.n_h, c.n_kv, c.vo_rank)
+    want = vo_products(c.f64["vo_v_f64"], c.f64["vo_o_f64"], c.n_h, c.n_kv, c.vo_rank)
+    assert ((got - want).abs().max() / want.abs().max()).item() < 1e-7
+
+
+def test_slice_dims_methods_swap_modules_in_place(dev):
+    """ModelAdapter.slice_gate_dims / slice_qk_dims / slice_vo_dims (the reference's in-place alternative to
+    save_layer + convert_model) install Linears of the compressed shapes with the bias rules of model_adapter.py:394-542."""
+    from modegpt_amd.adapters.model_adapter import ModelAdapter
+    model = _tiny_model("opt", dev)        # OPT: every projection has a bias
+    ad = ModelAdapter.from_model(model, None)
+    blk = ad.get_transformer_blocks()[0]
+    d, r = 128, 96
+    up, down = torch.randn(r, d, device=dev), torch.randn(d, r, device=dev)
+    old_down_bias = blk.fc2.bias.detach().clone()
+    ad.slice_gate_dims(0, up, down, None, torch.ones(r, device=dev), None, bias=True)
+    assert blk.fc1.weight.shape == (r, d) and blk.fc1.weight.dtype == torch.bfloat16 and bool((blk.fc1.bias == 1).all())
+    assert blk.fc2.weight.shape == (d, r) and torch.equal(blk.fc2.bias, old_down_bias)
+    heads = [torch.randn(5, d, device=dev) for _ in range(4)]
+    ad.slice_qk_dims(0, heads, heads)                                   # no per-head biases passed -> bias-free
+    assert blk.self_attn.q_proj.weight.shape == (20, d) and blk.self_attn.q_proj.bias is None
+    ad.slice_qk_dims(0, heads, heads, [torch.zeros(5, device=dev)] * 4, [torch.zeros(5, device=dev)] * 4)
+    # the module being replaced is now bias-free, so no bias is created either (comps.q_proj.bias is None)
+    assert blk.self_attn.k_proj.bias is None
+    old_o_bias = blk.self_attn.out_proj.bias.detach().clone()
+    ad.slice_vo_dims(0, [torch.randn(6, d, device=dev)] * 4, [torch.randn(d, 6, device=dev)] * 4, bias=True)
+    assert blk.self_attn.v_proj.weight.shape == (24, d) and blk.self_attn.v_proj.bias is None
+    assert blk.self_attn.out_proj.weight.shape == (d, 24) and torch.equal(blk.self_attn.out_proj.bias, old_o_bias)

@@ -187,3 +187,145 @@ def test_checkpoint_loads_through_its_modeling_file(kind, tmp_path):
         for i, layer in enumerate(loaded.model.layers):
             assert torch.equal(layer.self_attn.layer_rotary_mask.cpu(), masks[i])
             assert "layer_rotary_mask" not in got
+
+
+def test_cli_surface_matches_the_reference_source():
+    """Drop-in check in the build container (the reference does not exist on the GPU box: skipped there).  The flags,
+    types and defaults of the reference's CompressionConfig are read from its source TEXT (no import) and compared with
+    this engine's; the same for the signatures of the five functions main() calls."""
+    import ast
+    ref_root = "/root/reference/src"
+    if not os.path.isdir(ref_root):
+        pytest.skip("reference checkout not present")
+    from dataclasses import fields
+    from modegpt_amd.adapters.CompressionConfig import CompressionConfig
+    tree = ast.parse(open(os.path.join(ref_root, "adapters", "CompressionConfig.py")).read())
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "CompressionConfig")
+    ref_fields = {}
+    for node in cls.body:
+        if isinstance(node, ast.AnnAssign) and not node.target.id.startswith("_"):
+            ref_fields[node.target.id] = (ast.unparse(node.annotation), ast.literal_eval(node.value))
+    mine = {f.name: f for f in fields(CompressionConfig) if not f.name.startswith("_")}
+    assert set(mine) == set(ref_fields)
+    actions = {a.dest: a for a in CompressionConfig.make_parser()._actions}
+    for name, (ann, default) in ref_fields.items():
+        assert mine[name].default == default, name
+        want_type = {"str": str, "int": int, "float": float, "bool": bool, "Optional[str]": str}[ann]
+        act = actions[name]
+        assert act.option_strings == [f"--{name}"] and act.default == default, name
+        if want_type is bool:
+            assert act.nargs == 0 and act.const is True, name          # store_true, as upstream
+        else:
+            assert act.type is want_type, name
+    # parsing a reference-style command line yields the same values
+    argv = ["--model", "m", "--compression_ratio", "0.3", "--order", "mlp,qk,vo", "--calib_size", "512", "--debug"]
+    cfg = CompressionConfig.from_args(argv)
+    assert (cfg.model, cfg.compression_ratio, cfg.order, cfg.calib_size, cfg.debug) == ("m", 0.3, "mlp,qk,vo", 512, True)
+
+    def signature(path, fn):
+        t = ast.parse(open(path).read())
+        node = next(n for n in ast.walk(t) if isinstance(n, ast.FunctionDef) and n.name == fn)
+        a = node.args
+        names = [x.arg for x in a.args]
+        defaults = [ast.unparse(d) for d in a.defaults]
+        return names, defaults
+
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "modegpt_amd")
+    for rel_path, fn in (("calibration.py", "load_calibs"), ("compression_utils.py", "allocate_global_sparsity"),
+                         ("compression_utils.py", "sqrt_M"), ("compression/compress_mlp.py", "compress_nystrom"),
+                         ("compression/compress_qk.py", "compress_qk"), ("compression/compress_vo.py", "compress_vo")):
+        ref_names, ref_defaults = signature(os.path.join(ref_root, rel_path), fn)
+        my_names, my_defaults = signature(os.path.join(here, rel_path), fn)
+        assert my_names == ref_names, (fn, my_names, ref_names)
+        norm = lambda ds: [d.replace('"', "'") for d in ds]
+        assert norm(my_defaults) == norm(ref_defaults), (fn, my_defaults, ref_defaults)
+
+
+def test_adapter_plugin_surface_matches_the_reference_source():
+    """Same idea for the plug-in ABC: every method (and abstract method) the reference's ModelAdapter declares exists here
+    with the same positional parameters, so an adapter written against the reference subclasses this one unchanged."""
+    import ast
+    ref = "/root/reference/src/adapters/model_adapter.py"
+    if not os.path.exists(ref):
+        pytest.skip("reference checkout not present")
+    mine = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "modegpt_amd", "adapters", "model_adapter.py")
+
+    def methods(path):
+        tree = ast.parse(open(path).read())
+        cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "ModelAdapter")
+        out = {}
+        for n in cls.body:
+            if isinstance(n, ast.FunctionDef):
+                decos = {ast.unparse(d).split(".")[-1] for d in n.decorator_list}
+                out[n.name] = ([a.arg for a in n.args.args], "abstractmethod" in decos, "property" in decos)
+        return out
+
+    r, m = methods(ref), methods(mine)
+    missing = [k for k in r if not k.startswith("__") and k not in m]
+    assert not missing, f"ModelAdapter lacks reference methods: {missing}"
+    for name, (params, is_abstract, is_prop) in r.items():
+        if name.startswith("__"):
+            continue
+        assert m[name][0][:len(params)] == params or m[name][0] == params, (name, m[name][0], params)
+        assert m[name][2] == is_prop, name
+        if is_abstract:
+            assert m[name][1], f"{name} must stay abstract"
+    # the component dataclasses travel between adapter and compressors by field name
+    for cls_name in ("MLPComponents", "QKComponents", "VOComponents", "AttentionComponents", "MLPTensors", "QKTensors", "VOTensors"):
+        def fields_of(path):
+            tree = ast.parse(open(path).read())
+            c = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls_name)
+            return [n.target.id for n in c.body if isinstance(n, ast.AnnAssign)]
+        ref_f = fields_of(ref)
+        import importlib
+        mod = importlib.import_module("modegpt_amd.adapters.model_adapter")
+        import dataclasses
+        assert [f.name for f in dataclasses.fields(getattr(mod, cls_name))] == ref_f, cls_name
+
+
+# reference names this engine deliberately does not carry, each with its reason
+_SURFACE_EXCLUSIONS = {
+    "run_modegpt.py": {"_debug_load_param": "private debugging helper"},
+    "adapters/LlamaAdapter.py": {"LlamaAdapter._attn_hook": "post-RoPE statistic, disabled upstream (LlamaAdapter.py:83-90)",
+                                 "patched_attn_forward": "only used by the disabled post-RoPE hook"},
+    "analysis/optuna.py": {"objective": "upstream hard-codes one model's config; objective_factory(argv) builds it from flags"},
+}
+_SURFACE_FILES = ["calibration.py", "compression_utils.py", "model_utils.py", "eval.py", "run_modegpt.py",
+                  "compression/compress_mlp.py", "compression/compress_qk.py", "compression/compress_vo.py",
+                  "adapters/LlamaAdapter.py", "adapters/QwenAdapter.py", "adapters/OPTAdapter.py", "patchers/patch.py",
+                  "analysis/optuna.py"]
+
+
+@pytest.mark.parametrize("rel_path", _SURFACE_FILES)
+def test_every_reference_function_exists_with_its_parameters(rel_path):
+    """Module by module: every top-level function and every method of every class in the reference's file exists here
+    under the same name with the same leading parameters (read from source text; skipped where the reference is absent)."""
+    import ast
+    ref = os.path.join("/root/reference/src", rel_path)
+    if not os.path.exists(ref):
+        pytest.skip("reference checkout not present")
+    mine = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "modegpt_amd", rel_path)
+
+    def surface(path):
+        out = {}
+        for n in ast.parse(open(path).read()).body:
+            if isinstance(n, ast.FunctionDef):
+                out[n.name] = [a.arg for a in n.args.args]
+            elif isinstance(n, ast.ClassDef):
+                for m in n.body:
+                    if isinstance(m, ast.FunctionDef):
+                        out[f"{n.name}.{m.name}"] = [a.arg for a in m.args.args]
+        return out
+
+    r, m = surface(ref), surface(mine)
+    skip = _SURFACE_EXCLUSIONS.get(rel_path, {})
+    problems = []
+    for name, params in r.items():
+        leaf = name.split(".")[-1]
+        if name in skip or (leaf.startswith("__") and leaf != "__init__"):
+            continue
+        if name not in m:
+            problems.append(f"missing {name}({', '.join(params)})")
+        elif m[name][:len(params)] != params:
+            problems.append(f"{name}: reference ({', '.join(params)}) vs ({', '.join(m[name])})")
+    assert not problems, "\n".join(problems)
