@@ -365,11 +365,27 @@ __global__ __launch_bounds__(256) void rope_tile_kernel(TileArgs ta) {
   {
     const E* cg = (const E*)a.cos + b * a.cs_bstride + t0 * hd;
     const E* sg = (const E*)a.sin + b * a.cs_bstride + t0 * hd;
-    for (int c = threadIdx.x; c < tv * hd; c += 256) {
-      P2 v;
-      v.v[0] = cg[c];
-      v.v[1] = sg[c];
-      cs[c] = v;
+    if (a.cs_vec16) {  // 16 bytes of cos + 16 bytes of sin per lane and step, interleaved in registers
+      constexpr int PER16 = 16 / (int)sizeof(E);
+      typedef Pack<E, PER16> Q;
+      for (int c = threadIdx.x * PER16; c < tv * hd; c += 256 * PER16) {
+        const Q cv = *(const Q*)(cg + c), sv = *(const Q*)(sg + c);
+        P2 il[PER16];
+#pragma unroll
+        for (int k = 0; k < PER16; k++) {
+          il[k].v[0] = cv.v[k];
+          il[k].v[1] = sv.v[k];
+        }
+        *(u32x4*)(cs + c) = *(const u32x4*)&il[0];
+        *(u32x4*)(cs + c + PER16 / 2) = *(const u32x4*)&il[PER16 / 2];
+      }
+    } else {
+      for (int c = threadIdx.x; c < tv * hd; c += 256) {
+        P2 v;
+        v.v[0] = cg[c];
+        v.v[1] = sg[c];
+        cs[c] = v;
+      }
     }
   }
   for (int j = threadIdx.x; j < r; j += 256) {
@@ -559,8 +575,10 @@ extern "C" int mdg_rope_gather(const void* x, int dtype, int64_t ld_x, int64_t B
   while (vec > 1 && (half % vec || ld_x % vec || ((uintptr_t)x | (uintptr_t)out) % (es * vec) ||
                      (mask && (uintptr_t)mask % (8 * vec))))
     vec >>= 1;
-  if (vec > 1) {  // packs of the rotate_half partners straight from / to memory (measured: 4-byte packs at r = 76 still
-                  // beat the LDS route, 97 vs 108 us; 2-byte packs at r = 102 do not, 199 vs 162 us)
+  // Packs of the rotate_half partners straight from / to memory when they are at least 4 bytes.  Measured on
+  // [16, 2048, 32 x r] bf16, direct vs LDS route: r = 88 (8-byte packs) 84 vs 113 us; r = 76 (4-byte) 105 vs 99 us, a tie;
+  // r = 102 (2-byte) 199 vs 150 us.  MDG_ROPE_TILE=1 forces the LDS route (experiment knob of scripts/bench_kernels.py).
+  if (vec > 1 && !getenv("MDG_ROPE_TILE")) {
     const dim3 grid((unsigned)(N_XCD * n_kv), (unsigned)tiles8, (unsigned)a.chunks);
     if (dtype == MDG_BF16) MDG_HIP(launch_rope_vec<MDG_BF16>(a, vec, hpt, grid, st));
     else if (dtype == MDG_F16) MDG_HIP(launch_rope_vec<MDG_F16>(a, vec, hpt, grid, st));
