@@ -318,9 +318,20 @@ __device__ __forceinline__ void copy_runs(unsigned char* dst, size_t dst_stride,
                                           int segs, int seg_bytes) {
   typedef typename ChunkT<W>::type C;
   const int cps = seg_bytes / W, total = segs * cps;
-  for (int c = threadIdx.x; c < total; c += 256) {
-    const int sidx = c / cps, k = c - sidx * cps;
-    *(C*)(dst + sidx * dst_stride + (size_t)k * W) = *(const C*)(src + sidx * src_stride + (size_t)k * W);
+  // four chunks per lane in flight: all loads of a batch are issued before the first store waits for one
+  for (int c0 = threadIdx.x; c0 < total; c0 += 4 * 256) {
+    C buf[4];
+    size_t off[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int c = min(c0 + u * 256, total - 1);
+      const int sidx = c / cps, k = c - sidx * cps;
+      buf[u] = *(const C*)(src + sidx * src_stride + (size_t)k * W);
+      off[u] = sidx * dst_stride + (size_t)k * W;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (c0 + u * 256 < total) *(C*)(dst + off[u]) = buf[u];
   }
 }
 __device__ __forceinline__ void copy_runs_w(int w, unsigned char* dst, size_t dst_stride, const unsigned char* src,
@@ -415,71 +426,99 @@ __global__ __launch_bounds__(256) void rope_tile_kernel(TileArgs ta) {
   const int hp = (half + 1) >> 1;
   const int items = rows * hp;
   const int ch_shift = CH == 4 ? 2 : CH == 2 ? 1 : 0;
-  for (int item = threadIdx.x; item < items; item += 256) {
-    const int row = hp == 1 ? item : (int)__umulhi((unsigned)item, ta.half_magic);  // 2^32 / 1 does not fit the magic
-    const int j = (item - row * hp) * 2;
-    const bool two = HALF_EVEN || j + 1 < half;
-    const int tok = row >> ch_shift, hh = row & (CH - 1);
-    const E* xr = xin + (size_t)row * r;
-    E e1[2], e2[2];
-    short m1[2], m2[2];
-    {
-      const P2 p = *(const P2*)(xr + j);  // j is even and rows are even: aligned; the second element may be the partner half
-      e1[0] = p.v[0];
-      e1[1] = p.v[1];
-      const M2 q = *(const M2*)(msk + j);
-      m1[0] = q.v[0];
-      m1[1] = q.v[1];
-    }
-    if (HALF_EVEN) {
-      const P2 p = *(const P2*)(xr + half + j);
-      e2[0] = p.v[0];
-      e2[1] = p.v[1];
-      const M2 q = *(const M2*)(msk + half + j);
-      m2[0] = q.v[0];
-      m2[1] = q.v[1];
-    } else {
-      e2[0] = xr[half + j];
-      m2[0] = msk[half + j];
-      e2[1] = two ? xr[half + j + 1] : e2[0];
-      m2[1] = two ? msk[half + j + 1] : m2[0];
-    }
-    if (!two) m1[1] = m1[0];
-    const P2* cr = cs + (size_t)tok * hd;
-    E o1[2], o2[2];
+  // IT items per lane in flight: the rotate step is a chain of dependent LDS reads (mask -> table, row -> math), so the
+  // reads of all IT items are issued phase by phase before anything waits on them
+  constexpr int IT = 2;
+  for (int base = threadIdx.x; base < items; base += 256 * IT) {
+    int row[IT], j[IT];
+    bool live[IT], two[IT];
+    E e1[IT][2], e2[IT][2];
+    short m1[IT][2], m2[IT][2];
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-      float a1 = Lp<DT>::up(e1[k]), a2 = Lp<DT>::up(e2[k]);
-      if (NORM) {
-        const float iv = inv[row];
-        a1 = Lp<DT>::up(Lp<DT>::down(mul_r(Lp<DT>::up(nw[m1[k]]), mul_r(a1, iv))));
-        a2 = Lp<DT>::up(Lp<DT>::down(mul_r(Lp<DT>::up(nw[m2[k]]), mul_r(a2, iv))));
+    for (int u = 0; u < IT; u++) {
+      const int item = base + u * 256;
+      live[u] = item < items;
+      const int ic = live[u] ? item : base;
+      row[u] = hp == 1 ? ic : (int)__umulhi((unsigned)ic, ta.half_magic);  // 2^32 / 1 does not fit the magic
+      j[u] = (ic - row[u] * hp) * 2;
+      two[u] = HALF_EVEN || j[u] + 1 < half;
+      const E* xr = xin + (size_t)row[u] * r;
+      {
+        const P2 p = *(const P2*)(xr + j[u]);  // j is even and rows are even: aligned; the 2nd element may be the partner half
+        e1[u][0] = p.v[0];
+        e1[u][1] = p.v[1];
+        const M2 q = *(const M2*)(msk + j[u]);
+        m1[u][0] = q.v[0];
+        m1[u][1] = q.v[1];
       }
-      const P2 t1 = cr[m1[k]], t2 = cr[m2[k]];
-      const float u1 = Lp<DT>::up(Lp<DT>::down(mul_r(a1, Lp<DT>::up(t1.v[0]))));
-      const float v1 = Lp<DT>::up(Lp<DT>::down(mul_r(-a2, Lp<DT>::up(t1.v[1]))));
-      const float u2 = Lp<DT>::up(Lp<DT>::down(mul_r(a2, Lp<DT>::up(t2.v[0]))));
-      const float v2 = Lp<DT>::up(Lp<DT>::down(mul_r(a1, Lp<DT>::up(t2.v[1]))));
-      o1[k] = Lp<DT>::down(add_r(u1, v1));
-      o2[k] = Lp<DT>::down(add_r(u2, v2));
+      if (HALF_EVEN) {
+        const P2 p = *(const P2*)(xr + half + j[u]);
+        e2[u][0] = p.v[0];
+        e2[u][1] = p.v[1];
+        const M2 q = *(const M2*)(msk + half + j[u]);
+        m2[u][0] = q.v[0];
+        m2[u][1] = q.v[1];
+      } else {
+        e2[u][0] = xr[half + j[u]];
+        m2[u][0] = msk[half + j[u]];
+        e2[u][1] = two[u] ? xr[half + j[u] + 1] : e2[u][0];
+        m2[u][1] = two[u] ? msk[half + j[u] + 1] : m2[u][0];
+      }
+      if (!two[u]) m1[u][1] = m1[u][0];
     }
-    E* orow = xout + ((size_t)hh * TT + tok) * r;
-    if (two) {
-      P2 w;
-      w.v[0] = o1[0];
-      w.v[1] = o1[1];
-      *(P2*)(orow + j) = w;
-    } else {
-      orow[j] = o1[0];
+    P2 t1[IT][2], t2[IT][2];
+    float w1[IT][2], w2[IT][2], iv[IT];
+#pragma unroll
+    for (int u = 0; u < IT; u++) {
+      const P2* cr = cs + (size_t)(row[u] >> ch_shift) * hd;
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        t1[u][k] = cr[m1[u][k]];
+        t2[u][k] = cr[m2[u][k]];
+        if (NORM) {
+          w1[u][k] = Lp<DT>::up(nw[m1[u][k]]);
+          w2[u][k] = Lp<DT>::up(nw[m2[u][k]]);
+        }
+      }
+      if (NORM) iv[u] = inv[row[u]];
     }
-    if (HALF_EVEN) {
-      P2 w;
-      w.v[0] = o2[0];
-      w.v[1] = o2[1];
-      *(P2*)(orow + half + j) = w;
-    } else {
-      orow[half + j] = o2[0];
-      if (two) orow[half + j + 1] = o2[1];
+#pragma unroll
+    for (int u = 0; u < IT; u++) {
+      E o1[2], o2[2];
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        float a1 = Lp<DT>::up(e1[u][k]), a2 = Lp<DT>::up(e2[u][k]);
+        if (NORM) {
+          a1 = Lp<DT>::up(Lp<DT>::down(mul_r(w1[u][k], mul_r(a1, iv[u]))));
+          a2 = Lp<DT>::up(Lp<DT>::down(mul_r(w2[u][k], mul_r(a2, iv[u]))));
+        }
+        const float u1 = Lp<DT>::up(Lp<DT>::down(mul_r(a1, Lp<DT>::up(t1[u][k].v[0]))));
+        const float v1 = Lp<DT>::up(Lp<DT>::down(mul_r(-a2, Lp<DT>::up(t1[u][k].v[1]))));
+        const float u2 = Lp<DT>::up(Lp<DT>::down(mul_r(a2, Lp<DT>::up(t2[u][k].v[0]))));
+        const float v2 = Lp<DT>::up(Lp<DT>::down(mul_r(a1, Lp<DT>::up(t2[u][k].v[1]))));
+        o1[k] = Lp<DT>::down(add_r(u1, v1));
+        o2[k] = Lp<DT>::down(add_r(u2, v2));
+      }
+      if (!live[u]) continue;
+      const int tok = row[u] >> ch_shift, hh = row[u] & (CH - 1);
+      E* orow = xout + ((size_t)hh * TT + tok) * r;
+      if (two[u]) {
+        P2 w;
+        w.v[0] = o1[0];
+        w.v[1] = o1[1];
+        *(P2*)(orow + j[u]) = w;
+      } else {
+        orow[j[u]] = o1[0];
+      }
+      if (HALF_EVEN) {
+        P2 w;
+        w.v[0] = o2[0];
+        w.v[1] = o2[1];
+        *(P2*)(orow + half + j[u]) = w;
+      } else {
+        orow[half + j[u]] = o2[0];
+        if (two[u]) orow[half + j[u] + 1] = o2[1];
+      }
     }
   }
   __syncthreads();
@@ -577,7 +616,7 @@ extern "C" int mdg_rope_gather(const void* x, int dtype, int64_t ld_x, int64_t B
     vec >>= 1;
   // Packs of the rotate_half partners straight from / to memory when they are at least 4 bytes.  Measured on
   // [16, 2048, 32 x r] bf16, direct vs LDS route: r = 88 (8-byte packs) 84 vs 113 us; r = 76 (4-byte) 105 vs 99 us, a tie;
-  // r = 102 (2-byte) 199 vs 150 us.  MDG_ROPE_TILE=1 forces the LDS route (experiment knob of scripts/bench_kernels.py).
+  // r = 102 (2-byte) 199 vs 132 us.  MDG_ROPE_TILE=1 forces the LDS route (experiment knob of scripts/bench_kernels.py).
   if (vec > 1 && !getenv("MDG_ROPE_TILE")) {
     const dim3 grid((unsigned)(N_XCD * n_kv), (unsigned)tiles8, (unsigned)a.chunks);
     if (dtype == MDG_BF16) MDG_HIP(launch_rope_vec<MDG_BF16>(a, vec, hpt, grid, st));
