@@ -652,3 +652,41 @@ def test_slice_dims_methods_swap_modules_in_place(dev):
     ad.slice_vo_dims(0, [torch.randn(6, d, device=dev)] * 4, [torch.randn(d, 6, device=dev)] * 4, bias=True)
     assert blk.self_attn.v_proj.weight.shape == (24, d) and blk.self_attn.v_proj.bias is None
     assert blk.self_attn.out_proj.weight.shape == (d, 24) and torch.equal(blk.self_attn.out_proj.bias, old_o_bias)
+
+
+def test_run_modegpt_main_on_a_local_fp16_opt_checkpoint(dev, tmp_path, monkeypatch):
+    """BASELINE config #1's plumbing (OPT, fp16 checkpoint, 20 % compression) through the driver: fp16 weights are
+    widened exactly for the factorisations (w_dtype = f64 route), the OPT adapter's statistics (ReLU(fc1), per-head q/k),
+    the checkpoint with `ffn_dim = -1` reloads through OPTRebuild.py, and the compressed perplexity is finite."""
+    transformers = pytest.importorskip("transformers")
+    tokenizers = pytest.importorskip("tokenizers")
+    import json
+    from modegpt_amd import run_modegpt
+    from modegpt_amd.adapters.CompressionConfig import CompressionConfig
+
+    vocab = {f"w{i}": i for i in range(208)}
+    vocab.update({"<unk>": 208, "<s>": 209, "</s>": 210})
+    tok = tokenizers.Tokenizer(tokenizers.models.WordLevel(vocab, unk_token="<unk>"))
+    tok.pre_tokenizer = tokenizers.pre_tokenizers.Whitespace()
+    fast = transformers.PreTrainedTokenizerFast(tokenizer_object=tok, unk_token="<unk>", bos_token="<s>", eos_token="</s>",
+                                                pad_token="</s>")
+    torch.manual_seed(0)
+    cfg = transformers.OPTConfig(hidden_size=128, ffn_dim=320, num_hidden_layers=2, num_attention_heads=4, vocab_size=211,
+                                 max_position_embeddings=64, word_embed_proj_dim=128, init_std=0.15)
+    src = tmp_path / "opt_fp16"
+    transformers.OPTForCausalLM(cfg).to(torch.float16).save_pretrained(src)
+    fast.save_pretrained(src)
+    assert json.load(open(src / "config.json")).get("dtype", json.load(open(src / "config.json")).get("torch_dtype")) == "float16"
+    monkeypatch.chdir(tmp_path)
+    conf = CompressionConfig(model=str(src), output_dir=str(tmp_path / "out"), temp_storage_dir=str(tmp_path / "out" / "layers"),
+                             dataset="synthetic", order="mlp,qk,vo", calib_size=8, calibs_batch_size=4,
+                             compression_ratio=0.2, note="pytest-opt")
+    ppl = run_modegpt.main(config=conf)
+    assert ppl is not None and ppl == ppl and 1.0 < ppl < 1e9
+    out = tmp_path / "out" / "model"
+    c = json.load(open(out / "config.json"))
+    assert c["auto_map"]["AutoModelForCausalLM"] == "OPTRebuild.OPTForCausalLM" and c["ffn_dim"] == -1
+    assert len(c["qk_ranks"]) == 2 and len(c["vo_ranks"]) == 2 and len(c["gate_ranks"]) == 2
+    assert (out / "OPTRebuild.py").exists()
+    art = torch.load(tmp_path / "out" / "layers" / "layer_0_mlp")
+    assert set(art) == {"up", "down"} and art["up"].dtype == torch.bfloat16
