@@ -72,6 +72,31 @@ def cov_accum(sigma: torch.Tensor, x: torch.Tensor, n_heads: int = 1, relu: bool
                                 sigma.data_ptr(), feat, feat * feat, wsp, nbytes, _stream(x)), "mdg_cov_accum")
 
 
+def cov_accum_i8(sigma: torch.Tensor, x: torch.Tensor) -> bool:
+    """sigma (lower triangle) += X^T X for one bf16 matrix through the int8 digit-plane kernel (csrc/cov_i8.hip).
+    Returns True when the int8 route ran, False when the per-column outlier test sent the batch to the fp64 kernel
+    (the result is valid either way).  Feature count must be a multiple of 128."""
+    _need_gpu(sigma, x)
+    lib = _lib.load()
+    if sigma.dtype != torch.float64 or not sigma.is_contiguous() or sigma.dim() != 2:
+        raise ValueError("sigma must be a contiguous 2-D float64 tensor")
+    if x.dtype != torch.bfloat16:
+        raise ValueError("cov_accum_i8 takes bf16 activations")
+    x2 = x.detach().reshape(-1, x.shape[-1])
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    n = sigma.shape[0]
+    if sigma.shape[1] != n or x2.shape[1] != n:
+        raise ValueError(f"shape mismatch: sigma {tuple(sigma.shape)}, x {tuple(x2.shape)}")
+    nbytes = lib.mdg_cov_accum_i8_ws_bytes(x2.shape[0], n)
+    ws, wsp = _ws(nbytes, x.device)
+    used = C.c_int(0)
+    with torch.cuda.device(x.device):
+        check(lib.mdg_cov_accum_i8(x2.data_ptr(), x2.shape[0], n, x2.stride(0), sigma.data_ptr(), sigma.stride(0), wsp, nbytes,
+                                   C.byref(used), _stream(x)), "mdg_cov_accum_i8")
+    return bool(used.value)
+
+
 def cov_accum_multi(items) -> None:
     """One launch for several covariance problems of the same calibration batch.  items: sequence of
     (sigma, x, n_heads), largest problem first.  Falls back to one cov_accum call per item when the fused kernel's

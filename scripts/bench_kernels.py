@@ -120,3 +120,16 @@ if "cov64" in which:
     H64 = H.double()
     t = timeit(lambda: ops.cov_accum(S, H64), n=3)
     print(f"cov mlp fp64 input {T}x{d_ff}: {t*1e3:.1f} ms  {fl/t/1e12:.1f} TF   (+ torch bf16->fp64 pre-pass {t0*1e3:.2f} ms)")
+if "covi8" in which:
+    H = acts(T, d_ff)
+    S8 = torch.zeros(d_ff, d_ff, dtype=F64, device=dev); S64 = torch.zeros_like(S8)
+    used = ops.cov_accum_i8(S8, H); ops.cov_accum(S64, H)
+    low = torch.tril(torch.ones(d_ff, d_ff, dtype=torch.bool, device=dev))
+    print(f"cov_accum_i8 used the int8 route: {used};  max |i8 - fp64| / max |sigma| = {((S8 - S64)[low].abs().max() / S64.abs().max()).item():.2e}")
+    t8 = timeit(lambda: ops.cov_accum_i8(S8, H), n=3)
+    t64 = timeit(lambda: ops.cov_accum(S64, H), n=3)
+    fl = T * d_ff * (d_ff + 1)
+    print(f"cov mlp {T}x{d_ff}: int8 digit planes {t8*1e3:.1f} ms ({fl/t8/1e12:.1f} fp64-SYRK-equivalent TF)   fp64 MFMA {t64*1e3:.1f} ms ({fl/t64/1e12:.1f} TF)")
+    X = acts(T, d); Sx = torch.zeros(d, d, dtype=F64, device=dev)
+    t8 = timeit(lambda: ops.cov_accum_i8(Sx, X), n=3); t64 = timeit(lambda: ops.cov_accum(Sx, X), n=3)
+    print(f"cov x   {T}x{d}: int8 digit planes {t8*1e3:.2f} ms   fp64 MFMA {t64*1e3:.2f} ms")

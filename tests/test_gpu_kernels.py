@@ -526,3 +526,72 @@ def test_rope_strided_input_and_errors(ops, dev):
         ops.rope_gather(wide[:, :, :n_h * 3], cos.to(dev), sin.to(dev), None, n_h, n_kv, hd)
     with pytest.raises(RuntimeError, match="CPU tensor"):
         ops.rope_gather(x.cpu(), cos, sin, mask, n_h, n_kv, hd)
+
+
+# ---------------------------------------------------------------- int8 digit-plane covariance
+@pytest.mark.parametrize("tokens,feat", [(777, 256), (4096, 128), (33, 384), (20000, 256)])
+def test_cov_i8_matches_the_fp64_oracle(ops, dev, tokens, feat):
+    """The error-free int8 route against the oracle's fp64 X^T X: 1e-12 of |sigma| (the route's own bound on such data is
+    ~1e-13), lower triangle; a second call accumulates; 20000 tokens cross the 16384-token int32 flush."""
+    gen = torch.Generator().manual_seed(tokens + feat)
+    X = acts(gen, tokens, feat)
+    ref = torch.zeros(feat, feat, dtype=F64)
+    O.cov_accum_tokens(ref, X)
+    S = torch.zeros(feat, feat, dtype=F64, device=dev)
+    assert ops.cov_accum_i8(S, X.to(dev)) is True
+    low = torch.tril(torch.ones(feat, feat, dtype=torch.bool))
+    err = ((S.cpu() - ref)[low].abs().max() / ref.abs().max()).item()
+    assert err < 1e-12, err
+    X2 = acts(gen, 200, feat)
+    O.cov_accum_tokens(ref, X2)
+    assert ops.cov_accum_i8(S, X2.to(dev)) is True
+    assert ((S.cpu() - ref)[low].abs().max() / ref.abs().max()).item() < 1e-12
+
+
+def test_cov_i8_agrees_with_the_fp64_kernel_and_is_deterministic(ops, dev):
+    gen = torch.Generator().manual_seed(5)
+    X = acts(gen, 5000, 512).to(dev)
+    S8 = torch.zeros(512, 512, dtype=F64, device=dev)
+    S8b = torch.zeros_like(S8)
+    S64 = torch.zeros_like(S8)
+    assert ops.cov_accum_i8(S8, X) and ops.cov_accum_i8(S8b, X)
+    ops.cov_accum(S64, X)
+    assert torch.equal(S8, S8b), "integer accumulation: bit-identical from run to run"
+    low = torch.tril(torch.ones(512, 512, dtype=torch.bool, device=dev))
+    assert ((S8 - S64)[low].abs().max() / S64.abs().max()).item() < 1e-12
+    ops.cov_finalize(S8, 1.0 / 5000)
+    assert torch.equal(S8, S8.T)
+
+
+def test_cov_i8_hands_outlier_columns_to_the_fp64_kernel(ops, dev):
+    """A column whose maximum towers over its typical magnitude (the massive-activation pattern) fails the per-column test:
+    the call reports the fp64 route and the result is the fp64 kernel's."""
+    gen = torch.Generator().manual_seed(6)
+    X = acts(gen, 3000, 256)
+    X[17, 40] = 3000.0
+    S = torch.zeros(256, 256, dtype=F64, device=dev)
+    S64 = torch.zeros_like(S)
+    assert ops.cov_accum_i8(S, X.to(dev)) is False
+    ops.cov_accum(S64, X.to(dev))
+    assert torch.equal(S, S64)
+
+
+def test_cov_i8_special_values_and_errors(ops, dev):
+    """Zeros, denormals, an all-zero column, tokens not a multiple of the k-step; wrong shapes are refused."""
+    gen = torch.Generator().manual_seed(8)
+    X = acts(gen, 100, 128)
+    X[:, 5] = 0
+    X[::3, 9] = torch.tensor(2.0 ** -130, dtype=torch.float32).to(torch.bfloat16)   # bf16 denormals
+    X[1::3, 9] = torch.tensor(-2.0 ** -128, dtype=torch.float32).to(torch.bfloat16)
+    X[2::3, 9] = 0
+    ref = torch.zeros(128, 128, dtype=F64)
+    O.cov_accum_tokens(ref, X)
+    S = torch.zeros(128, 128, dtype=F64, device=dev)
+    ops.cov_accum_i8(S, X.to(dev))
+    low = torch.tril(torch.ones(128, 128, dtype=torch.bool))
+    assert ((S.cpu() - ref)[low].abs().max() / ref.abs().max()).item() < 1e-12
+    assert S[9, 9].item() == ref[9, 9].item() != 0.0          # products of denormals are exact
+    with pytest.raises(RuntimeError, match="multiple of 128"):
+        ops.cov_accum_i8(torch.zeros(200, 200, dtype=F64, device=dev), acts(gen, 64, 200).to(dev))
+    with pytest.raises(ValueError):
+        ops.cov_accum_i8(S, X.float().to(dev))
