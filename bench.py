@@ -35,6 +35,7 @@ sys.path.insert(0, ROOT)
 from modegpt_amd import engine, ops, sharding  # noqa: E402
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X public fp64-matrix spec; bench also reports the measured issue rate
+INT8_MFMA_PEAK_TOPS = 5000.0  # dense int8 = 2x the bf16 rate per clock (MI355X_MICROARCH.md, matrix cores table)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -52,6 +53,15 @@ class LaunchTimer:
         e1.record()
         self.pairs.append((flops, e0, e1))
 
+    def run_i8(self, ops_count, sigma, x):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()      # materialise the HIP events; the library re-records them around its product kernel
+        e1.record()
+        planes = ops.cov_accum_i8(sigma, x, events=(e0, e1))
+        if planes:
+            self.pairs.append((ops_count * planes * (planes + 1) // 30, e0, e1))   # ops_count is quoted for 5 planes = 15 pairs
+
     def summary(self):
         torch.cuda.synchronize()
         ms = sum(a.elapsed_time(b) for _, a, b in self.pairs)
@@ -64,13 +74,18 @@ def step(shape, adapter, layer_idx, batches, keep, n_texts, timer=None):
     dev = batches[0]["h"].device
     covs = engine.new_covs(shape, dev)
     f, d, nh, nkv, hd = shape["d_ff"], shape["d"], shape["n_heads"], shape["n_kv_heads"], shape["head_dim"]
+    i8 = ops.COV_MODE == "i8" and shape["arch"] != "opt"
     for b in batches:
         t = b["h"].shape[0]
         if timer is None:
             engine.accumulate(covs, b, shape)
-        else:  # the same fused launch as engine.accumulate (all four hooks of the layer), bracketed by events
+        elif not i8:  # the same fused launch as engine.accumulate (all four hooks of the layer), bracketed by events
             flops = t * (f * (f + 1) + d * (d + 1) + (nh + nkv) * hd * (hd + 1))   # SYRK count of the four problems
             timer.run(flops, lambda: engine.accumulate(covs, b, shape))
+        else:  # engine.accumulate's i8 route spelled out, so that the dominant kernel (i8_syrk_kernel on sigma_mlp) can be
+            #    timed alone: the library records the two events right around that launch
+            timer.run_i8(15 * t * f * (f + 1), covs["mlp"], b["h"])     # 15 plane-pair products, SYRK count each
+            ops.cov_accum_multi([(covs["x"], b["x"], 1), (covs["q"], b["q"], nh), (covs["k"], b["k"], nkv)], mode="i8")
     engine.finalize(covs, n_texts)
     tensors, mask = engine.compress_layer(adapter, layer_idx, covs, keep)
     return tensors, mask, covs
@@ -158,8 +173,13 @@ def main():
     ap.add_argument("--batch_size", type=int, default=16, help="samples of 2048 tokens per batch")
     ap.add_argument("--keep", type=float, default=0.7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cov-mode", default=None, choices=["f64", "i8"],
+                    help="matrix cores for sigma_mlp / sigma_x: f64 (v_mfma_f64) or i8 (exact digit planes on v_mfma_i32_i8); "
+                         "default: ops.COV_MODE (env MODEGPT_COV_MODE, else f64)")
     a = ap.parse_args()
 
+    if a.cov_mode:
+        ops.COV_MODE = a.cov_mode
     rank, world = sharding.init_from_env()
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
@@ -202,11 +222,12 @@ def main():
     assert len(gathered) == world * a.steps
 
     n_launch, flops, ms = timer.summary()
+    i8 = ops.COV_MODE == "i8" and shape["arch"] != "opt" and n_launch > 0
     achieved = flops / (ms * 1e-3) / 1e12
     # HBM bytes per launch come from a separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run of the same kernel on the
     # same four launch shapes (PMC passes cannot ride along a timed run); only valid for the default workload.
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_cov_hbm_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r01_cov_i8_hbm_traffic.json" if i8 else "r01_cov_hbm_traffic.json")
     if os.path.exists(tpath) and a.model == "llama-3-8b" and a.batch_size == 16:
         with open(tpath) as f:
             traffic = json.load(f)["hbm_bytes_per_launch"]
@@ -214,7 +235,8 @@ def main():
         "metric": "transformer layers compressed/sec (covariance+decomp+rebuild), Llama-3-8B @30%",
         "value": world * a.steps / elapsed, "unit": "layers/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
+        "dtype": "i8 digit planes of the bf16 activations (int32 accumulate, folded in f64; exact)" if i8 else "f64",
+        "data": "synthetic",
         "config": {"workload": f"{a.model} shapes, {n_texts} calibration samples x 2048 tokens in {a.batches} batches "
                                f"of {a.batch_size}, keep ratio {a.keep} (compression {1 - a.keep:.0%}), ridges "
                                f"{ridges}, one layer per step per GPU", "layers_per_gpu": a.steps,
@@ -228,6 +250,22 @@ def main():
                      "avg_launch_ms": ms / n_launch, "flop_per_launch": flops / n_launch,
                      "flop_count": "SYRK: tokens * sum over the four problems of n * (n + 1) per launch"},
     }
+    if i8:
+        f = shape["d_ff"]
+        out["roofline"] = {
+            "bound": "mfma", "achieved": achieved, "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s",
+            "frac": achieved / INT8_MFMA_PEAK_TOPS, "traffic": traffic,
+            "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), profiles/r01_cov_i8_hbm_traffic.json",
+            "kernel": "i8_syrk_kernel on sigma_mlp (v_mfma_i32_32x32x32_i8; the 15 (5 planes) or 21 (6 planes) digit-plane "
+                      "pair products of one calibration batch per launch, timed alone by events the library records around it)",
+            "launches": n_launch, "avg_launch_ms": ms / n_launch, "op_per_launch": flops / n_launch,
+            "op_count": "plane pairs (15 or 21, see routes) x tokens x n (n + 1): the SYRK count of each product, 2 ops per multiply-add",
+            "fp64_syrk_equivalent_tflops": sum(ev0.elapsed_time(ev1) for _, ev0, ev1 in timer.pairs) and
+            (n_launch * batches[0]["h"].shape[0] * f * (f + 1)) / (ms * 1e-3) / 1e12,
+            "routes": dict(ops.I8_STATS),
+            "note": "sigma_x goes through the same kernel; sigma_q / sigma_k (1.4 % of the work) and any batch that fails the "
+                    "per-column outlier test go through the v_mfma_f64 kernel (--cov-mode f64 runs everything there: "
+                    "0.909 of the fp64 peak, DESIGN.md section 7)"}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         li, tensors, mask, covs = last
         gpu_out = dict(tensors)
@@ -237,6 +275,21 @@ def main():
         sc = ops.ridge_scores(covs["mlp"], _fl32(ridges["nystrom_ridge"]))
         gpu_out["mlp_idx"] = ops.select_smallest_sorted(sc, int(shape["d_ff"] * a.keep))
         out["roofline"]["measured_mfma_f64_issue_rate_tflops"] = ops.probe_mfma_f64(4096)
+        if i8:  # the same sigma_mlp batch through the v_mfma_f64 kernel, for the record
+            scratch = torch.zeros_like(covs["mlp"])
+            h = batches[0]["h"]
+            ops.cov_accum(scratch, h)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ops.cov_accum(scratch, h)
+            ops.cov_accum(scratch, h)
+            e1.record()
+            torch.cuda.synchronize()
+            tf = 2 * h.shape[0] * shape["d_ff"] * (shape["d_ff"] + 1) / (e0.elapsed_time(e1) * 1e-3) / 1e12
+            out["roofline"]["f64_route"] = {"kernel": "cov_accum_kernel (v_mfma_f64_16x16x4_f64) on the same sigma_mlp batch",
+                                            "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                            "frac": tf / FP64_MFMA_PEAK_TFLOPS, "avg_launch_ms": e0.elapsed_time(e1) / 2}
+            del scratch
         out["cpu_baseline"] = cpu_baseline(shape, layers[li], covs, 2048, n_texts * 2048, a.keep, ridges, gpu_out)
         if shape["arch"] != "opt":
             out["next_rows"] = {"rope_gather": rope_gather_roofline(shape, a.keep, dev)}

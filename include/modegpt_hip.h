@@ -77,15 +77,18 @@ typedef struct {
 size_t mdg_cov_accum_multi_ws_bytes(int n, const mdg_cov_problem* problems, int dtype);
 int mdg_cov_accum_multi(int n, const mdg_cov_problem* problems, int dtype, void* ws, size_t ws_bytes, void* stream);
 /* The same accumulation for ONE bf16 matrix through the int8 matrix cores, exactly (csrc/cov_i8.hip): every bf16 value is
- * split into five balanced base-256 digits against a per-column power-of-two scale, the 15 digit-plane products with
- * s + t <= 4 are formed by v_mfma_i32_32x32x32_i8 with exact int32 accumulation and folded into sigma in fp64 every 16384
- * tokens.  Agrees with mdg_cov_accum to ~1e-13 of |sigma| on columns that are not dominated by outliers; each call tests
- * that (per column, at least 1/16 of the elements within 5 binades of the column maximum) and otherwise runs mdg_cov_accum
- * on the batch itself.  *used_i8 (host, optional) reports which route ran.  n_feat must be a multiple of 128.
- * SYNCHRONISES once (the route decision).  ws: mdg_cov_accum_i8_ws_bytes (about 5 bytes per element of x). */
+ * split into six balanced base-256 digits against a per-column power-of-two scale; the digit-plane products with
+ * s + t < P are formed by v_mfma_i32_32x32x32_i8 with exact int32 accumulation and folded into sigma in fp64 every 16384
+ * tokens.  Each call measures, per column, the share of elements more than 10 binades below the column maximum and picks
+ * P = 5 (share <= 1/64 everywhere: within ~2e-13 of sigma's scale), P = 6 (<= 1/8: ~3e-14 on SiLU-gated activations) or
+ * runs mdg_cov_accum on the batch itself (heavier tails, columns dominated by a few massive activations).
+ * *used_i8 (host, optional) reports the route: 5, 6, or 0 for the fp64 kernel.  n_feat must be a multiple of 128.
+ * SYNCHRONISES once (the route decision).  ws: mdg_cov_accum_i8_ws_bytes (about 6 bytes per element of x).
+ * ev_start / ev_stop: optional hipEvent_t recorded on `stream` right before / after the product kernel (bench.py times the
+ * dominant kernel alone with them); NULL otherwise. */
 size_t mdg_cov_accum_i8_ws_bytes(int64_t n_tokens, int64_t n_feat);
 int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat, int64_t ld, double* sigma, int64_t ld_sigma, void* ws,
-                     size_t ws_bytes, int* used_i8, void* stream);
+                     size_t ws_bytes, int* used_i8, void* ev_start, void* ev_stop, void* stream);
 /* sigma[b] <- scale * sigma[b] on the lower triangle, mirrored into the upper.  scale = 1/(n_texts*2048)
  * reproduces calibration.py:141-146. */
 int mdg_cov_finalize(double* sigma, int64_t n, int64_t batch, int64_t ld_sigma, int64_t sigma_batch_stride,

@@ -37,7 +37,7 @@ SIGNATURES = {
     "mdg_cov_accum_ws_bytes": (_sz, [_i64, _i64, _i64]),
     "mdg_cov_accum": (_i32, [_ptr, _i32, _i64, _i64, _i64, _i64, _i32, _ptr, _i64, _i64, _ptr, _sz, _ptr]),
     "mdg_cov_accum_i8_ws_bytes": (_sz, [_i64, _i64]),
-    "mdg_cov_accum_i8": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _i64, _ptr, _sz, C.POINTER(_i32), _ptr]),
+    "mdg_cov_accum_i8": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _i64, _ptr, _sz, C.POINTER(_i32), _ptr, _ptr, _ptr]),
     "mdg_cov_accum_multi_ws_bytes": (_sz, [_i32, C.POINTER(CovProblem), _i32]),
     "mdg_cov_accum_multi": (_i32, [_i32, C.POINTER(CovProblem), _i32, _ptr, _sz, _ptr]),
     "mdg_cov_finalize": (_i32, [_ptr, _i64, _i64, _i64, _i64, _f64, _ptr]),

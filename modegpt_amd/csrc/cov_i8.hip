@@ -1,26 +1,30 @@
 // sigma += X^T X through the int8 matrix cores, exactly: an error-free split of the bf16 activations into digit planes.
 //
-// A bf16 value is a signed 8-bit significand times a power of two.  Against a per-column scale 2^(E_j - 134), E_j the largest
-// exponent in column j of this call, it is a 40-bit fixed-point integer N = sig << (30 - (E_j - e)): five balanced base-256
-// digits d_0..d_4 in [-128, 127] (|d_0| <= 64).  Then
-//     x_ti x_tj = 2^(E_i + E_j - 328) * sum_{s,t} d_s(t,i) d_t(t,j) 256^(8 - s - t)
-// and sum over tokens of d_s d_t is an int8 MFMA product with exact int32 accumulation.  Products with s + t >= 5 carry less
-// than 2^-38 of (column maximum)^2 per token and are dropped, 15 plane pairs in 5 scale classes remain; elements more than
-// 30 bits below their column's maximum are rounded at 2^-40 of it.  On data whose columns are not dominated by outliers this
-// is ~1e-13 of |sigma| after 10^6 tokens (the fp64 route's own rounding is of that order); a column whose maximum towers over
-// its typical magnitude loses accuracy, so every call checks a per-column statistic (the share of elements within 2^-5 of the
-// column maximum's binade) and hands the batch to the fp64 kernel when it fails.  fp64 reference semantics: src/adapters/
-// LlamaAdapter.py:127-147 (sigma += X^T X with X upcast to fp64).
+// A bf16 value is a signed 8-bit significand times a power of two.  Against a per-column scale 2^(E_j - 172), E_j the largest
+// exponent in column j of this call, it is a 48-bit fixed-point integer N = sig << (38 - (E_j - e)): six balanced base-256
+// digits d_0..d_5 in [-128, 127] (|d_0| <= 64).  Then
+//     x_ti x_tj = 2^(E_i + E_j - 344) * sum_{s,t} d_s(t,i) d_t(t,j) 256^(10 - s - t)
+// and sum over tokens of d_s d_t is an int8 MFMA product with exact int32 accumulation.  Keeping the plane pairs with
+// s + t < P (P = 5: 15 pairs, P = 6: 21 pairs) drops terms below 2^-8P of (column maximum)^2 per token; what that costs
+// depends on how far below their column's maximum the elements sit, so every call measures it -- per column, the share of
+// nonzero elements more than 10 binades below the maximum ("deep") -- and picks the route (measured against the exact product,
+// scripts/probes/digit_plane_sim.py: Gaussian / Laplace / ReLU columns, deep share < 1/64: P = 5 is within 2e-13 of sigma's
+// scale; SiLU-gated products, share ~0.1: P = 5 gives 3e-12, P = 6 gives 3e-14; cubed Gaussians, share ~0.5, or a column
+// dominated by a few massive activations, share ~1: beyond both):
+//     every column's deep share <= 1/64  ->  P = 5        <= 1/8  ->  P = 6        else  ->  the fp64 kernel (mdg_cov_accum)
+// fp64 reference semantics: src/adapters/LlamaAdapter.py:127-147 (sigma += X^T X with X upcast to fp64).
 //
-// Three kernels per call:
+// Kernels per call:
 //   i8_colmax_kernel   E_j = max exponent per column
-//   i8_split_kernel    digit planes, written in the blocked layout the product kernel streams: [plane][32-row group][k-step]
-//                      [k-half][row][16 tokens] -- each 1 KB piece is one contiguous global_load_lds_dwordx4 per wave
-//   i8_syrk_kernel     128 x 64 output tiles of the lower triangle; 4 waves, wave tile 64 x 32 (160 int32 accumulators: the
-//                      64 x 64 wave tile's 320 exceed the 256 AGPRs); per k-step of 32 tokens ONE set of 15 fragment reads
-//                      feeds all 30 MFMAs of the 15 plane pairs (3x less LDS traffic per MFMA than 15 separate GEMMs, which is
-//                      what lets it pass the library's int8 rate); LDS ring of 4 stages filled by LDS-DMA three stages ahead,
-//                      one raw barrier per stage; every 16384 tokens the int32 classes are folded into sigma in fp64.
+//   i8_split_kernel    six digit planes, written in the blocked layout the product kernel streams: [plane][32-row group]
+//                      [k-step][k-half][row][16 tokens] -- each 1 KB piece is one contiguous global_load_lds_dwordx4 per wave;
+//                      counts the deep elements per column on the way
+//   i8_syrk_kernel<P>  128 x 64 output tiles of the lower triangle; 4 waves, wave tile 64 x 32 (32 P int32 accumulators; a
+//                      64 x 64 wave tile's 320 would exceed the 256 AGPRs); per k-step of 32 tokens ONE set of 3 P fragment
+//                      reads feeds all P (P + 1) MFMAs of the plane pairs (3x less LDS traffic per MFMA than separate GEMMs,
+//                      which is what lets it pass the library's int8 rate); LDS ring of 4 stages filled by LDS-DMA three
+//                      stages ahead, one raw barrier per stage; every 16384 tokens the int32 classes are folded into sigma
+//                      in fp64.  The P = 5 variant reads the top five of the six planes (a balanced-digit truncation).
 #include "common.hpp"
 
 namespace mdg {
@@ -29,14 +33,14 @@ namespace {
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int NP = 5;            // digit planes
+constexpr int NP = 6;            // digit planes written by the split pass; the product kernel uses the top 5 or all 6
 constexpr int TI = 128, TJ = 64; // output tile: TI rows of I x TJ rows of J
 constexpr int KS = 32;           // tokens per k-step (one v_mfma_i32_32x32x32_i8)
 constexpr int PA = TI * KS, PB = TJ * KS;
-constexpr int STAGE_BYTES = NP * (PA + PB);  // 30 KB
 constexpr int RING = 4;
-constexpr int FLUSH_STEPS = 512;  // 16384 tokens: (k + 1) * 2^14 * 16384 < 2^31 for every class k <= 4
-constexpr int NEAR_BINADES = 5;   // an element is "near the column maximum" when its exponent is within this many binades
+constexpr int FLUSH_STEPS = 512;  // 16384 tokens: (k + 1) * 2^14 * 16384 < 2^31 for every class k <= 5
+constexpr int TOP_SHIFT = 8 * NP - 10;  // 38: the column maximum's significand sits below bit 46 of the 48-bit integer
+constexpr int DEEP_BINADES = 10;  // an element is "deep" when its exponent is at least this far below the column maximum
 
 // bf16 bits -> (signed 9-bit significand, effective exponent >= 1);  value = sig * 2^(ee - 134)
 __device__ __forceinline__ void bf16_parts(unsigned b, int& sig, int& ee) {
@@ -65,16 +69,16 @@ __global__ __launch_bounds__(256) void i8_colmax_kernel(const bf16_t* x, int64_t
 // k-step.  A workgroup walks SPLIT_STEPS k-steps of its row group, 8 at a time.
 constexpr int SPLIT_STEPS = 64;
 __global__ __launch_bounds__(256) void i8_split_kernel(const bf16_t* x, int64_t ld, int64_t T, int n, int nk, const int* emax,
-                                                       signed char* planes, int* near_cnt) {
-  __shared__ int near_lds[32];
+                                                       signed char* planes, int* deep_cnt) {
+  __shared__ int deep_lds[32];
   const int r = threadIdx.x & 31;
   const int G = blockIdx.x;
   const int j = G * 32 + r;
   const int E = emax[j];
   const int64_t groups = n / 32;
-  if (threadIdx.x < 32) near_lds[threadIdx.x] = 0;
+  if (threadIdx.x < 32) deep_lds[threadIdx.x] = 0;
   __syncthreads();
-  int near = 0;
+  int deep = 0;
   for (int kq = 0; kq < SPLIT_STEPS; kq += 8) {
     const int kt = blockIdx.y * SPLIT_STEPS + kq + (threadIdx.x >> 5);
     if (kt >= nk) break;
@@ -87,12 +91,12 @@ __global__ __launch_bounds__(256) void i8_split_kernel(const bf16_t* x, int64_t 
         int sig = 0, ee = 1;
         if (t < T) bf16_parts(x[t * ld + j], sig, ee);
         const int sh = E - ee;
-        near += (sig != 0 && sh <= NEAR_BINADES);
+        deep += (sig != 0 && sh >= DEEP_BINADES);
         long long N;
-        if (sh <= 30) {
-          N = (long long)sig << (30 - sh);
+        if (sh <= TOP_SHIFT) {
+          N = (long long)sig << (TOP_SHIFT - sh);
         } else {
-          const int dn = sh - 30;  // round the magnitude half up; nothing survives a shift by more than 9
+          const int dn = sh - TOP_SHIFT;  // round the magnitude half up; nothing survives a shift by more than 9
           const int mag = dn > 9 ? 0 : ((sig < 0 ? -sig : sig) + (1 << (dn - 1))) >> dn;
           N = sig < 0 ? -mag : mag;
         }
@@ -111,15 +115,19 @@ __global__ __launch_bounds__(256) void i8_split_kernel(const bf16_t* x, int64_t 
       }
     }
   }
-  if (near) atomicAdd(&near_lds[r], near);
+  if (deep) atomicAdd(&deep_lds[r], deep);
   __syncthreads();
-  if (threadIdx.x < 32 && near_lds[threadIdx.x]) atomicAdd(near_cnt + G * 32 + threadIdx.x, near_lds[threadIdx.x]);
+  if (threadIdx.x < 32 && deep_lds[threadIdx.x]) atomicAdd(deep_cnt + G * 32 + threadIdx.x, deep_lds[threadIdx.x]);
 }
 
-// flag[0] = 1 when some column has fewer than T / 16 elements near its maximum (an outlier-dominated column)
-__global__ __launch_bounds__(256) void i8_crest_kernel(const int* near_cnt, int n, int64_t T, int* flag) {
+// flag bit 0: some column has more than T / 64 deep elements (five planes are not enough); bit 1: more than T / 8 (six
+// are not either)
+__global__ __launch_bounds__(256) void i8_depth_kernel(const int* deep_cnt, int n, int64_t T, int* flag) {
   const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j < n && (int64_t)near_cnt[j] * 16 < T) atomicOr(flag, 1);
+  if (j >= n) return;
+  const int64_t c = deep_cnt[j];
+  const int bits = (c * 64 > T ? 1 : 0) | (c * 8 > T ? 2 : 0);
+  if (bits) atomicOr(flag, bits);
 }
 
 struct SyrkArgs {
@@ -135,7 +143,11 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
                                    0, 0);
 }
 
+template <int P>  // planes used: 5 or 6
 __global__ __launch_bounds__(256, 1) void i8_syrk_kernel(SyrkArgs a) {
+  constexpr int STAGE_BYTES = P * (PA + PB);       // 30 / 36 KB
+  constexpr int PIECES = 6 * P;                    // 1 KB pieces per stage
+  constexpr int PER_WAVE_MIN = PIECES / 4;         // every wave issues at least this many LDS-DMA loads per stage
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   // tile t of the lower region: bi = 128-row block, bj = 64-row block with bj <= 2 bi + 1; bi (bi + 1) tiles precede row bi
   const int tile = blockIdx.x;
@@ -148,33 +160,33 @@ __global__ __launch_bounds__(256, 1) void i8_syrk_kernel(SyrkArgs a) {
   const int64_t groups = a.n / 32;
   const int nk = a.nk;
 
-  // staging: 30 pieces of 1 KB per stage (A: 5 planes x 4 row groups, B: 5 planes x 2); wave w issues pieces w, w + 4, ...
+  // staging: 6 P pieces of 1 KB per stage (A: P planes x 4 row groups, B: P planes x 2); wave w issues pieces w, w + 4, ...
   auto issue_stage = [&](int kt, int buf) {
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
+    for (int q = 0; q < (PIECES + 3) / 4; q++) {
       const int p = wave + 4 * q;
-      if (p < 30) {
-        const bool isA = p < 20;
-        const int pp = isA ? p : p - 20;
+      if (p < PIECES) {
+        const bool isA = p < 4 * P;
+        const int pp = isA ? p : p - 4 * P;
         const int s = isA ? pp >> 2 : pp >> 1, g = isA ? pp & 3 : pp & 1;
         const int64_t G = (isA ? bi * (TI / 32) : bj * (TJ / 32)) + g;
         const signed char* src = a.planes + ((s * groups + G) * (int64_t)nk + kt) * 1024 + lane * 16;
-        unsigned char* dst = lds + buf * STAGE_BYTES + (isA ? s * PA : NP * PA + s * PB) + g * 1024;
+        unsigned char* dst = lds + buf * STAGE_BYTES + (isA ? s * PA : P * PA + s * PB) + g * 1024;
         glds16(src, dst);
       }
     }
   };
 
-  i32x16 acc[NP][2];
+  i32x16 acc[P][2];
 #pragma unroll
-  for (int k = 0; k < NP; k++)
+  for (int k = 0; k < P; k++)
 #pragma unroll
     for (int b = 0; b < 2; b++) acc[k][b] = (i32x16)0;
 
-  // sigma[i][j] += 2^(E_i + E_j - 328) * sum_k acc_k 256^(8 - k)  =  (sum_k acc_k 2^(64 - 8k)) * 2^(E_i - 164) * 2^(E_j - 164)
+  // sigma[i][j] += 2^(E_i + E_j - 344) * sum_k acc_k 256^(10 - k)  =  (sum_k acc_k 2^(80 - 8k)) * 2^(E_i - 172) * 2^(E_j - 172)
   auto flush = [&]() {
     const int col = bj * TJ + wc * 32 + (lane & 31);
-    const double sc_j = ldexp(1.0, a.emax[col] - 164);
+    const double sc_j = ldexp(1.0, a.emax[col] - 172);
     // all 32 read-modify-writes of a lane: loads first (independent, in flight together), then the arithmetic and the stores;
     // written as `*p += v` one by one the compiler must keep them in order and every element pays a full memory round trip
     double old[2][16];
@@ -194,11 +206,11 @@ __global__ __launch_bounds__(256, 1) void i8_syrk_kernel(SyrkArgs a) {
         const int row = bi * TI + wr * 64 + b * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
         double v = 0.;
 #pragma unroll
-        for (int k = NP - 1; k >= 0; k--) v += ldexp((double)acc[k][b][reg], 64 - 8 * k);
-        if (col <= row) a.sigma[(int64_t)row * a.ld_sigma + col] = old[b][reg] + v * sc_j * ldexp(1.0, er[b][reg] - 164);
+        for (int k = P - 1; k >= 0; k--) v += ldexp((double)acc[k][b][reg], 80 - 8 * k);
+        if (col <= row) a.sigma[(int64_t)row * a.ld_sigma + col] = old[b][reg] + v * sc_j * ldexp(1.0, er[b][reg] - 172);
       }
 #pragma unroll
-    for (int k = 0; k < NP; k++)
+    for (int k = 0; k < P; k++)
 #pragma unroll
       for (int b = 0; b < 2; b++) acc[k][b] = (i32x16)0;
     // the stores above share the VM counter with the LDS-DMA loads and may retire out of order with them: drain, so that
@@ -213,25 +225,25 @@ __global__ __launch_bounds__(256, 1) void i8_syrk_kernel(SyrkArgs a) {
     const int k1 = min(nk, k0 + FLUSH_STEPS);
     for (int kt = k0; kt < k1; kt++) {
       const int buf = kt % RING;
-      // waves 0,1 issue 8 LDS-DMA loads per stage, waves 2,3 issue 7; stages kt+1 and kt+2 may stay in flight: "at most 14
-      // outstanding" retires stage kt on every wave; the tail drains everything
-      if (kt + RING - 2 < nk) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+      // stages kt+1 and kt+2 may stay in flight: "at most 2 x (loads a wave issues per stage, rounded down)" outstanding
+      // retires stage kt on every wave (P = 5: waves issue 8, 8, 7, 7 -> 14; P = 6: 9 each -> 18); the tail drains everything
+      if (kt + RING - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_WAVE_MIN) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if (kt + RING - 1 < nk) issue_stage(kt + RING - 1, (kt + RING - 1) % RING);
       const unsigned char* base = lds + buf * STAGE_BYTES;
       const int r = lane & 31, h = lane >> 5;
-      i32x4 fa[NP][2], fb[NP];
+      i32x4 fa[P][2], fb[P];
 #pragma unroll
-      for (int s = 0; s < NP; s++) {
+      for (int s = 0; s < P; s++) {
 #pragma unroll
         for (int b = 0; b < 2; b++) fa[s][b] = *(const i32x4*)(base + s * PA + (wr * 2 + b) * 1024 + h * 512 + r * 16);
-        fb[s] = *(const i32x4*)(base + NP * PA + s * PB + wc * 1024 + h * 512 + r * 16);
+        fb[s] = *(const i32x4*)(base + P * PA + s * PB + wc * 1024 + h * 512 + r * 16);
       }
 #pragma unroll
-      for (int s = 0; s < NP; s++)
+      for (int s = 0; s < P; s++)
 #pragma unroll
-        for (int t = 0; t < NP - s; t++)
+        for (int t = 0; t < P - s; t++)
 #pragma unroll
           for (int b = 0; b < 2; b++)
             acc[s + t][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s][b], fb[t], acc[s + t][b], 0, 0, 0);
@@ -254,7 +266,7 @@ extern "C" size_t mdg_cov_accum_i8_ws_bytes(int64_t n_tokens, int64_t n_feat) {
 }
 
 extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat, int64_t ld, double* sigma, int64_t ld_sigma,
-                                void* ws, size_t ws_bytes, int* used_i8, void* stream) {
+                                void* ws, size_t ws_bytes, int* used_i8, void* ev_start, void* ev_stop, void* stream) {
   MDG_CLEAR();
   if (used_i8) *used_i8 = 0;
   MDG_CHECK_ARG(n_tokens >= 0 && n_feat > 0, "mdg_cov_accum_i8: bad sizes (tokens=%lld feat=%lld)", (long long)n_tokens,
@@ -272,8 +284,8 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
   const int nk = (int)ceil_div(n_tokens, KS);
   signed char* planes = (signed char*)ws;
   int* emax = (int*)((char*)ws + align_up(planes_bytes(n_tokens, n_feat), 256));
-  int* near_cnt = emax + n;
-  int* flag = near_cnt + n;
+  int* deep_cnt = emax + n;
+  int* flag = deep_cnt + n;
   void* fb_ws = (char*)emax + align_up((size_t)(2 * n + 4) * sizeof(int), 256);
   MDG_HIP(hipMemsetAsync(emax, 0, (size_t)(2 * n + 4) * sizeof(int), st));
   {
@@ -282,22 +294,28 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
     hipLaunchKernelGGL(i8_colmax_kernel, grid, dim3(256), 0, st, (const bf16_t*)x, ld, n_tokens, n, rows_per_block, emax);
   }
   hipLaunchKernelGGL(i8_split_kernel, dim3((unsigned)(n / 32), (unsigned)ceil_div(nk, SPLIT_STEPS)), dim3(256), 0, st, (const bf16_t*)x, ld,
-                     n_tokens, n, nk, emax, planes, near_cnt);
-  hipLaunchKernelGGL(i8_crest_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, near_cnt, n, n_tokens, flag);
+                     n_tokens, n, nk, emax, planes, deep_cnt);
+  hipLaunchKernelGGL(i8_depth_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, deep_cnt, n, n_tokens, flag);
   MDG_LAUNCH_CHECK();
-  int outlier = 0;
-  MDG_HIP(hipMemcpyAsync(&outlier, flag, sizeof(int), hipMemcpyDeviceToHost, st));
+  int depth = 0;
+  MDG_HIP(hipMemcpyAsync(&depth, flag, sizeof(int), hipMemcpyDeviceToHost, st));
   MDG_HIP(hipStreamSynchronize(st));
-  if (outlier)  // a column dominated by outliers: five planes do not carry fp64-level accuracy there
+  if (depth & 2)  // some column is mostly far below its maximum: six planes do not carry fp64-level accuracy there
     return mdg_cov_accum(x, MDG_BF16, n_tokens, n_feat, 1, ld, 0, sigma, ld_sigma, 0, fb_ws,
                          ws_bytes - (size_t)((char*)fb_ws - (char*)ws), stream);
   SyrkArgs a;
   a.planes = planes; a.emax = emax; a.sigma = sigma; a.ld_sigma = ld_sigma; a.n = n; a.nk = nk;
   const int rb = n / TI;
-  const size_t lds = (size_t)RING * STAGE_BYTES;
-  MDG_HIP(hipFuncSetAttribute((const void*)i8_syrk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(i8_syrk_kernel, dim3((unsigned)(rb * (rb + 1))), dim3(256), lds, st, a);
+  const int planes_used = (depth & 1) ? 6 : 5;
+  const size_t lds = (size_t)RING * planes_used * (PA + PB);
+  const dim3 grid((unsigned)(rb * (rb + 1)));
+  if (planes_used == 6) MDG_HIP(hipFuncSetAttribute((const void*)i8_syrk_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  else MDG_HIP(hipFuncSetAttribute((const void*)i8_syrk_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (ev_start) MDG_HIP(hipEventRecord((hipEvent_t)ev_start, st));
+  if (planes_used == 6) hipLaunchKernelGGL(i8_syrk_kernel<6>, grid, dim3(256), lds, st, a);
+  else hipLaunchKernelGGL(i8_syrk_kernel<5>, grid, dim3(256), lds, st, a);
   MDG_LAUNCH_CHECK();
-  if (used_i8) *used_i8 = 1;
+  if (ev_stop) MDG_HIP(hipEventRecord((hipEvent_t)ev_stop, st));
+  if (used_i8) *used_i8 = planes_used;
   return MDG_OK;
 }

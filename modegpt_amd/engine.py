@@ -67,16 +67,17 @@ def new_covs(shape: dict, device) -> Dict[str, torch.Tensor]:
     return {"mlp": z(f, f), "x": z(d, d), "q": z(nh, hd, hd), "k": z(nkv, hd, hd)}
 
 
-def accumulate(covs: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], shape: dict) -> None:
+def accumulate(covs: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], shape: dict, mode: Optional[str] = None) -> None:
     """What the four hooks of one layer do for one calibration batch: one fused launch (the Llama / Qwen3 adapters
-    defer sigma_x / sigma_q / sigma_k to the layer's last hook for exactly this); OPT's ReLU statistic stays separate."""
+    defer sigma_x / sigma_q / sigma_k to the layer's last hook for exactly this); OPT's ReLU statistic stays separate.
+    mode: None = ops.COV_MODE; "i8" routes sigma_mlp and sigma_x through the int8 digit-plane kernel."""
     if shape["arch"] == "opt":
         ops.cov_accum(covs["mlp"], batch["h"], relu=True)
         ops.cov_accum_multi([(covs["x"], batch["x"], 1), (covs["q"], batch["q"], shape["n_heads"]),
-                             (covs["k"], batch["k"], shape["n_kv_heads"])])
+                             (covs["k"], batch["k"], shape["n_kv_heads"])], mode=mode)
         return
     ops.cov_accum_multi([(covs["mlp"], batch["h"], 1), (covs["x"], batch["x"], 1),
-                         (covs["q"], batch["q"], shape["n_heads"]), (covs["k"], batch["k"], shape["n_kv_heads"])])
+                         (covs["q"], batch["q"], shape["n_heads"]), (covs["k"], batch["k"], shape["n_kv_heads"])], mode=mode)
 
 
 def finalize(covs: Dict[str, torch.Tensor], n_texts: int) -> None:

@@ -6,6 +6,7 @@ libmodegpt_hip.so.  Every function requires CUDA(HIP) tensors and raises otherwi
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -72,10 +73,12 @@ def cov_accum(sigma: torch.Tensor, x: torch.Tensor, n_heads: int = 1, relu: bool
                                 sigma.data_ptr(), feat, feat * feat, wsp, nbytes, _stream(x)), "mdg_cov_accum")
 
 
-def cov_accum_i8(sigma: torch.Tensor, x: torch.Tensor) -> bool:
+def cov_accum_i8(sigma: torch.Tensor, x: torch.Tensor, events=None) -> int:
     """sigma (lower triangle) += X^T X for one bf16 matrix through the int8 digit-plane kernel (csrc/cov_i8.hip).
-    Returns True when the int8 route ran, False when the per-column outlier test sent the batch to the fp64 kernel
-    (the result is valid either way).  Feature count must be a multiple of 128."""
+    Returns the number of digit planes the product used (5 or 6), or 0 when the per-column depth statistic sent the batch
+    to the fp64 kernel (the result is valid either way; I8_STATS counts the routes).  Feature count must be a multiple
+    of 128.  events: optional pair of torch.cuda.Event(enable_timing=True), each recorded once already, re-recorded
+    around the product kernel alone."""
     _need_gpu(sigma, x)
     lib = _lib.load()
     if sigma.dtype != torch.float64 or not sigma.is_contiguous() or sigma.dim() != 2:
@@ -93,17 +96,41 @@ def cov_accum_i8(sigma: torch.Tensor, x: torch.Tensor) -> bool:
     used = C.c_int(0)
     with torch.cuda.device(x.device):
         check(lib.mdg_cov_accum_i8(x2.data_ptr(), x2.shape[0], n, x2.stride(0), sigma.data_ptr(), sigma.stride(0), wsp, nbytes,
-                                   C.byref(used), _stream(x)), "mdg_cov_accum_i8")
-    return bool(used.value)
+                                   C.byref(used), None if events is None else events[0].cuda_event,
+                                   None if events is None else events[1].cuda_event, _stream(x)), "mdg_cov_accum_i8")
+    I8_STATS[{5: "i8_5", 6: "i8_6"}.get(used.value, "fallback_f64")] += 1
+    return used.value
 
 
-def cov_accum_multi(items) -> None:
+# Which matrix cores accumulate the large covariances of a layer: "f64" (v_mfma_f64, the accumulation order of the
+# reference's fp64 matmul) or "i8" (exact digit-plane split on the int8 cores, csrc/cov_i8.hip; per-head statistics and
+# anything it cannot take stay on the fp64 kernel, and every call falls back by itself on outlier-dominated columns).
+COV_MODE = os.environ.get("MODEGPT_COV_MODE", "i8")
+I8_STATS = {"i8_5": 0, "i8_6": 0, "fallback_f64": 0}      # how the "i8" requests of this process were served
+
+
+def cov_accum_multi(items, mode: Optional[str] = None) -> None:
     """One launch for several covariance problems of the same calibration batch.  items: sequence of
     (sigma, x, n_heads), largest problem first.  Falls back to one cov_accum call per item when the fused kernel's
-    preconditions do not hold (mixed dtypes, feature count not a multiple of 128, unaligned rows)."""
+    preconditions do not hold (mixed dtypes, feature count not a multiple of 128, unaligned rows).
+    mode (default ops.COV_MODE): "i8" sends every single-matrix bf16 problem whose width is a multiple of 128 through
+    cov_accum_i8 and fuses only the rest."""
     items = [(s_, x_, h_) for (s_, x_, h_) in items if x_.numel() > 0]
     if not items:
         return
+    mode = mode or COV_MODE
+    if mode not in ("f64", "i8"):
+        raise ValueError(f"covariance mode must be 'f64' or 'i8', got {mode!r}")
+    if mode == "i8":
+        rest = []
+        for sigma, x, n_heads in items:
+            if n_heads == 1 and x.dtype == torch.bfloat16 and sigma.dim() == 2 and sigma.shape[-1] % 128 == 0:
+                cov_accum_i8(sigma, x)
+            else:
+                rest.append((sigma, x, n_heads))
+        items = rest
+        if not items:
+            return
     lib = _lib.load()
     prepared = []
     dtype = items[0][1].dtype
