@@ -1,9 +1,28 @@
-"""Summarise a rocprofv3 rocpd .db: per-kernel dispatch stats (and PMC counter sums if present) as CSV on stdout."""
+"""Summarise a rocprofv3 rocpd .db: per-kernel dispatch stats (and PMC counter sums if present) as CSV on stdout.
+With a second argument `bygrid`, kernels are additionally split by their grid size (one row per launch shape)."""
 import sqlite3
 import sys
 
 db = sqlite3.connect(sys.argv[1])
 cur = db.cursor()
+BYGRID = len(sys.argv) > 2 and sys.argv[2] == "bygrid"
+if BYGRID:
+    print("kernel,grid_x,calls,avg_ms,min_ms,max_ms")
+    for r in cur.execute("""select s.kernel_name, d.grid_size_x, count(*), avg(d.end-d.start)/1e6, min(d.end-d.start)/1e6,
+            max(d.end-d.start)/1e6 from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id=s.id
+            group by 1, 2 order by 4 desc"""):
+        print('"%s",%d,%d,%.4f,%.4f,%.4f' % r)
+    try:
+        rows = list(cur.execute("""select s.kernel_name, d.grid_size_x, p.name, count(distinct d.id), sum(e.value) / count(distinct d.id)
+            from rocpd_pmc_event e join rocpd_info_pmc p on e.pmc_id=p.id join rocpd_kernel_dispatch d on e.event_id=d.event_id
+            join rocpd_info_kernel_symbol s on d.kernel_id=s.id group by 1, 2, 3 order by 1, 2, 3"""))
+        if rows:
+            print("\nkernel,grid_x,counter,dispatches,sum_per_dispatch")
+            for r in rows:
+                print('"%s",%d,%s,%d,%.6g' % r)
+    except sqlite3.Error as e:
+        print("# no pmc tables:", e)
+    sys.exit(0)
 tot = cur.execute("select sum(end-start) from rocpd_kernel_dispatch").fetchone()[0]
 print("kernel,calls,total_ms,avg_ms,min_ms,max_ms,pct")
 q = """select s.kernel_name, count(*), sum(d.end-d.start)/1e6, avg(d.end-d.start)/1e6, min(d.end-d.start)/1e6,
