@@ -106,6 +106,7 @@ def cov_accum_i8(sigma: torch.Tensor, x: torch.Tensor, events=None) -> int:
 # reference's fp64 matmul) or "i8" (exact digit-plane split on the int8 cores, csrc/cov_i8.hip; per-head statistics and
 # anything it cannot take stay on the fp64 kernel, and every call falls back by itself on outlier-dominated columns).
 COV_MODE = os.environ.get("MODEGPT_COV_MODE", "i8")
+I8_MIN_FEATURES = 2048
 I8_STATS = {"i8_5": 0, "i8_6": 0, "fallback_f64": 0}      # how the "i8" requests of this process were served
 
 
@@ -124,7 +125,9 @@ def cov_accum_multi(items, mode: Optional[str] = None) -> None:
     if mode == "i8":
         rest = []
         for sigma, x, n_heads in items:
-            if n_heads == 1 and x.dtype == torch.bfloat16 and sigma.dim() == 2 and sigma.shape[-1] % 128 == 0:
+            # below ~2048 features the 128 x 64 tiles do not fill the 256 CUs and the fp64 kernel is the faster one
+            if n_heads == 1 and x.dtype == torch.bfloat16 and sigma.dim() == 2 and sigma.shape[-1] % 128 == 0 \
+                    and sigma.shape[-1] >= I8_MIN_FEATURES:
                 cov_accum_i8(sigma, x)
             else:
                 rest.append((sigma, x, n_heads))
