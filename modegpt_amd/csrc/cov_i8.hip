@@ -189,26 +189,25 @@ __global__ __launch_bounds__(256, 1) void i8_syrk_kernel(SyrkArgs a) {
     const double sc_j = ldexp(1.0, a.emax[col] - 172);
     // all 32 read-modify-writes of a lane: loads first (independent, in flight together), then the arithmetic and the stores;
     // written as `*p += v` one by one the compiler must keep them in order and every element pays a full memory round trip
-    double old[2][16];
-    int er[2][16];
 #pragma unroll
-    for (int b = 0; b < 2; b++)
+    for (int b = 0; b < 2; b++) {  // one 32-row block at a time: 16 loads in flight per lane, and no spills
+      double old[16];
+      int er[16];
 #pragma unroll
       for (int reg = 0; reg < 16; reg++) {
         const int row = bi * TI + wr * 64 + b * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-        old[b][reg] = a.sigma[(int64_t)row * a.ld_sigma + col];
-        er[b][reg] = a.emax[row];
+        old[reg] = a.sigma[(int64_t)row * a.ld_sigma + col];
+        er[reg] = a.emax[row];
       }
-#pragma unroll
-    for (int b = 0; b < 2; b++)
 #pragma unroll
       for (int reg = 0; reg < 16; reg++) {
         const int row = bi * TI + wr * 64 + b * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
         double v = 0.;
 #pragma unroll
         for (int k = P - 1; k >= 0; k--) v += ldexp((double)acc[k][b][reg], 80 - 8 * k);
-        if (col <= row) a.sigma[(int64_t)row * a.ld_sigma + col] = old[b][reg] + v * sc_j * ldexp(1.0, er[b][reg] - 172);
+        if (col <= row) a.sigma[(int64_t)row * a.ld_sigma + col] = old[reg] + v * sc_j * ldexp(1.0, er[reg] - 172);
       }
+    }
 #pragma unroll
     for (int k = 0; k < P; k++)
 #pragma unroll
