@@ -149,12 +149,20 @@ __global__ __launch_bounds__(256, 1) void i8_syrk_kernel(SyrkArgs a) {
   constexpr int PIECES = 6 * P;                    // 1 KB pieces per stage
   constexpr int PER_WAVE_MIN = PIECES / 4;         // every wave issues at least this many LDS-DMA loads per stage
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  // tile t of the lower region: bi = 128-row block, bj = 64-row block with bj <= 2 bi + 1; bi (bi + 1) tiles precede row bi
-  const int tile = blockIdx.x;
-  int bi = (int)((sqrtf(4.f * tile + 1.f) - 1.f) * 0.5f);
-  while ((bi + 1) * (bi + 2) <= tile) bi++;
-  while (bi * (bi + 1) > tile) bi--;
-  const int bj = tile - bi * (bi + 1);
+  // Tile (bi, bj): bi = 128-row block, bj = 64-row block, lower region bj <= 2 bi + 1.  XCD-aware order: workgroups are
+  // dealt round-robin to the 8 XCDs, each with its own L2, so workgroup w belongs to XCD w % 8 and is the (w / 8)-th one
+  // there.  The tiles are grouped into super-blocks of 4 x 8 tiles (512 x 512 features: 32 tiles = the 32 CUs of an XCD);
+  // a super-block lives on ONE XCD, so per k-step its tiles pull 5 x (512 + 512) x 32 B of distinct panel rows through that
+  // L2 instead of 32 x 30 KB.  Super-blocks (R, C), C <= R, cover the lower region; tiles of a diagonal super-block that lie
+  // above it exit at once.
+  const int w = blockIdx.x;
+  const int sb = (w >> 3) / 32 * 8 + (w & 7), t_in = (w >> 3) & 31;
+  int R = (int)((sqrtf(8.f * sb + 1.f) - 1.f) * 0.5f);
+  while ((R + 1) * (R + 2) / 2 <= sb) R++;
+  while (R * (R + 1) / 2 > sb) R--;
+  const int C = sb - R * (R + 1) / 2;
+  const int bi = 4 * R + (t_in >> 3), bj = 8 * C + (t_in & 7);
+  if (bi >= a.n / TI || bj > 2 * bi + 1) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wr = wave >> 1, wc = wave & 1;
   const int64_t groups = a.n / 32;
@@ -307,7 +315,8 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
   const int rb = n / TI;
   const int planes_used = (depth & 1) ? 6 : 5;
   const size_t lds = (size_t)RING * planes_used * (PA + PB);
-  const dim3 grid((unsigned)(rb * (rb + 1)));
+  const int sr = (rb + 3) / 4, nsb = sr * (sr + 1) / 2;                      // super-block rows, super-blocks
+  const dim3 grid((unsigned)((nsb + 7) / 8 * 8 * 32));
   if (planes_used == 6) MDG_HIP(hipFuncSetAttribute((const void*)i8_syrk_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   else MDG_HIP(hipFuncSetAttribute((const void*)i8_syrk_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (ev_start) MDG_HIP(hipEventRecord((hipEvent_t)ev_start, st));
