@@ -8,10 +8,11 @@
 // s + t < P (P = 5: 15 pairs, P = 6: 21 pairs) drops terms below 2^-8P of (column maximum)^2 per token; what that costs
 // depends on how far below their column's maximum the elements sit, so every call measures it -- per column, the share of
 // nonzero elements more than 10 binades below the maximum ("deep") -- and picks the route (measured against the exact product,
-// scripts/probes/digit_plane_sim.py: Gaussian / Laplace / ReLU columns, deep share < 1/64: P = 5 is within 2e-13 of sigma's
-// scale; SiLU-gated products, share ~0.1: P = 5 gives 3e-12, P = 6 gives 3e-14; cubed Gaussians, share ~0.5, or a column
+// scripts/probes/digit_plane_sim.py, 32768 tokens: Gaussian / ReLU columns, deep share < 1/64: P = 5 is within 2e-13 of
+// sigma's scale; Laplace / Student-t / SiLU- and GELU-gated products / products of two or three Gaussians, share 0.02 - 0.2:
+// P = 5 gives 5e-13 .. 8e-12, P = 6 gives 5e-15 .. 1e-13; cubed Gaussians, share ~0.5: P = 6 gives 3e-12; a column
 // dominated by a few massive activations, share ~1: beyond both):
-//     every column's deep share <= 1/64  ->  P = 5        <= 1/8  ->  P = 6        else  ->  the fp64 kernel (mdg_cov_accum)
+//     every column's deep share <= 1/64  ->  P = 5        <= 1/4  ->  P = 6        else  ->  the fp64 kernel (mdg_cov_accum)
 // fp64 reference semantics: src/adapters/LlamaAdapter.py:127-147 (sigma += X^T X with X upcast to fp64).
 //
 // Kernels per call:
@@ -37,7 +38,6 @@ constexpr int NP = 6;            // digit planes written by the split pass; the 
 constexpr int TI = 128, TJ = 64; // output tile: TI rows of I x TJ rows of J
 constexpr int KS = 32;           // tokens per k-step (one v_mfma_i32_32x32x32_i8)
 constexpr int PA = TI * KS, PB = TJ * KS;
-constexpr int RING = 4;
 constexpr int FLUSH_STEPS = 512;  // 16384 tokens: (k + 1) * 2^14 * 16384 < 2^31 for every class k <= 5
 constexpr int TOP_SHIFT = 8 * NP - 10;  // 38: the column maximum's significand sits below bit 46 of the 48-bit integer
 constexpr int DEEP_BINADES = 10;  // an element is "deep" when its exponent is at least this far below the column maximum
@@ -120,13 +120,13 @@ __global__ __launch_bounds__(256) void i8_split_kernel(const bf16_t* x, int64_t 
   if (threadIdx.x < 32 && deep_lds[threadIdx.x]) atomicAdd(deep_cnt + G * 32 + threadIdx.x, deep_lds[threadIdx.x]);
 }
 
-// flag bit 0: some column has more than T / 64 deep elements (five planes are not enough); bit 1: more than T / 8 (six
+// flag bit 0: some column has more than T / 64 deep elements (five planes are not enough); bit 1: more than T / 4 (six
 // are not either)
 __global__ __launch_bounds__(256) void i8_depth_kernel(const int* deep_cnt, int n, int64_t T, int* flag) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n) return;
   const int64_t c = deep_cnt[j];
-  const int bits = (c * 64 > T ? 1 : 0) | (c * 8 > T ? 2 : 0);
+  const int bits = (c * 64 > T ? 1 : 0) | (c * 4 > T ? 2 : 0);
   if (bits) atomicOr(flag, bits);
 }
 
@@ -143,25 +143,41 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
                                    0, 0);
 }
 
+// LDS ring depth: 4 x 30 KB / 4 x 36 KB.  3 and 5 measured the same (the kernel is not short of look-ahead).
+template <int P> constexpr int ring_depth() { return 4; }
+
 template <int P>  // planes used: 5 or 6
 __global__ __launch_bounds__(256, 1) void i8_syrk_kernel(SyrkArgs a) {
+  constexpr int RING = ring_depth<P>();
   constexpr int STAGE_BYTES = P * (PA + PB);       // 30 / 36 KB
   constexpr int PIECES = 6 * P;                    // 1 KB pieces per stage
   constexpr int PER_WAVE_MIN = PIECES / 4;         // every wave issues at least this many LDS-DMA loads per stage
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  // Tile (bi, bj): bi = 128-row block, bj = 64-row block, lower region bj <= 2 bi + 1.  XCD-aware order: workgroups are
-  // dealt round-robin to the 8 XCDs, each with its own L2, so workgroup w belongs to XCD w % 8 and is the (w / 8)-th one
-  // there.  The tiles are grouped into super-blocks of 4 x 8 tiles (512 x 512 features: 32 tiles = the 32 CUs of an XCD);
-  // a super-block lives on ONE XCD, so per k-step its tiles pull 5 x (512 + 512) x 32 B of distinct panel rows through that
-  // L2 instead of 32 x 30 KB.  Super-blocks (R, C), C <= R, cover the lower region; tiles of a diagonal super-block that lie
-  // above it exit at once.
-  const int w = blockIdx.x;
-  const int sb = (w >> 3) / 32 * 8 + (w & 7), t_in = (w >> 3) & 31;
-  int R = (int)((sqrtf(8.f * sb + 1.f) - 1.f) * 0.5f);
-  while ((R + 1) * (R + 2) / 2 <= sb) R++;
-  while (R * (R + 1) / 2 > sb) R--;
-  const int C = sb - R * (R + 1) / 2;
-  const int bi = 4 * R + (t_in >> 3), bj = 8 * C + (t_in & 7);
+  // Tile (bi, bj): bi = 128-row block, bj = 64-row block, lower region bj <= 2 bi + 1.
+  // P = 5, XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2, so workgroup w belongs to
+  // XCD w % 8 and is the (w / 8)-th one there.  The tiles are grouped into super-blocks of 4 x 8 tiles (512 x 512 features:
+  // 32 tiles = the 32 CUs of an XCD); a super-block lives on ONE XCD, so per k-step its tiles pull 5 x (512 + 512) x 32 B of
+  // distinct panel rows through that L2 instead of 32 x 30 KB (FETCH_SIZE 231 -> 132 GB per launch, 47.7 -> 44.8 ms).
+  // Super-blocks (R, C), C <= R, cover the lower region; tiles of a diagonal super-block that lie above it exit at once.
+  // P = 6 keeps the plain row-major tile order: there the super-blocks measured 86.7 ms against 59.3 ms (32 workgroups asking
+  // one L2 for the same 36 KB at the same moment queue behind each other).
+  int bi, bj;
+  if (P == 5) {
+    const int w = blockIdx.x;
+    const int sb = (w >> 3) / 32 * 8 + (w & 7), t_in = (w >> 3) & 31;
+    int R = (int)((sqrtf(8.f * sb + 1.f) - 1.f) * 0.5f);
+    while ((R + 1) * (R + 2) / 2 <= sb) R++;
+    while (R * (R + 1) / 2 > sb) R--;
+    const int C = sb - R * (R + 1) / 2;
+    bi = 4 * R + (t_in >> 3);
+    bj = 8 * C + (t_in & 7);
+  } else {
+    const int tile = blockIdx.x;  // bi (bi + 1) tiles precede row bi
+    bi = (int)((sqrtf(4.f * tile + 1.f) - 1.f) * 0.5f);
+    while ((bi + 1) * (bi + 2) <= tile) bi++;
+    while (bi * (bi + 1) > tile) bi--;
+    bj = tile - bi * (bi + 1);
+  }
   if (bi >= a.n / TI || bj > 2 * bi + 1) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wr = wave >> 1, wc = wave & 1;
@@ -234,7 +250,7 @@ __global__ __launch_bounds__(256, 1) void i8_syrk_kernel(SyrkArgs a) {
       const int buf = kt % RING;
       // stages kt+1 and kt+2 may stay in flight: "at most 2 x (loads a wave issues per stage, rounded down)" outstanding
       // retires stage kt on every wave (P = 5: waves issue 8, 8, 7, 7 -> 14; P = 6: 9 each -> 18); the tail drains everything
-      if (kt + RING - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_WAVE_MIN) : "memory");
+      if (kt + RING - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * PER_WAVE_MIN) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if (kt + RING - 1 < nk) issue_stage(kt + RING - 1, (kt + RING - 1) % RING);
@@ -313,10 +329,12 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
   SyrkArgs a;
   a.planes = planes; a.emax = emax; a.sigma = sigma; a.ld_sigma = ld_sigma; a.n = n; a.nk = nk;
   const int rb = n / TI;
-  const int planes_used = (depth & 1) ? 6 : 5;
-  const size_t lds = (size_t)RING * planes_used * (PA + PB);
+  int planes_used = (depth & 1) ? 6 : 5;
+  if (const char* ev = getenv("MDG_I8_PLANES"))  // experiment knob (scripts/bench_kernels.py): force the 6-plane product
+    if (atoi(ev) == 6) planes_used = 6;
+  const size_t lds = (size_t)(planes_used == 5 ? ring_depth<5>() : ring_depth<6>()) * planes_used * (PA + PB);
   const int sr = (rb + 3) / 4, nsb = sr * (sr + 1) / 2;                      // super-block rows, super-blocks
-  const dim3 grid((unsigned)((nsb + 7) / 8 * 8 * 32));
+  const dim3 grid(planes_used == 5 ? (unsigned)((nsb + 7) / 8 * 8 * 32) : (unsigned)(rb * (rb + 1)));
   if (planes_used == 6) MDG_HIP(hipFuncSetAttribute((const void*)i8_syrk_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   else MDG_HIP(hipFuncSetAttribute((const void*)i8_syrk_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (ev_start) MDG_HIP(hipEventRecord((hipEvent_t)ev_start, st));

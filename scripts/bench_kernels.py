@@ -133,3 +133,19 @@ if "covi8" in which:
     X = acts(T, d); Sx = torch.zeros(d, d, dtype=F64, device=dev)
     t8 = timeit(lambda: ops.cov_accum_i8(Sx, X), n=3); t64 = timeit(lambda: ops.cov_accum(Sx, X), n=3)
     print(f"cov x   {T}x{d}: int8 digit planes {t8*1e3:.2f} ms   fp64 MFMA {t64*1e3:.2f} ms")
+if "covi8p6" in which:
+    # SiLU-gated activations (the MLP statistic of a real Llama): the depth statistic picks six planes
+    gg = torch.randn(T, d_ff, device=dev, generator=g); uu = torch.randn(T, d_ff, device=dev, generator=g)
+    H = (torch.nn.functional.silu(gg) * uu).to(torch.bfloat16); del gg, uu
+    S8 = torch.zeros(d_ff, d_ff, dtype=F64, device=dev); S64 = torch.zeros_like(S8)
+    used = ops.cov_accum_i8(S8, H); ops.cov_accum(S64, H)
+    dd = torch.sqrt(torch.diag(S64))
+    low = torch.tril(torch.ones(d_ff, d_ff, dtype=torch.bool, device=dev))
+    err = 0.0
+    for i0 in range(0, d_ff, 2048):   # entry-wise error over sqrt(sigma_ii sigma_jj), in row blocks to bound memory
+        blk = ((S8[i0:i0 + 2048] - S64[i0:i0 + 2048]).abs() / (dd[i0:i0 + 2048, None] * dd[None])) * low[i0:i0 + 2048]
+        err = max(err, blk.max().item())
+    print(f"SiLU-gated columns: route {used} planes;  max |i8 - fp64| / sqrt(s_ii s_jj) = {err:.2e}")
+    t8 = timeit(lambda: ops.cov_accum_i8(S8, H), n=3)
+    t64 = timeit(lambda: ops.cov_accum(S64, H), n=3)
+    print(f"cov mlp {T}x{d_ff} (SiLU-gated): int8 digit planes {t8*1e3:.1f} ms   fp64 MFMA {t64*1e3:.1f} ms")

@@ -13,7 +13,10 @@
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int S = 5;          // digit planes
+#ifndef S_PLANES
+#define S_PLANES 5
+#endif
+constexpr int S = S_PLANES;   // digit planes (-DS_PLANES=6 for the 21-pair variant)
 constexpr int TILE = 128;     // workgroup tile: TILE rows of I x TJ rows of J (features)
 constexpr int TJ = 64;
 constexpr int BK = 32;        // tokens per stage = one MFMA k-step
@@ -46,11 +49,11 @@ __global__ __launch_bounds__(256, 1) void planes_syrk(const int8_t* __restrict__
   // an MFMA k-half read 512 contiguous bytes
   auto issue_stage = [&](int kt, int buf) {
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-      const int p = wave + 4 * q;          // 0 .. 31, 30 used
-      if (p < 30) {
-        const bool isA = p < 20;
-        const int pp = isA ? p : p - 20;
+    for (int q = 0; q < (6 * S + 3) / 4; q++) {
+      const int p = wave + 4 * q;
+      if (p < 6 * S) {
+        const bool isA = p < 4 * S;
+        const int pp = isA ? p : p - 4 * S;
         const int s = isA ? pp >> 2 : pp >> 1, g = isA ? pp & 3 : pp & 1;
         // blocked plane layout written by the split pass: [plane][row group of 32][k-step][half][row][16 B] -- a piece is
         // 1 KB contiguous in memory (8 full cache lines per wave instruction instead of 32 quarter-used ones)
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256, 1) void planes_syrk(const int8_t* __restrict__
     const int buf = kt % NBUF;
     // waves 0,1 issue 8 glds per stage, waves 2,3 issue 7; stages kt+1, kt+2 may stay in flight: at most 14 outstanding
     // retires stage kt on every wave (the tail drains everything)
-    if (kt + NBUF - 2 < nk) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    if (kt + NBUF - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (6 * S / 4)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (kt + NBUF - 1 < nk) issue_stage(kt + NBUF - 1, (kt + NBUF - 1) % NBUF);
@@ -191,7 +194,7 @@ int main() {
     }
     CK(hipGetLastError());
     CK(hipFuncSetAttribute((const void*)planes_syrk, hipFuncAttributeMaxDynamicSharedMemorySize, NBUF * STAGE));
-    const double ops = 15.0 * 2.0 * (double)tiles * TILE * TJ * T;   // 15 plane pairs, 2 ops per MAC (128 x 64 tiles incl. the diagonal's upper halves)
+    const double ops = (S * (S + 1) / 2) * 2.0 * (double)tiles * TILE * TJ * T;   // 15 plane pairs, 2 ops per MAC (128 x 64 tiles incl. the diagonal's upper halves)
     printf("n=%d T=%d: %.2f ms  %.0f int8 TOP/s (%.1f%% of 5000)   [fp64 SYRK kernel on the same batch: ~95 ms]\n", n, T, best,
            ops / best / 1e9, ops / best / 1e9 / 50.0);
   }
