@@ -66,3 +66,5 @@ t0 = time.time(); ppl = compute_perplexity(model, None, bs=4, dataset="synthetic
 print(f"compressed model, in-process compressed attention: synthetic-token perplexity {ppl:.1f} (random weights; vocab 32000) in {t_ppl:.1f} s")
 print(f"TOTAL {t_cal + t_mlp + t_qk + t_vo:.1f} s for {L} layers = {L / (t_cal + t_mlp + t_qk + t_vo):.3f} layers/s (model forward and artefact IO included)")
 shutil.rmtree(tmp, ignore_errors=True)
+from modegpt_amd import ops as _ops
+print(f"covariance routes of the large statistics (mode {_ops.COV_MODE}): {_ops.I8_STATS}")
