@@ -121,12 +121,12 @@ __global__ __launch_bounds__(256) void i8_split_kernel(const bf16_t* x, int64_t 
 }
 
 // flag bit 0: some column has more than T / 64 deep elements (five planes are not enough); bit 1: more than T / 4 (six
-// are not either)
-__global__ __launch_bounds__(256) void i8_depth_kernel(const int* deep_cnt, int n, int64_t T, int* flag) {
+// are not either, or the column holds an Inf / NaN, which only the fp64 kernel propagates the way the reference does)
+__global__ __launch_bounds__(256) void i8_depth_kernel(const int* deep_cnt, const int* emax, int n, int64_t T, int* flag) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n) return;
   const int64_t c = deep_cnt[j];
-  const int bits = (c * 64 > T ? 1 : 0) | (c * 4 > T ? 2 : 0);
+  const int bits = (c * 64 > T ? 1 : 0) | ((c * 4 > T || emax[j] == 255) ? 2 : 0);
   if (bits) atomicOr(flag, bits);
 }
 
@@ -318,7 +318,7 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
   }
   hipLaunchKernelGGL(i8_split_kernel, dim3((unsigned)(n / 32), (unsigned)ceil_div(nk, SPLIT_STEPS)), dim3(256), 0, st, (const bf16_t*)x, ld,
                      n_tokens, n, nk, emax, planes, deep_cnt);
-  hipLaunchKernelGGL(i8_depth_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, deep_cnt, n, n_tokens, flag);
+  hipLaunchKernelGGL(i8_depth_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, deep_cnt, emax, n, n_tokens, flag);
   MDG_LAUNCH_CHECK();
   int depth = 0;
   MDG_HIP(hipMemcpyAsync(&depth, flag, sizeof(int), hipMemcpyDeviceToHost, st));

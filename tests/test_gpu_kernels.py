@@ -612,6 +612,11 @@ def test_cov_i8_special_values_and_errors(ops, dev):
     low = torch.tril(torch.ones(128, 128, dtype=torch.bool))
     assert ((S.cpu() - ref)[low].abs().max() / ref.abs().max()).item() < 1e-12
     assert S[9, 9].item() == ref[9, 9].item() != 0.0          # products of denormals are exact
+    Xn = X.clone()
+    Xn[3, 7] = float("inf")
+    Sn = torch.zeros(128, 128, dtype=F64, device=dev)
+    assert ops.cov_accum_i8(Sn, Xn.to(dev)) == 0                  # Inf / NaN: the fp64 kernel's semantics
+    assert not bool(torch.isfinite(Sn[7, 7]))
     with pytest.raises(RuntimeError, match="multiple of 128"):
         ops.cov_accum_i8(torch.zeros(200, 200, dtype=F64, device=dev), acts(gen, 64, 200).to(dev))
     with pytest.raises(ValueError):
