@@ -13,8 +13,12 @@ and weights are resident in HBM before the timed region.  With N GPUs every rank
 compressed layers on every rank.
 
 The JSON line also carries
-  roofline     -- the dominant kernel (cov_accum_multi_kernel, fp64 MFMA bound): algorithmic SYRK flops of its launches
-                  in the timed region / their summed durations (HIP events on the launch stream)
+  roofline     -- the dominant kernel.  Default covariance route (--cov-mode i8, exact int8 digit planes): i8_syrk_kernel on
+                  sigma_mlp, int8 MFMA bound -- algorithmic int8 ops of its launches in the timed region (plane pairs x SYRK
+                  count) / their summed durations, timed alone by HIP events the library records around that kernel on the
+                  launch stream; the v_mfma_f64 kernel on the same batch is reported beside it as roofline.f64_route.
+                  --cov-mode f64: cov_accum_multi_kernel, fp64 MFMA bound -- SYRK flops of the fused launches / their
+                  durations (HIP events around each launch)
   cpu_baseline -- this repo's CPU oracle (torch-CPU fp64 restatement of the reference) timed on the host cores
                   on a bounded sample of the same workload (N = 1, rank 0 only)
 """
@@ -260,11 +264,10 @@ def main():
                       "pair products of one calibration batch per launch, timed alone by events the library records around it)",
             "launches": n_launch, "avg_launch_ms": ms / n_launch, "op_per_launch": flops / n_launch,
             "op_count": "plane pairs (15 or 21, see routes) x tokens x n (n + 1): the SYRK count of each product, 2 ops per multiply-add",
-            "fp64_syrk_equivalent_tflops": sum(ev0.elapsed_time(ev1) for _, ev0, ev1 in timer.pairs) and
-            (n_launch * batches[0]["h"].shape[0] * f * (f + 1)) / (ms * 1e-3) / 1e12,
+            "fp64_syrk_equivalent_tflops": n_launch * batches[0]["h"].shape[0] * f * (f + 1) / (ms * 1e-3) / 1e12,
             "routes": dict(ops.I8_STATS),
-            "note": "sigma_x goes through the same kernel; sigma_q / sigma_k (1.4 % of the work) and any batch that fails the "
-                    "per-column outlier test go through the v_mfma_f64 kernel (--cov-mode f64 runs everything there: "
+            "note": "sigma_x goes through the same kernel; sigma_q / sigma_k (1.4 % of the work) and any batch whose columns the "
+                    "per-column depth statistic finds too heavy-tailed for six planes go through the v_mfma_f64 kernel (--cov-mode f64 runs everything there: "
                     "0.909 of the fp64 peak, DESIGN.md section 7)"}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         li, tensors, mask, covs = last
