@@ -621,3 +621,17 @@ def test_cov_i8_special_values_and_errors(ops, dev):
         ops.cov_accum_i8(torch.zeros(200, 200, dtype=F64, device=dev), acts(gen, 64, 200).to(dev))
     with pytest.raises(ValueError):
         ops.cov_accum_i8(S, X.float().to(dev))
+
+
+def test_cov_i8_reads_a_column_slice_in_place(ops, dev):
+    """Hook inputs are often column slices of a fused projection: the int8 route takes the row pitch as is."""
+    gen = torch.Generator().manual_seed(12)
+    wide = acts(gen, 1500, 640).to(dev)
+    X = wide[:, 128:128 + 384]                       # row pitch 640, 384 columns, 256-byte offset
+    assert X.stride(0) == 640 and not X.is_contiguous()
+    S = torch.zeros(384, 384, dtype=F64, device=dev)
+    assert ops.cov_accum_i8(S, X) == 5
+    ref = torch.zeros(384, 384, dtype=F64)
+    O.cov_accum_tokens(ref, X.cpu())
+    low = torch.tril(torch.ones(384, 384, dtype=torch.bool))
+    assert ((S.cpu() - ref)[low].abs().max() / ref.abs().max()).item() < 1e-12
