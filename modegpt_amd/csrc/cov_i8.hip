@@ -159,18 +159,24 @@ __global__ __launch_bounds__(256, 1) void i8_syrk_kernel(SyrkArgs a) {
   // 32 tiles = the 32 CUs of an XCD); a super-block lives on ONE XCD, so per k-step its tiles pull 5 x (512 + 512) x 32 B of
   // distinct panel rows through that L2 instead of 32 x 30 KB (FETCH_SIZE 231 -> 132 GB per launch, 47.7 -> 44.8 ms).
   // Super-blocks (R, C), C <= R, cover the lower region; tiles of a diagonal super-block that lie above it exit at once.
-  // P = 6 keeps the plain row-major tile order: there the super-blocks measured 86.7 ms against 59.3 ms (32 workgroups asking
-  // one L2 for the same 36 KB at the same moment queue behind each other).
+  // P = 6 keeps the plain row-major tile order: there every XCD-pinned grouping tried (1 x 2, 2 x 4, 4 x 8 tiles, build flag
+  // MDG_I8_SB6) measured 84 - 87 ms against 60.8 ms row-major; not understood yet (PMC: waves parked 52 % of the time).
   int bi, bj;
-  if (P == 5) {
+#ifndef MDG_I8_SB6
+#define MDG_I8_SB6 0
+#endif
+  constexpr int SI = P == 5 ? 4 : MDG_I8_SB6;   // super-block: SI x 2 SI tiles; 0 = plain row-major order
+  if (SI > 0) {
+    constexpr int TPS = SI * 2 * SI;            // tiles per super-block
     const int w = blockIdx.x;
-    const int sb = (w >> 3) / 32 * 8 + (w & 7), t_in = (w >> 3) & 31;
+    const int q = w >> 3;
+    const int sb = q / TPS * 8 + (w & 7), t_in = q % TPS;
     int R = (int)((sqrtf(8.f * sb + 1.f) - 1.f) * 0.5f);
     while ((R + 1) * (R + 2) / 2 <= sb) R++;
     while (R * (R + 1) / 2 > sb) R--;
     const int C = sb - R * (R + 1) / 2;
-    bi = 4 * R + (t_in >> 3);
-    bj = 8 * C + (t_in & 7);
+    bi = SI * R + t_in / (2 * SI);
+    bj = 2 * SI * C + t_in % (2 * SI);
   } else {
     const int tile = blockIdx.x;  // bi (bi + 1) tiles precede row bi
     bi = (int)((sqrtf(4.f * tile + 1.f) - 1.f) * 0.5f);
@@ -333,8 +339,9 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
   if (const char* ev = getenv("MDG_I8_PLANES"))  // experiment knob (scripts/bench_kernels.py): force the 6-plane product
     if (atoi(ev) == 6) planes_used = 6;
   const size_t lds = (size_t)(planes_used == 5 ? ring_depth<5>() : ring_depth<6>()) * planes_used * (PA + PB);
-  const int sr = (rb + 3) / 4, nsb = sr * (sr + 1) / 2;                      // super-block rows, super-blocks
-  const dim3 grid(planes_used == 5 ? (unsigned)((nsb + 7) / 8 * 8 * 32) : (unsigned)(rb * (rb + 1)));
+  const int si = planes_used == 5 ? 4 : MDG_I8_SB6;                          // super-block rows (see the kernel); 0 = row-major
+  const int sr = si ? (rb + si - 1) / si : 0, nsb = sr * (sr + 1) / 2;       // super-block rows, super-blocks
+  const dim3 grid(si ? (unsigned)((nsb + 7) / 8 * 8 * (2 * si * si)) : (unsigned)(rb * (rb + 1)));
   if (planes_used == 6) MDG_HIP(hipFuncSetAttribute((const void*)i8_syrk_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   else MDG_HIP(hipFuncSetAttribute((const void*)i8_syrk_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (ev_start) MDG_HIP(hipEventRecord((hipEvent_t)ev_start, st));
