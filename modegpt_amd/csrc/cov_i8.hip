@@ -7,7 +7,7 @@
 // and sum over tokens of d_s d_t is an int8 MFMA product with exact int32 accumulation.  Keeping the plane pairs with
 // s + t < P (P = 5: 15 pairs, P = 6: 21 pairs) drops terms below 2^-8P of (column maximum)^2 per token; what that costs
 // depends on how far below their column's maximum the elements sit, so every call measures it -- per column, the share of
-// nonzero elements more than 10 binades below the maximum ("deep") -- and picks the route (measured against the exact product,
+// its nonzero elements that lie more than 10 binades below the maximum ("deep") -- and picks the route (measured against the exact product,
 // scripts/probes/digit_plane_sim.py, 32768 tokens: Gaussian / ReLU columns, deep share < 1/64: P = 5 is within 2e-13 of
 // sigma's scale; Laplace / Student-t / SiLU- and GELU-gated products / products of two or three Gaussians, share 0.02 - 0.2:
 // P = 5 gives 5e-13 .. 8e-12, P = 6 gives 5e-15 .. 1e-13; cubed Gaussians, share ~0.5: P = 6 gives 3e-12; a column
@@ -69,16 +69,16 @@ __global__ __launch_bounds__(256) void i8_colmax_kernel(const bf16_t* x, int64_t
 // k-step.  A workgroup walks SPLIT_STEPS k-steps of its row group, 8 at a time.
 constexpr int SPLIT_STEPS = 64;
 __global__ __launch_bounds__(256) void i8_split_kernel(const bf16_t* x, int64_t ld, int64_t T, int n, int nk, const int* emax,
-                                                       signed char* planes, int* deep_cnt) {
-  __shared__ int deep_lds[32];
+                                                       signed char* planes, int* deep_cnt, int* nz_cnt) {
+  __shared__ int deep_lds[32], nz_lds[32];
   const int r = threadIdx.x & 31;
   const int G = blockIdx.x;
   const int j = G * 32 + r;
   const int E = emax[j];
   const int64_t groups = n / 32;
-  if (threadIdx.x < 32) deep_lds[threadIdx.x] = 0;
+  if (threadIdx.x < 32) deep_lds[threadIdx.x] = nz_lds[threadIdx.x] = 0;
   __syncthreads();
-  int deep = 0;
+  int deep = 0, nz = 0;
   for (int kq = 0; kq < SPLIT_STEPS; kq += 8) {
     const int kt = blockIdx.y * SPLIT_STEPS + kq + (threadIdx.x >> 5);
     if (kt >= nk) break;
@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void i8_split_kernel(const bf16_t* x, int64_t 
         if (t < T) bf16_parts(x[t * ld + j], sig, ee);
         const int sh = E - ee;
         deep += (sig != 0 && sh >= DEEP_BINADES);
+        nz += (sig != 0);
         long long N;
         if (sh <= TOP_SHIFT) {
           N = (long long)sig << (TOP_SHIFT - sh);
@@ -116,17 +117,21 @@ __global__ __launch_bounds__(256) void i8_split_kernel(const bf16_t* x, int64_t 
     }
   }
   if (deep) atomicAdd(&deep_lds[r], deep);
+  if (nz) atomicAdd(&nz_lds[r], nz);
   __syncthreads();
   if (threadIdx.x < 32 && deep_lds[threadIdx.x]) atomicAdd(deep_cnt + G * 32 + threadIdx.x, deep_lds[threadIdx.x]);
+  if (threadIdx.x < 32 && nz_lds[threadIdx.x]) atomicAdd(nz_cnt + G * 32 + threadIdx.x, nz_lds[threadIdx.x]);
 }
 
-// flag bit 0: some column has more than T / 64 deep elements (five planes are not enough); bit 1: more than T / 4 (six
-// are not either, or the column holds an Inf / NaN, which only the fp64 kernel propagates the way the reference does)
-__global__ __launch_bounds__(256) void i8_depth_kernel(const int* deep_cnt, const int* emax, int n, int64_t T, int* flag) {
+// flag bit 0: in some column more than 1 / 64 of the nonzero elements are deep (five planes are not enough); bit 1: more
+// than 1 / 4 (six are not either), or the column holds an Inf / NaN, which only the fp64 kernel propagates the way the
+// reference does.  The share is taken over the NONZERO elements: zeros add nothing to sigma, so a sparse column's accuracy is
+// set by the few elements it has.
+__global__ __launch_bounds__(256) void i8_depth_kernel(const int* deep_cnt, const int* nz_cnt, const int* emax, int n, int* flag) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n) return;
-  const int64_t c = deep_cnt[j];
-  const int bits = (c * 64 > T ? 1 : 0) | ((c * 4 > T || emax[j] == 255) ? 2 : 0);
+  const int64_t c = deep_cnt[j], nz = nz_cnt[j];
+  const int bits = (c * 64 > nz ? 1 : 0) | ((c * 4 > nz || emax[j] == 255) ? 2 : 0);
   if (bits) atomicOr(flag, bits);
 }
 
@@ -291,7 +296,7 @@ using namespace mdg;
 extern "C" size_t mdg_cov_accum_i8_ws_bytes(int64_t n_tokens, int64_t n_feat) {
   if (n_tokens <= 0 || n_feat <= 0) return 0;
   const size_t fallback = mdg_cov_accum_ws_bytes(n_tokens, n_feat, 1);
-  return align_up(planes_bytes(n_tokens, n_feat), 256) + align_up((size_t)(2 * n_feat + 4) * sizeof(int), 256) + fallback + 256;
+  return align_up(planes_bytes(n_tokens, n_feat), 256) + align_up((size_t)(3 * n_feat + 4) * sizeof(int), 256) + fallback + 256;
 }
 
 extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat, int64_t ld, double* sigma, int64_t ld_sigma,
@@ -314,17 +319,18 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
   signed char* planes = (signed char*)ws;
   int* emax = (int*)((char*)ws + align_up(planes_bytes(n_tokens, n_feat), 256));
   int* deep_cnt = emax + n;
-  int* flag = deep_cnt + n;
-  void* fb_ws = (char*)emax + align_up((size_t)(2 * n + 4) * sizeof(int), 256);
-  MDG_HIP(hipMemsetAsync(emax, 0, (size_t)(2 * n + 4) * sizeof(int), st));
+  int* nz_cnt = deep_cnt + n;
+  int* flag = nz_cnt + n;
+  void* fb_ws = (char*)emax + align_up((size_t)(3 * n + 4) * sizeof(int), 256);
+  MDG_HIP(hipMemsetAsync(emax, 0, (size_t)(3 * n + 4) * sizeof(int), st));
   {
     const int64_t rows_per_block = 2048;
     const dim3 grid((unsigned)ceil_div(n, 64), (unsigned)ceil_div(n_tokens, rows_per_block));
     hipLaunchKernelGGL(i8_colmax_kernel, grid, dim3(256), 0, st, (const bf16_t*)x, ld, n_tokens, n, rows_per_block, emax);
   }
   hipLaunchKernelGGL(i8_split_kernel, dim3((unsigned)(n / 32), (unsigned)ceil_div(nk, SPLIT_STEPS)), dim3(256), 0, st, (const bf16_t*)x, ld,
-                     n_tokens, n, nk, emax, planes, deep_cnt);
-  hipLaunchKernelGGL(i8_depth_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, deep_cnt, emax, n, n_tokens, flag);
+                     n_tokens, n, nk, emax, planes, deep_cnt, nz_cnt);
+  hipLaunchKernelGGL(i8_depth_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, deep_cnt, nz_cnt, emax, n, flag);
   MDG_LAUNCH_CHECK();
   int depth = 0;
   MDG_HIP(hipMemcpyAsync(&depth, flag, sizeof(int), hipMemcpyDeviceToHost, st));

@@ -635,3 +635,34 @@ def test_cov_i8_reads_a_column_slice_in_place(ops, dev):
     O.cov_accum_tokens(ref, X.cpu())
     low = torch.tril(torch.ones(384, 384, dtype=torch.bool))
     assert ((S.cpu() - ref)[low].abs().max() / ref.abs().max()).item() < 1e-12
+
+
+def test_cov_i8_randomised_shapes_and_scales(ops, dev):
+    """Sweep of shapes, column scales across the whole bf16 exponent range (2^-120 .. 2^120), sparse columns, sign patterns:
+    whichever route a call takes, it must agree with the fp64 kernel entry-wise to 1e-12 of sqrt(sigma_ii sigma_jj)."""
+    gen = torch.Generator().manual_seed(2024)
+    routes = set()
+    for trial in range(12):
+        T = int(torch.randint(1, 3000, (1,), generator=gen))
+        n = 128 * int(torch.randint(1, 5, (1,), generator=gen))
+        z = torch.randn(T, n, generator=gen)
+        kind = trial % 4
+        if kind == 1:
+            z = z * (torch.rand(T, n, generator=gen) < 0.3)              # 70 % zeros
+        elif kind == 2:
+            z = z.abs()                                                   # one-signed
+        elif kind == 3:
+            z = torch.nn.functional.silu(z) * torch.randn(T, n, generator=gen)
+        expo = torch.randint(-120, 121, (n,), generator=gen).double()
+        X = (z.double() * torch.pow(torch.tensor(2.0, dtype=F64), expo)).to(torch.bfloat16).to(dev)
+        S8 = torch.zeros(n, n, dtype=F64, device=dev)
+        S64 = torch.zeros_like(S8)
+        routes.add(ops.cov_accum_i8(S8, X))
+        ops.cov_accum(S64, X)
+        d = torch.sqrt(torch.diag(S64))
+        d = torch.where(d > 0, d, torch.ones_like(d))
+        low = torch.tril(torch.ones(n, n, dtype=torch.bool, device=dev))
+        err = (((S8 - S64).abs() / (d[:, None] * d[None]))[low]).max().item()
+        assert err < 1e-12, (trial, T, n, kind, err)
+        assert bool(torch.isfinite(S8[low]).all())
+    assert routes & {5, 6}, routes
