@@ -123,6 +123,106 @@ __global__ __launch_bounds__(256) void i8_split_kernel(const bf16_t* x, int64_t 
   if (threadIdx.x < 32 && nz_lds[threadIdx.x]) atomicAdd(nz_cnt + G * 32 + threadIdx.x, nz_lds[threadIdx.x]);
 }
 
+// ---- the same two passes for the usual case of 16-byte addressable rows (ld % 8 == 0, aligned base): 16-byte loads.
+// The scalar kernels above read 2 bytes per lane in 64-byte row segments and run at ~2 TB/s; these read whole 256-byte
+// segments and are bound by the 6 bytes per element the split writes.
+__device__ __forceinline__ int bf16_ee_if_nonzero(unsigned b) {  // effective exponent of a nonzero value, 0 for +-0
+  const int e = (b >> 7) & 0xFF;
+  return (b & 0x7FFF) ? (e ? e : 1) : 0;
+}
+
+__global__ __launch_bounds__(256) void i8_colmax_vec_kernel(const bf16_t* x, int64_t ld, int64_t T, int64_t rows_per_block, int* emax) {
+  __shared__ int best_lds[128];
+  const int cg = threadIdx.x & 15, tl = threadIdx.x >> 4;  // 16 column groups of 8 columns x 16 token lanes
+  const int j0 = blockIdx.x * 128 + cg * 8;
+  const int64_t t0 = (int64_t)blockIdx.y * rows_per_block + tl;
+  const int64_t t1 = min(T, (int64_t)(blockIdx.y + 1) * rows_per_block);
+  if (threadIdx.x < 128) best_lds[threadIdx.x] = 1;
+  __syncthreads();
+  int best[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+  for (int64_t t = t0; t < t1; t += 16) {
+    const i32x4 v = *(const i32x4*)(x + t * ld + j0);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const unsigned w = (unsigned)v[q];
+      best[2 * q] = max(best[2 * q], bf16_ee_if_nonzero(w & 0xFFFF));
+      best[2 * q + 1] = max(best[2 * q + 1], bf16_ee_if_nonzero(w >> 16));
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 8; q++) atomicMax(&best_lds[cg * 8 + q], best[q]);
+  __syncthreads();
+  if (threadIdx.x < 128) atomicMax(emax + blockIdx.x * 128 + threadIdx.x, best_lds[threadIdx.x]);
+}
+
+// workgroup = 128 features (4 row groups) x 64 tokens (2 k-steps): the tile goes through LDS, one thread then owns one
+// feature of one k-step
+__global__ __launch_bounds__(256) void i8_split_vec_kernel(const bf16_t* x, int64_t ld, int64_t T, int n, int nk, const int* emax,
+                                                           signed char* planes, int* deep_cnt, int* nz_cnt) {
+  __shared__ __attribute__((aligned(16))) bf16_t tile[64 * 128];
+  __shared__ int deep_lds[128], nz_lds[128];
+  const int f0 = blockIdx.x * 128;
+  const int kt0 = blockIdx.y * 2;
+  const int64_t tok0 = (int64_t)kt0 * KS;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int c = threadIdx.x + 256 * q;  // 16-byte chunk: token c / 16, columns (c % 16) * 8 ..
+    const int64_t t = tok0 + (c >> 4);
+    i32x4 v = (i32x4)0;
+    if (t < T) v = *(const i32x4*)(x + t * ld + f0 + (c & 15) * 8);
+    *(i32x4*)(tile + c * 8) = v;
+  }
+  if (threadIdx.x < 128) deep_lds[threadIdx.x] = nz_lds[threadIdx.x] = 0;
+  __syncthreads();
+  const int f = threadIdx.x & 127, ks = threadIdx.x >> 7;
+  const int kt = kt0 + ks;
+  const int E = emax[f0 + f];
+  const int64_t groups = n / 32;
+  const int G = (f0 + f) >> 5, r = f & 31;
+  int deep = 0, nz = 0;
+  if (kt < nk) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      unsigned dig[NP][4] = {};
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        int sig, ee;
+        bf16_parts(tile[(ks * 32 + h * 16 + q) * 128 + f], sig, ee);
+        const int sh = E - ee;
+        deep += (sig != 0 && sh >= DEEP_BINADES);
+        nz += (sig != 0);
+        long long N;
+        if (sh <= TOP_SHIFT) {
+          N = (long long)sig << (TOP_SHIFT - sh);
+        } else {
+          const int dn = sh - TOP_SHIFT;
+          const int mag = dn > 9 ? 0 : ((sig < 0 ? -sig : sig) + (1 << (dn - 1))) >> dn;
+          N = sig < 0 ? -mag : mag;
+        }
+#pragma unroll
+        for (int s2 = NP - 1; s2 >= 1; s2--) {
+          const int b = (int)((N + 128) & 255) - 128;
+          dig[s2][q >> 2] |= (unsigned)(b & 255) << (8 * (q & 3));
+          N = (N - b) >> 8;
+        }
+        dig[0][q >> 2] |= (unsigned)((int)N & 255) << (8 * (q & 3));
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < NP; s2++) {
+        signed char* piece = planes + ((s2 * groups + G) * (int64_t)nk + kt) * 1024;
+        *(i32x4*)(piece + h * 512 + r * 16) = (i32x4){(int)dig[s2][0], (int)dig[s2][1], (int)dig[s2][2], (int)dig[s2][3]};
+      }
+    }
+  }
+  if (deep) atomicAdd(&deep_lds[f], deep);
+  if (nz) atomicAdd(&nz_lds[f], nz);
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    if (deep_lds[threadIdx.x]) atomicAdd(deep_cnt + f0 + threadIdx.x, deep_lds[threadIdx.x]);
+    if (nz_lds[threadIdx.x]) atomicAdd(nz_cnt + f0 + threadIdx.x, nz_lds[threadIdx.x]);
+  }
+}
+
 // flag bit 0: in some column more than 1 / 64 of the nonzero elements are deep (five planes are not enough); bit 1: more
 // than 1 / 4 (six are not either), or the column holds an Inf / NaN, which only the fp64 kernel propagates the way the
 // reference does.  The share is taken over the NONZERO elements: zeros add nothing to sigma, so a sparse column's accuracy is
@@ -323,13 +423,22 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
   int* flag = nz_cnt + n;
   void* fb_ws = (char*)emax + align_up((size_t)(3 * n + 4) * sizeof(int), 256);
   MDG_HIP(hipMemsetAsync(emax, 0, (size_t)(3 * n + 4) * sizeof(int), st));
+  const bool vec = ((uintptr_t)x % 16 == 0) && (ld % 8 == 0);
   {
     const int64_t rows_per_block = 2048;
-    const dim3 grid((unsigned)ceil_div(n, 64), (unsigned)ceil_div(n_tokens, rows_per_block));
-    hipLaunchKernelGGL(i8_colmax_kernel, grid, dim3(256), 0, st, (const bf16_t*)x, ld, n_tokens, n, rows_per_block, emax);
+    if (vec)
+      hipLaunchKernelGGL(i8_colmax_vec_kernel, dim3((unsigned)(n / 128), (unsigned)ceil_div(n_tokens, rows_per_block)), dim3(256), 0,
+                         st, (const bf16_t*)x, ld, n_tokens, rows_per_block, emax);
+    else
+      hipLaunchKernelGGL(i8_colmax_kernel, dim3((unsigned)ceil_div(n, 64), (unsigned)ceil_div(n_tokens, rows_per_block)), dim3(256),
+                         0, st, (const bf16_t*)x, ld, n_tokens, n, rows_per_block, emax);
   }
-  hipLaunchKernelGGL(i8_split_kernel, dim3((unsigned)(n / 32), (unsigned)ceil_div(nk, SPLIT_STEPS)), dim3(256), 0, st, (const bf16_t*)x, ld,
-                     n_tokens, n, nk, emax, planes, deep_cnt, nz_cnt);
+  if (vec)
+    hipLaunchKernelGGL(i8_split_vec_kernel, dim3((unsigned)(n / 128), (unsigned)ceil_div(nk, 2)), dim3(256), 0, st,
+                       (const bf16_t*)x, ld, n_tokens, n, nk, emax, planes, deep_cnt, nz_cnt);
+  else
+    hipLaunchKernelGGL(i8_split_kernel, dim3((unsigned)(n / 32), (unsigned)ceil_div(nk, SPLIT_STEPS)), dim3(256), 0, st,
+                       (const bf16_t*)x, ld, n_tokens, n, nk, emax, planes, deep_cnt, nz_cnt);
   hipLaunchKernelGGL(i8_depth_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, deep_cnt, nz_cnt, emax, n, flag);
   MDG_LAUNCH_CHECK();
   int depth = 0;

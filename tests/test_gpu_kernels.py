@@ -635,6 +635,14 @@ def test_cov_i8_reads_a_column_slice_in_place(ops, dev):
     O.cov_accum_tokens(ref, X.cpu())
     low = torch.tril(torch.ones(384, 384, dtype=torch.bool))
     assert ((S.cpu() - ref)[low].abs().max() / ref.abs().max()).item() < 1e-12
+    # rows that are not 16-byte addressable (odd pitch, 6-byte offset): the element-wise passes
+    odd = acts(gen, 900, 653).to(dev)
+    Y = odd[:, 3:3 + 384]
+    S2 = torch.zeros(384, 384, dtype=F64, device=dev)
+    assert ops.cov_accum_i8(S2, Y) == 5
+    ref2 = torch.zeros(384, 384, dtype=F64)
+    O.cov_accum_tokens(ref2, Y.cpu())
+    assert ((S2.cpu() - ref2)[low].abs().max() / ref2.abs().max()).item() < 1e-12
 
 
 def test_cov_i8_randomised_shapes_and_scales(ops, dev):
