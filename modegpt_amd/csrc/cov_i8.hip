@@ -248,11 +248,20 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
                                    0, 0);
 }
 
-// LDS ring depth: 4 x 30 KB / 4 x 36 KB.  3 and 5 measured the same (the kernel is not short of look-ahead).
-template <int P> constexpr int ring_depth() { return 4; }
+// Occupancy and LDS ring depth per route.  P = 5: TWO workgroups per CU (2 waves per SIMD, <= 256 registers each: 160
+// accumulators + 45 fragment registers fit) with a 2-stage ring (2 x 30 KB each) -- while one workgroup sits in its stage
+// barrier / LDS fragment reads the other one's MFMAs run (45.8 -> 40.5 ms per call against one workgroup with a 4-stage
+// ring).  P = 6: one workgroup per CU, 4 x 36 KB (two per CU measured 96 ms against 61).
+#ifndef MDG_I8_OCC5
+#define MDG_I8_OCC5 2
+#endif
+#ifndef MDG_I8_SB5
+#define MDG_I8_SB5 4
+#endif
+template <int P> constexpr int ring_depth() { return P == 5 ? (MDG_I8_OCC5 == 2 ? 2 : 4) : 4; }
 
 template <int P>  // planes used: 5 or 6
-__global__ __launch_bounds__(256, 1) void i8_syrk_kernel(SyrkArgs a) {
+__global__ __launch_bounds__(256, P == 5 ? MDG_I8_OCC5 : 1) void i8_syrk_kernel(SyrkArgs a) {
   constexpr int RING = ring_depth<P>();
   constexpr int STAGE_BYTES = P * (PA + PB);       // 30 / 36 KB
   constexpr int PIECES = 6 * P;                    // 1 KB pieces per stage
@@ -270,7 +279,7 @@ __global__ __launch_bounds__(256, 1) void i8_syrk_kernel(SyrkArgs a) {
 #ifndef MDG_I8_SB6
 #define MDG_I8_SB6 0
 #endif
-  constexpr int SI = P == 5 ? 4 : MDG_I8_SB6;   // super-block: SI x 2 SI tiles; 0 = plain row-major order
+  constexpr int SI = P == 5 ? MDG_I8_SB5 : MDG_I8_SB6;   // super-block: SI x 2 SI tiles; 0 = plain row-major order
   if (SI > 0) {
     constexpr int TPS = SI * 2 * SI;            // tiles per super-block
     const int w = blockIdx.x;
@@ -290,6 +299,8 @@ __global__ __launch_bounds__(256, 1) void i8_syrk_kernel(SyrkArgs a) {
     bj = tile - bi * (bi + 1);
   }
   if (bi >= a.n / TI || bj > 2 * bi + 1) return;
+  // (the wave index deliberately NOT through readfirstlane: with a provably uniform wave index hipcc 7.2 makes the staging
+  // code scalar but puts an s_waitcnt vmcnt(0) in front of every LDS-DMA load, which serialises the 4-stage ring: 61 -> 165 ms)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wr = wave >> 1, wc = wave & 1;
   const int64_t groups = a.n / 32;
@@ -454,7 +465,7 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
   if (const char* ev = getenv("MDG_I8_PLANES"))  // experiment knob (scripts/bench_kernels.py): force the 6-plane product
     if (atoi(ev) == 6) planes_used = 6;
   const size_t lds = (size_t)(planes_used == 5 ? ring_depth<5>() : ring_depth<6>()) * planes_used * (PA + PB);
-  const int si = planes_used == 5 ? 4 : MDG_I8_SB6;                          // super-block rows (see the kernel); 0 = row-major
+  const int si = planes_used == 5 ? MDG_I8_SB5 : MDG_I8_SB6;                          // super-block rows (see the kernel); 0 = row-major
   const int sr = si ? (rb + si - 1) / si : 0, nsb = sr * (sr + 1) / 2;       // super-block rows, super-blocks
   const dim3 grid(si ? (unsigned)((nsb + 7) / 8 * 8 * (2 * si * si)) : (unsigned)(rb * (rb + 1)));
   if (planes_used == 6) MDG_HIP(hipFuncSetAttribute((const void*)i8_syrk_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
