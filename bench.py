@@ -268,7 +268,9 @@ def main():
             "routes": dict(ops.I8_STATS),
             "note": "sigma_x goes through the same kernel; sigma_q / sigma_k (1.4 % of the work) and any batch whose columns the "
                     "per-column depth statistic finds too heavy-tailed for six planes go through the v_mfma_f64 kernel (--cov-mode f64 runs everything there: "
-                    "0.909 of the fp64 peak, DESIGN.md section 7)"}
+                    "0.909 of the fp64 peak, DESIGN.md section 7)",
+            "power_note": "while this kernel loops the device sits at its power cap (rocm-smi: 1330 W, sclk 1.94 GHz instead of 2.4; "
+                          "scripts/probes/i8_clock_power.py): at that clock the int8 pipe peaks at 4.0 POP/s; `peak` above is the guide's 2.4 GHz figure"}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         li, tensors, mask, covs = last
         gpu_out = dict(tensors)

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256, P == 5 ? MDG_I8_OCC5 : 1) void i8_syrk_kernel(
   // P = 5, XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2, so workgroup w belongs to
   // XCD w % 8 and is the (w / 8)-th one there.  The tiles are grouped into super-blocks of 4 x 8 tiles (512 x 512 features:
   // 32 tiles = the 32 CUs of an XCD); a super-block lives on ONE XCD, so per k-step its tiles pull 5 x (512 + 512) x 32 B of
-  // distinct panel rows through that L2 instead of 32 x 30 KB (FETCH_SIZE 231 -> 132 GB per launch, 47.7 -> 44.8 ms).
+  // distinct panel rows through that L2 instead of 32 x 30 KB (FETCH_SIZE 231 -> 132 GB per launch, 47.7 -> 44.8 ms with one workgroup per CU; with two the order matters less, 41.9 -> 39.7 ms).
   // Super-blocks (R, C), C <= R, cover the lower region; tiles of a diagonal super-block that lie above it exit at once.
   // P = 6 keeps the plain row-major tile order: there every XCD-pinned grouping tried (1 x 2, 2 x 4, 4 x 8 tiles, build flag
   // MDG_I8_SB6) measured 84 - 87 ms against 60.8 ms row-major; not understood yet (PMC: waves parked 52 % of the time).
