@@ -35,9 +35,9 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int NP = 6;            // digit planes written by the split pass; the product kernel uses the top 5 or all 6
-constexpr int TI = 128, TJ = 64; // output tile: TI rows of I x TJ rows of J
+constexpr int TI = 128;           // output tile rows (rows of the I operand); its width TJ is 64 or 128, see i8_syrk_kernel
 constexpr int KS = 32;           // tokens per k-step (one v_mfma_i32_32x32x32_i8)
-constexpr int PA = TI * KS, PB = TJ * KS;
+constexpr int PA = TI * KS;      // bytes of one plane of the I operand in a stage
 constexpr int FLUSH_STEPS = 512;  // 16384 tokens: (k + 1) * 2^14 * 16384 < 2^31 for every class k <= 5
 constexpr int TOP_SHIFT = 8 * NP - 10;  // 38: the column maximum's significand sits below bit 46 of the 48-bit integer
 constexpr int DEEP_BINADES = 10;  // an element is "deep" when its exponent is at least this far below the column maximum
@@ -248,24 +248,46 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
                                    0, 0);
 }
 
-// Occupancy and LDS ring depth per route.  P = 5: TWO workgroups per CU (2 waves per SIMD, <= 256 registers each: 160
-// accumulators + 45 fragment registers fit) with a 2-stage ring (2 x 30 KB each) -- while one workgroup sits in its stage
-// barrier / LDS fragment reads the other one's MFMAs run (45.8 -> 40.5 ms per call against one workgroup with a 4-stage
-// ring).  P = 6: one workgroup per CU, 4 x 36 KB (two per CU measured 96 ms against 61).
+// Shape, occupancy and LDS ring per route.
+//   P = 5, NW = 8 (default): 128 x 128 tile worked by 8 waves (one workgroup of 512 threads = 2 waves per SIMD, <= 256 registers
+//     each: 160 accumulators + fragments fit), 2-stage ring of 40 KB stages -- 40 KB of L2->LDS traffic per k-step for 16384
+//     outputs where two 128 x 64 tiles move 60 KB.  The kernel is power-capped, so bytes moved per MFMA
+//     is what counts: probe (scripts/probes/i8_planes_syrk.hip, random bytes) 44.2 ms against 48.5 ms for the next shape.
+//   P = 5, NW = 4 (-DMDG_I8_WIDE5=0): 128 x 64 tile, 4 waves, TWO workgroups per CU with a 2-stage ring (2 x 30 KB each) --
+//     while one workgroup sits in its stage barrier / LDS fragment reads the other one's MFMAs run (45.8 -> 40.5 ms per call
+//     against one workgroup with a 4-stage ring).
+//   P = 6: 128 x 64 tile, 4 waves, one workgroup per CU (192 accumulators), 4 x 36 KB ring (two per CU measured 96 ms against 61).
+#ifndef MDG_I8_WIDE6
+#define MDG_I8_WIDE6 1
+#endif
+#ifndef MDG_I8_WIDE5
+#define MDG_I8_WIDE5 1
+#endif
 #ifndef MDG_I8_OCC5
 #define MDG_I8_OCC5 2
 #endif
 #ifndef MDG_I8_SB5
 #define MDG_I8_SB5 4
 #endif
-template <int P> constexpr int ring_depth() { return P == 5 ? (MDG_I8_OCC5 == 2 ? 2 : 4) : 4; }
+#ifndef MDG_I8_SB6
+#define MDG_I8_SB6 2
+#endif
+#ifndef MDG_I8_RING8
+#define MDG_I8_RING8 2
+#endif
+template <int P, int NW> constexpr int ring_depth() { return NW == 8 ? MDG_I8_RING8 : (P == 5 ? (MDG_I8_OCC5 == 2 ? 2 : 4) : 4); }
 
-template <int P>  // planes used: 5 or 6
-__global__ __launch_bounds__(256, P == 5 ? MDG_I8_OCC5 : 1) void i8_syrk_kernel(SyrkArgs a) {
-  constexpr int RING = ring_depth<P>();
-  constexpr int STAGE_BYTES = P * (PA + PB);       // 30 / 36 KB
-  constexpr int PIECES = 6 * P;                    // 1 KB pieces per stage
-  constexpr int PER_WAVE_MIN = PIECES / 4;         // every wave issues at least this many LDS-DMA loads per stage
+template <int P, int NW>  // planes used: 5 or 6; waves: 4 (128 x 64 tile) or 8 (128 x 128 tile)
+__global__ __launch_bounds__(64 * NW, (P == 5 && NW == 4) ? MDG_I8_OCC5 : 1) void i8_syrk_kernel(SyrkArgs a) {
+  constexpr int RING = ring_depth<P, NW>();
+  constexpr int WB = (NW == 8 && P == 6) ? 1 : 2;  // 32-row blocks of a wave tile: 64 x 32, or 32 x 32 (96 accumulators at P = 6)
+  constexpr int TJ = (NW == 8 && WB == 2) ? 128 : 64;  // tile columns (rows of the J operand); waves are laid out (128 / 32 WB) x (TJ / 32)
+  constexpr int PB = TJ * KS;
+  constexpr int GA = TI / 32, GB = TJ / 32;        // 32-row groups (1 KB pieces per plane and stage) of the two operands
+  constexpr int WCOLS = TJ / 32;
+  constexpr int STAGE_BYTES = P * (PA + PB);       // 30 / 36 KB (40 KB for the 128 x 128 tile)
+  constexpr int PIECES = (GA + GB) * P;            // 1 KB pieces per stage
+  constexpr int PER_WAVE_MIN = PIECES / NW;        // every wave issues at least this many LDS-DMA loads per stage
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   // Tile (bi, bj): bi = 128-row block, bj = 64-row block, lower region bj <= 2 bi + 1.
   // P = 5, XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2, so workgroup w belongs to
@@ -276,11 +298,28 @@ __global__ __launch_bounds__(256, P == 5 ? MDG_I8_OCC5 : 1) void i8_syrk_kernel(
   // P = 6 keeps the plain row-major tile order: there every XCD-pinned grouping tried (1 x 2, 2 x 4, 4 x 8 tiles, build flag
   // MDG_I8_SB6) measured 84 - 87 ms against 60.8 ms row-major; not understood yet (PMC: waves parked 52 % of the time).
   int bi, bj;
-#ifndef MDG_I8_SB6
-#define MDG_I8_SB6 0
-#endif
   constexpr int SI = P == 5 ? MDG_I8_SB5 : MDG_I8_SB6;   // super-block: SI x 2 SI tiles; 0 = plain row-major order
-  if (SI > 0) {
+  if (TJ == 128) {
+    // square 128 x 128 tiles, bj <= bi; super-blocks of SI x SI tiles dealt to the XCDs as below (SI = 0: row-major)
+    if (SI > 0) {
+      constexpr int TPS = SI * SI;
+      const int w = blockIdx.x;
+      const int q = w >> 3;
+      const int sb = q / TPS * 8 + (w & 7), t_in = q % TPS;
+      int R = (int)((sqrtf(8.f * sb + 1.f) - 1.f) * 0.5f);
+      while ((R + 1) * (R + 2) / 2 <= sb) R++;
+      while (R * (R + 1) / 2 > sb) R--;
+      const int C = sb - R * (R + 1) / 2;
+      bi = SI * R + t_in / SI;
+      bj = SI * C + t_in % SI;
+    } else {
+      const int tile = blockIdx.x;  // bi (bi + 1) / 2 tiles precede row bi
+      bi = (int)((sqrtf(8.f * tile + 1.f) - 1.f) * 0.5f);
+      while ((bi + 1) * (bi + 2) / 2 <= tile) bi++;
+      while (bi * (bi + 1) / 2 > tile) bi--;
+      bj = tile - bi * (bi + 1) / 2;
+    }
+  } else if (SI > 0) {
     constexpr int TPS = SI * 2 * SI;            // tiles per super-block
     const int w = blockIdx.x;
     const int q = w >> 3;
@@ -298,23 +337,23 @@ __global__ __launch_bounds__(256, P == 5 ? MDG_I8_OCC5 : 1) void i8_syrk_kernel(
     while (bi * (bi + 1) > tile) bi--;
     bj = tile - bi * (bi + 1);
   }
-  if (bi >= a.n / TI || bj > 2 * bi + 1) return;
+  if (bi >= a.n / TI || bj * TJ > bi * TI + TI - 1) return;
   // (the wave index deliberately NOT through readfirstlane: with a provably uniform wave index hipcc 7.2 makes the staging
   // code scalar but puts an s_waitcnt vmcnt(0) in front of every LDS-DMA load, which serialises the 4-stage ring: 61 -> 165 ms)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WCOLS, wc = wave % WCOLS;
   const int64_t groups = a.n / 32;
   const int nk = a.nk;
 
-  // staging: 6 P pieces of 1 KB per stage (A: P planes x 4 row groups, B: P planes x 2); wave w issues pieces w, w + 4, ...
+  // staging: (GA + GB) P pieces of 1 KB per stage (A: P planes x 4 row groups, B: P planes x 2 or 4); wave w issues pieces w, w + NW, ...
   auto issue_stage = [&](int kt, int buf) {
 #pragma unroll
-    for (int q = 0; q < (PIECES + 3) / 4; q++) {
-      const int p = wave + 4 * q;
+    for (int q = 0; q < (PIECES + NW - 1) / NW; q++) {
+      const int p = wave + NW * q;
       if (p < PIECES) {
-        const bool isA = p < 4 * P;
-        const int pp = isA ? p : p - 4 * P;
-        const int s = isA ? pp >> 2 : pp >> 1, g = isA ? pp & 3 : pp & 1;
+        const bool isA = p < GA * P;
+        const int pp = isA ? p : p - GA * P;
+        const int s = isA ? pp / GA : pp / GB, g = isA ? pp % GA : pp % GB;
         const int64_t G = (isA ? bi * (TI / 32) : bj * (TJ / 32)) + g;
         const signed char* src = a.planes + ((s * groups + G) * (int64_t)nk + kt) * 1024 + lane * 16;
         unsigned char* dst = lds + buf * STAGE_BYTES + (isA ? s * PA : P * PA + s * PB) + g * 1024;
@@ -323,11 +362,11 @@ __global__ __launch_bounds__(256, P == 5 ? MDG_I8_OCC5 : 1) void i8_syrk_kernel(
     }
   };
 
-  i32x16 acc[P][2];
+  i32x16 acc[P][WB];
 #pragma unroll
   for (int k = 0; k < P; k++)
 #pragma unroll
-    for (int b = 0; b < 2; b++) acc[k][b] = (i32x16)0;
+    for (int b = 0; b < WB; b++) acc[k][b] = (i32x16)0;
 
   // sigma[i][j] += 2^(E_i + E_j - 344) * sum_k acc_k 256^(10 - k)  =  (sum_k acc_k 2^(80 - 8k)) * 2^(E_i - 172) * 2^(E_j - 172)
   auto flush = [&]() {
@@ -336,18 +375,18 @@ __global__ __launch_bounds__(256, P == 5 ? MDG_I8_OCC5 : 1) void i8_syrk_kernel(
     // all 32 read-modify-writes of a lane: loads first (independent, in flight together), then the arithmetic and the stores;
     // written as `*p += v` one by one the compiler must keep them in order and every element pays a full memory round trip
 #pragma unroll
-    for (int b = 0; b < 2; b++) {  // one 32-row block at a time: 16 loads in flight per lane, and no spills
+    for (int b = 0; b < WB; b++) {  // one 32-row block at a time: 16 loads in flight per lane, and no spills
       double old[16];
       int er[16];
 #pragma unroll
       for (int reg = 0; reg < 16; reg++) {
-        const int row = bi * TI + wr * 64 + b * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        const int row = bi * TI + wr * 32 * WB + b * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
         old[reg] = a.sigma[(int64_t)row * a.ld_sigma + col];
         er[reg] = a.emax[row];
       }
 #pragma unroll
       for (int reg = 0; reg < 16; reg++) {
-        const int row = bi * TI + wr * 64 + b * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        const int row = bi * TI + wr * 32 * WB + b * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
         double v = 0.;
 #pragma unroll
         for (int k = P - 1; k >= 0; k--) v += ldexp((double)acc[k][b][reg], 80 - 8 * k);
@@ -357,7 +396,7 @@ __global__ __launch_bounds__(256, P == 5 ? MDG_I8_OCC5 : 1) void i8_syrk_kernel(
 #pragma unroll
     for (int k = 0; k < P; k++)
 #pragma unroll
-      for (int b = 0; b < 2; b++) acc[k][b] = (i32x16)0;
+      for (int b = 0; b < WB; b++) acc[k][b] = (i32x16)0;
     // the stores above share the VM counter with the LDS-DMA loads and may retire out of order with them: drain, so that
     // the counted wait of the next stage again counts LDS-DMA loads only
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -378,11 +417,11 @@ __global__ __launch_bounds__(256, P == 5 ? MDG_I8_OCC5 : 1) void i8_syrk_kernel(
       if (kt + RING - 1 < nk) issue_stage(kt + RING - 1, (kt + RING - 1) % RING);
       const unsigned char* base = lds + buf * STAGE_BYTES;
       const int r = lane & 31, h = lane >> 5;
-      i32x4 fa[P][2], fb[P];
+      i32x4 fa[P][WB], fb[P];
 #pragma unroll
       for (int s = 0; s < P; s++) {
 #pragma unroll
-        for (int b = 0; b < 2; b++) fa[s][b] = *(const i32x4*)(base + s * PA + (wr * 2 + b) * 1024 + h * 512 + r * 16);
+        for (int b = 0; b < WB; b++) fa[s][b] = *(const i32x4*)(base + s * PA + (wr * WB + b) * 1024 + h * 512 + r * 16);
         fb[s] = *(const i32x4*)(base + P * PA + s * PB + wc * 1024 + h * 512 + r * 16);
       }
 #pragma unroll
@@ -390,7 +429,7 @@ __global__ __launch_bounds__(256, P == 5 ? MDG_I8_OCC5 : 1) void i8_syrk_kernel(
 #pragma unroll
         for (int t = 0; t < P - s; t++)
 #pragma unroll
-          for (int b = 0; b < 2; b++)
+          for (int b = 0; b < WB; b++)
             acc[s + t][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s][b], fb[t], acc[s + t][b], 0, 0, 0);
     }
     flush();
@@ -464,15 +503,20 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
   int planes_used = (depth & 1) ? 6 : 5;
   if (const char* ev = getenv("MDG_I8_PLANES"))  // experiment knob (scripts/bench_kernels.py): force the 6-plane product
     if (atoi(ev) == 6) planes_used = 6;
-  const size_t lds = (size_t)(planes_used == 5 ? ring_depth<5>() : ring_depth<6>()) * planes_used * (PA + PB);
-  const int si = planes_used == 5 ? MDG_I8_SB5 : MDG_I8_SB6;                          // super-block rows (see the kernel); 0 = row-major
+  constexpr int NW5 = MDG_I8_WIDE5 ? 8 : 4;                                  // waves of the 5-plane kernel: 128 x 128 or 128 x 64 tiles
+  constexpr int NW6 = MDG_I8_WIDE6 ? 8 : 4;                                  // 6 planes: 8 waves of 32 x 32 or 4 of 64 x 32 on a 128 x 64 tile
+  const bool wide = planes_used == 5 && NW5 == 8;
+  const int tj = wide ? 128 : 64;
+  const size_t lds = (size_t)(planes_used == 5 ? ring_depth<5, NW5>() : ring_depth<6, NW6>()) * planes_used * (PA + tj * KS);
+  const int si = planes_used == 5 ? MDG_I8_SB5 : MDG_I8_SB6;                 // super-block rows (see the kernel); 0 = row-major
   const int sr = si ? (rb + si - 1) / si : 0, nsb = sr * (sr + 1) / 2;       // super-block rows, super-blocks
-  const dim3 grid(si ? (unsigned)((nsb + 7) / 8 * 8 * (2 * si * si)) : (unsigned)(rb * (rb + 1)));
-  if (planes_used == 6) MDG_HIP(hipFuncSetAttribute((const void*)i8_syrk_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  else MDG_HIP(hipFuncSetAttribute((const void*)i8_syrk_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int tps = wide ? si * si : 2 * si * si;                              // tiles per super-block
+  const dim3 grid(si ? (unsigned)((nsb + 7) / 8 * 8 * tps) : (unsigned)(wide ? rb * (rb + 1) / 2 : rb * (rb + 1)));
+  if (planes_used == 6) MDG_HIP(hipFuncSetAttribute((const void*)i8_syrk_kernel<6, NW6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  else MDG_HIP(hipFuncSetAttribute((const void*)i8_syrk_kernel<5, NW5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (ev_start) MDG_HIP(hipEventRecord((hipEvent_t)ev_start, st));
-  if (planes_used == 6) hipLaunchKernelGGL(i8_syrk_kernel<6>, grid, dim3(256), lds, st, a);
-  else hipLaunchKernelGGL(i8_syrk_kernel<5>, grid, dim3(256), lds, st, a);
+  if (planes_used == 6) hipLaunchKernelGGL((i8_syrk_kernel<6, NW6>), grid, dim3(64 * NW6), lds, st, a);
+  else hipLaunchKernelGGL((i8_syrk_kernel<5, NW5>), grid, dim3(64 * NW5), lds, st, a);
   MDG_LAUNCH_CHECK();
   if (ev_stop) MDG_HIP(hipEventRecord((hipEvent_t)ev_stop, st));
   if (used_i8) *used_i8 = planes_used;

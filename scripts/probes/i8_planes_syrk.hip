@@ -17,12 +17,35 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 #define S_PLANES 5
 #endif
 constexpr int S = S_PLANES;   // digit planes (-DS_PLANES=6 for the 21-pair variant)
+// Variants (all 64 x 32 wave tiles of v_mfma_i32_32x32x32_i8):
+//   default                  4 waves, 128 x 64 tile, one workgroup per CU, 4-stage ring   (the first product kernel)
+//   -DOCC=2 -DNBUF_=2        4 waves, 128 x 64 tile, two workgroups per CU, 2-stage ring   (the 5-plane product kernel now)
+//   -DWAVES=8 -DNBUF_=3      8 waves (2 per SIMD), 128 x 128 tile, one workgroup of 512 threads, 3-stage ring: 40 KB per stage
+//                            for 16384 outputs instead of 2 x 30 KB -- a third fewer L2->LDS bytes per MFMA
+#ifndef WAVES
+#define WAVES 4
+#endif
+#ifndef OCC
+#define OCC 1
+#endif
+#ifndef WBLK
+#define WBLK 2      // 32-row blocks per wave along I: 2 = 64 x 32 wave tile; 1 = 32 x 32 (8 waves as 4 x 2 over a 128 x 64 tile:
+#endif              //   -DS_PLANES=6 -DWAVES=8 -DWBLK=1 -DNBUF_=4 -- 96 accumulators, two waves per SIMD for the 6-plane route)
+#ifndef NBUF_
+#define NBUF_ 4
+#endif
+constexpr int NW = WAVES;
 constexpr int TILE = 128;     // workgroup tile: TILE rows of I x TJ rows of J (features)
-constexpr int TJ = 64;
+constexpr int TJ = (NW == 8 && WBLK == 2) ? 128 : 64;
+constexpr int WCOLS = TJ / 32;               // waves along J
 constexpr int BK = 32;        // tokens per stage = one MFMA k-step
 constexpr int PANEL_A = TILE * BK, PANEL_B = TJ * BK;   // bytes of one plane of an operand in a stage
 constexpr int STAGE = S * (PANEL_A + PANEL_B);          // 30 KB
-constexpr int NBUF = 4;                      // LDS ring: three stages in flight behind the one being consumed
+constexpr int NBUF = NBUF_;                  // LDS ring: NBUF - 1 stages in flight behind the one being consumed
+constexpr int GA = TILE / 32, GB = TJ / 32;  // 32-row groups per operand
+constexpr int PIECES = S * (GA + GB);
+
+__host__ __device__ inline int tiles_of(int n) { return TJ == 64 ? (n / TILE) * (n / TILE + 1) : (n / TILE) * (n / TILE + 1) / 2; }
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l,
@@ -32,16 +55,24 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 // planes: [S][n][ldt] int8;  out (optional): [tiles][S][TILE][TJ] int32, tile index = bi*(bi+1) + bj  (bj <= 2 bi + 1)
 // 4 waves as 2 x 2, wave tile 64 x 32 = 2 x 1 MFMA blocks, 5 classes -> 160 accumulator registers (the 64 x 64 wave tile's
 // 320 do not fit the 256 AGPRs and the compiler shuffles 200 registers per stage)
-__global__ __launch_bounds__(256, 1) void planes_syrk(const int8_t* __restrict__ planes, int n, int T, int64_t ldt, int* out,
+__global__ __launch_bounds__(64 * NW, OCC) void planes_syrk(const int8_t* __restrict__ planes, int n, int T, int64_t ldt, int* out,
                                                       int* sink) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tile = blockIdx.x;
-  int bi = (int)((sqrtf(4.f * tile + 1.f) - 1.f) * 0.5f);
-  while ((bi + 1) * (bi + 2) <= tile) bi++;
-  while (bi * (bi + 1) > tile) bi--;
-  const int bj = tile - bi * (bi + 1);
+  int bi, bj;
+  if (TJ == 64) {
+    bi = (int)((sqrtf(4.f * tile + 1.f) - 1.f) * 0.5f);
+    while ((bi + 1) * (bi + 2) <= tile) bi++;
+    while (bi * (bi + 1) > tile) bi--;
+    bj = tile - bi * (bi + 1);
+  } else {
+    bi = (int)((sqrtf(8.f * tile + 1.f) - 1.f) * 0.5f);
+    while ((bi + 1) * (bi + 2) / 2 <= tile) bi++;
+    while (bi * (bi + 1) / 2 > tile) bi--;
+    bj = tile - bi * (bi + 1) / 2;
+  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WCOLS, wc = wave % WCOLS;
   const int64_t plane_stride = (int64_t)n * ldt;
 
   // staging: 30 pieces of 1 KB per stage (A: 5 planes x 4 row groups, B: 5 planes x 2); wave w issues pieces w, w+4, ...
@@ -49,12 +80,12 @@ __global__ __launch_bounds__(256, 1) void planes_syrk(const int8_t* __restrict__
   // an MFMA k-half read 512 contiguous bytes
   auto issue_stage = [&](int kt, int buf) {
 #pragma unroll
-    for (int q = 0; q < (6 * S + 3) / 4; q++) {
-      const int p = wave + 4 * q;
-      if (p < 6 * S) {
-        const bool isA = p < 4 * S;
-        const int pp = isA ? p : p - 4 * S;
-        const int s = isA ? pp >> 2 : pp >> 1, g = isA ? pp & 3 : pp & 1;
+    for (int q = 0; q < (PIECES + NW - 1) / NW; q++) {
+      const int p = wave + NW * q;
+      if (p < PIECES) {
+        const bool isA = p < GA * S;
+        const int pp = isA ? p : p - GA * S;
+        const int s = isA ? pp / GA : pp / GB, g = isA ? pp % GA : pp % GB;
         // blocked plane layout written by the split pass: [plane][row group of 32][k-step][half][row][16 B] -- a piece is
         // 1 KB contiguous in memory (8 full cache lines per wave instruction instead of 32 quarter-used ones)
         const int64_t G = (isA ? bi * (TILE / 32) : bj * (TJ / 32)) + g;
@@ -65,11 +96,11 @@ __global__ __launch_bounds__(256, 1) void planes_syrk(const int8_t* __restrict__
     }
   };
 
-  i32x16 acc[S][2];
+  i32x16 acc[S][WBLK];
 #pragma unroll
   for (int k = 0; k < S; k++)
 #pragma unroll
-    for (int a = 0; a < 2; a++) acc[k][a] = (i32x16)0;
+    for (int a = 0; a < WBLK; a++) acc[k][a] = (i32x16)0;
 
   const int nk = T / BK;
   for (int p = 0; p < NBUF - 1 && p < nk; p++) issue_stage(p, p);
@@ -77,18 +108,18 @@ __global__ __launch_bounds__(256, 1) void planes_syrk(const int8_t* __restrict__
     const int buf = kt % NBUF;
     // waves 0,1 issue 8 glds per stage, waves 2,3 issue 7; stages kt+1, kt+2 may stay in flight: at most 14 outstanding
     // retires stage kt on every wave (the tail drains everything)
-    if (kt + NBUF - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (6 * S / 4)) : "memory");
+    if (kt + NBUF - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * (PIECES / NW)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (kt + NBUF - 1 < nk) issue_stage(kt + NBUF - 1, (kt + NBUF - 1) % NBUF);
     const unsigned char* base = lds + buf * STAGE;
     const int r = lane & 31, h = lane >> 5;
-    i32x4 fa[S][2], fb[S];
+    i32x4 fa[S][WBLK], fb[S];
 #pragma unroll
     for (int s = 0; s < S; s++) {
 #pragma unroll
-      for (int blk = 0; blk < 2; blk++)
-        fa[s][blk] = *(const i32x4*)(base + s * PANEL_A + (wr * 2 + blk) * 1024 + h * 512 + r * 16);
+      for (int blk = 0; blk < WBLK; blk++)
+        fa[s][blk] = *(const i32x4*)(base + s * PANEL_A + (wr * WBLK + blk) * 1024 + h * 512 + r * 16);
       fb[s] = *(const i32x4*)(base + S * PANEL_A + s * PANEL_B + wc * 1024 + h * 512 + r * 16);
     }
 #pragma unroll
@@ -96,7 +127,7 @@ __global__ __launch_bounds__(256, 1) void planes_syrk(const int8_t* __restrict__
 #pragma unroll
       for (int t = 0; t < S - s; t++)
 #pragma unroll
-        for (int a = 0; a < 2; a++)
+        for (int a = 0; a < WBLK; a++)
           acc[s + t][a] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s][a], fb[t], acc[s + t][a], 0, 0, 0);
   }
 
@@ -105,10 +136,10 @@ __global__ __launch_bounds__(256, 1) void planes_syrk(const int8_t* __restrict__
 #pragma unroll
     for (int k = 0; k < S; k++)
 #pragma unroll
-      for (int a = 0; a < 2; a++)
+      for (int a = 0; a < WBLK; a++)
 #pragma unroll
         for (int reg = 0; reg < 16; reg++) {
-          const int row = wr * 64 + a * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+          const int row = wr * 32 * WBLK + a * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
           const int col = wc * 32 + (lane & 31);
           o[(k * TILE + row) * TJ + col] = acc[k][a][reg];
         }
@@ -117,7 +148,7 @@ __global__ __launch_bounds__(256, 1) void planes_syrk(const int8_t* __restrict__
 #pragma unroll
     for (int k = 0; k < S; k++)
 #pragma unroll
-      for (int a = 0; a < 2; a++)
+      for (int a = 0; a < WBLK; a++)
 #pragma unroll
         for (int reg = 0; reg < 16; reg++) x ^= acc[k][a][reg];
     if (x == 0x7fffffff) sink[0] = x;
@@ -134,7 +165,7 @@ int main() {
     srand(1);
     for (auto& v : h) v = (int8_t)(rand() % 256 - 128);
     int8_t* d; int* out; int* sink;
-    const int tiles = (n / TILE) * (n / TILE + 1);
+    const int tiles = tiles_of(n);
     CK(hipMalloc(&d, h.size())); CK(hipMalloc(&out, (size_t)tiles * S * TILE * TJ * 4)); CK(hipMalloc(&sink, 4));
     {
       std::vector<int8_t> blk(h.size());
@@ -147,14 +178,15 @@ int main() {
       CK(hipMemcpy(d, blk.data(), blk.size(), hipMemcpyHostToDevice));
     }
     CK(hipFuncSetAttribute((const void*)planes_syrk, hipFuncAttributeMaxDynamicSharedMemorySize, NBUF * STAGE));
-    hipLaunchKernelGGL(planes_syrk, dim3(tiles), dim3(256), NBUF * STAGE, 0, d, n, T, (int64_t)T, out, sink);
+    hipLaunchKernelGGL(planes_syrk, dim3(tiles), dim3(64 * NW), NBUF * STAGE, 0, d, n, T, (int64_t)T, out, sink);
     CK(hipDeviceSynchronize());
     std::vector<int> got((size_t)tiles * S * TILE * TJ);
     CK(hipMemcpy(got.data(), out, got.size() * 4, hipMemcpyDeviceToHost));
     long bad = 0;
     for (int tile = 0; tile < tiles && bad < 5; tile++) {
-      int bi = 0; while ((bi + 1) * (bi + 2) <= tile) bi++;
-      const int bj = tile - bi * (bi + 1);
+      int bi = 0, bj;
+      if (TJ == 64) { while ((bi + 1) * (bi + 2) <= tile) bi++; bj = tile - bi * (bi + 1); }
+      else { while ((bi + 1) * (bi + 2) / 2 <= tile) bi++; bj = tile - bi * (bi + 1) / 2; }
       for (int k = 0; k < S; k++)
         for (int i = 0; i < TILE; i += 37)
           for (int j = 0; j < TJ; j += 29) {
@@ -185,12 +217,12 @@ int main() {
     std::vector<int8_t> h(1 << 24);
     for (auto& v : h) v = (int8_t)(rand() % 256 - 128);
     for (size_t off = 0; off < bytes; off += h.size()) CK(hipMemcpy(d + off, h.data(), std::min(h.size(), bytes - off), hipMemcpyHostToDevice));
-    const int tiles = (n / TILE) * (n / TILE + 1);
+    const int tiles = tiles_of(n);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e9;
     for (int rep = 0; rep < 3; rep++) {
       hipEventRecord(e0);
-      hipLaunchKernelGGL(planes_syrk, dim3(tiles), dim3(256), NBUF * STAGE, 0, d, n, T, (int64_t)T, (int*)nullptr, sink);
+      hipLaunchKernelGGL(planes_syrk, dim3(tiles), dim3(64 * NW), NBUF * STAGE, 0, d, n, T, (int64_t)T, (int*)nullptr, sink);
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
       if (ms < best) best = ms;
@@ -198,6 +230,7 @@ int main() {
     CK(hipGetLastError());
     CK(hipFuncSetAttribute((const void*)planes_syrk, hipFuncAttributeMaxDynamicSharedMemorySize, NBUF * STAGE));
     const double ops = (S * (S + 1) / 2) * 2.0 * (double)tiles * TILE * TJ * T;   // 15 plane pairs, 2 ops per MAC (128 x 64 tiles incl. the diagonal's upper halves)
+    printf("waves %d, tile 128 x %d, %d workgroup(s) per CU, ring %d: ", NW, TJ, OCC, NBUF);
     printf("n=%d T=%d: %.2f ms  %.0f int8 TOP/s (%.1f%% of 5000) incl. the diagonal tiles' upper halves; useful (SYRK count) %.0f TOP/s\n", n, T,
            best, ops / best / 1e9, ops / best / 1e9 / 50.0, (S * (S + 1) / 2) * (double)n * (n + 1) * T / best / 1e9);
   }
