@@ -20,12 +20,15 @@
 //   i8_split_kernel    six digit planes, written in the blocked layout the product kernel streams: [plane][32-row group]
 //                      [k-step][k-half][row][16 tokens] -- each 1 KB piece is one contiguous global_load_lds_dwordx4 per wave;
 //                      counts the deep elements per column on the way
-//   i8_syrk_kernel<P>  128 x 64 output tiles of the lower triangle; 4 waves, wave tile 64 x 32 (32 P int32 accumulators; a
-//                      64 x 64 wave tile's 320 would exceed the 256 AGPRs); per k-step of 32 tokens ONE set of 3 P fragment
-//                      reads feeds all P (P + 1) MFMAs of the plane pairs (3x less LDS traffic per MFMA than separate GEMMs,
-//                      which is what lets it pass the library's int8 rate); LDS ring of 4 stages filled by LDS-DMA three
-//                      stages ahead, one raw barrier per stage; every 16384 tokens the int32 classes are folded into sigma
-//                      in fp64.  The P = 5 variant reads the top five of the six planes (a balanced-digit truncation).
+//   i8_syrk_kernel<P, waves>  output tiles of the lower triangle, two waves per SIMD inside one workgroup of 8 waves:
+//                      P = 5: 128 x 128 tile, wave tile 64 x 32 (160 int32 accumulators; a 64 x 64 wave tile's 320 would not
+//                      fit); P = 6: 128 x 64 tile, wave tile 32 x 32 (96).  Per k-step of 32 tokens ONE set of fragment reads
+//                      feeds all P (P + 1) / 2 plane-pair products of the wave tile (3x less LDS traffic per MFMA than separate
+//                      GEMMs, which is what lets it pass the library's int8 rate); 2-stage LDS ring filled by LDS-DMA, one raw
+//                      barrier per stage; every 16384 tokens the int32 classes are folded into sigma in fp64.  The P = 5
+//                      variant reads the top five of the six planes (a balanced-digit truncation).  The 4-wave shapes of
+//                      the first versions (128 x 64 tile, 64 x 32 wave tiles, 4-stage ring with counted waits) stay available
+//                      behind -DMDG_I8_WIDE5=0 / -DMDG_I8_WIDE6=0.
 #include "common.hpp"
 
 namespace mdg {
@@ -295,8 +298,8 @@ __global__ __launch_bounds__(64 * NW, (P == 5 && NW == 4) ? MDG_I8_OCC5 : 1) voi
   // 32 tiles = the 32 CUs of an XCD); a super-block lives on ONE XCD, so per k-step its tiles pull 5 x (512 + 512) x 32 B of
   // distinct panel rows through that L2 instead of 32 x 30 KB (FETCH_SIZE 231 -> 132 GB per launch, 47.7 -> 44.8 ms with one workgroup per CU; with two the order matters less, 41.9 -> 39.7 ms).
   // Super-blocks (R, C), C <= R, cover the lower region; tiles of a diagonal super-block that lie above it exit at once.
-  // P = 6 keeps the plain row-major tile order: there every XCD-pinned grouping tried (1 x 2, 2 x 4, 4 x 8 tiles, build flag
-  // MDG_I8_SB6) measured 84 - 87 ms against 60.8 ms row-major; not understood yet (PMC: waves parked 52 % of the time).
+  // P = 6 (8 waves of 32 x 32): super-blocks of 2 x 4 tiles (build flag MDG_I8_SB6; 52.1 ms against 54.9 row-major).  With the
+  // 4-wave shape every XCD-pinned grouping measured 84 - 87 ms against 60.8 ms row-major (not understood; waves parked 52 %).
   int bi, bj;
   constexpr int SI = P == 5 ? MDG_I8_SB5 : MDG_I8_SB6;   // super-block: SI x 2 SI tiles; 0 = plain row-major order
   if (TJ == 128) {

@@ -51,4 +51,4 @@ for label, fn in (("idle", lambda: time.sleep(0.05)), ("i8 route", lambda: ops.c
     print(f"== {label}: {n} calls in {dt:.2f} s ({1e3 * dt / n:.1f} ms per call)")
     for t, s in samples[:: max(1, len(samples) // 5)]:
         f = s.split("|")[-1].split(",")
-        print(f"  t={t - t0:5.2f}s  sclk {f[6]}  power {f[-1]} W")
+        print(f"  t={t - t0:5.2f}s  sclk {f[5]}  power {f[-1]} W")
