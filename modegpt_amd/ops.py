@@ -123,18 +123,49 @@ def cov_accum_multi(items, mode: Optional[str] = None) -> None:
     if mode not in ("f64", "i8"):
         raise ValueError(f"covariance mode must be 'f64' or 'i8', got {mode!r}")
     if mode == "i8":
-        rest = []
+        rest, planes = [], []
         for sigma, x, n_heads in items:
             # below ~2048 features the 128 x 128 tiles do not fill the 256 CUs and the fp64 kernel is the faster one
             # (scripts/probes/i8_small_n.py: 1536 features 1.35 vs 1.23 ms, 2048 features 1.40 vs 2.14 ms)
             if n_heads == 1 and x.dtype == torch.bfloat16 and sigma.dim() == 2 and sigma.shape[-1] % 128 == 0 \
                     and sigma.shape[-1] >= I8_MIN_FEATURES:
-                cov_accum_i8(sigma, x)
+                planes.append((sigma, x))
             else:
                 rest.append((sigma, x, n_heads))
+        if planes and rest and COV_OVERLAP_SMALL:
+            # the small fp64 problems (per-head sigma_q / sigma_k) run on a side stream next to the LAST -- smallest -- int8
+            # problem, whose few hundred tiles leave CUs idle in their final round; the large problem keeps the chip to itself
+            for sigma, x in planes[:-1]:
+                cov_accum_i8(sigma, x)
+            dev = planes[-1][1].device
+            main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                _cov_accum_fused(rest)
+            cov_accum_i8(*planes[-1])
+            main.wait_stream(side)       # later work on the caller's stream (and any reuse of these buffers) is ordered after both
+            return
+        for sigma, x in planes:
+            cov_accum_i8(sigma, x)
         items = rest
         if not items:
             return
+    _cov_accum_fused(items)
+
+
+_SIDE_STREAMS = {}
+COV_OVERLAP_SMALL = os.environ.get("MODEGPT_COV_OVERLAP", "1") != "0"
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+    return _SIDE_STREAMS[key]
+
+
+def _cov_accum_fused(items) -> None:
+    """The fp64 part of cov_accum_multi: one fused launch when the preconditions hold, else one cov_accum per item."""
     lib = _lib.load()
     prepared = []
     dtype = items[0][1].dtype

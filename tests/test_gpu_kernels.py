@@ -674,3 +674,32 @@ def test_cov_i8_randomised_shapes_and_scales(ops, dev):
         assert err < 1e-12, (trial, T, n, kind, err)
         assert bool(torch.isfinite(S8[low]).all())
     assert routes & {5, 6}, routes
+
+
+def test_cov_accum_multi_side_stream_overlap_changes_nothing(ops, dev, monkeypatch):
+    """In "i8" mode the small per-head fp64 problems run on a side stream beside the last int8 problem
+    (ops.COV_OVERLAP_SMALL); results must be bit-identical to the one-stream order, call after call, and later work on
+    the caller's stream must see them."""
+    gen = torch.Generator().manual_seed(77)
+    n, nh, hd, T = 2048, 4, 64, 3000
+    monkeypatch.setattr(ops, "I8_MIN_FEATURES", 256)
+    batches = [(acts(gen, T, n).to(dev), acts(gen, T, nh * hd).to(dev), acts(gen, T, 2 * hd).to(dev)) for _ in range(3)]
+
+    def run(overlap):
+        monkeypatch.setattr(ops, "COV_OVERLAP_SMALL", overlap)
+        sx = torch.zeros(n, n, dtype=F64, device=dev)
+        sq = torch.zeros(nh, hd, hd, dtype=F64, device=dev)
+        sk = torch.zeros(2, hd, hd, dtype=F64, device=dev)
+        for x, q, k in batches:
+            ops.cov_accum_multi([(sx, x, 1), (sq, q, nh), (sk, k, 2)], mode="i8")
+        # consumed on the caller's stream right away, without a device-wide synchronize
+        return sx.clone(), sq.clone(), sk.clone()
+
+    a, b = run(True), run(False)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    ref = torch.zeros(nh, hd, hd, dtype=F64)
+    for _, q, _ in batches:
+        O.cov_accum_heads(ref, q.cpu(), nh, hd)
+    low = torch.tril(torch.ones(hd, hd, dtype=torch.bool))
+    assert ((a[1].cpu() - ref)[:, low].abs().max() / ref.abs().max()).item() < 1e-12
