@@ -294,6 +294,31 @@ def main():
             out["roofline"]["f64_route"] = {"kernel": "cov_accum_kernel (v_mfma_f64_16x16x4_f64) on the same sigma_mlp batch",
                                             "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                             "frac": tf / FP64_MFMA_PEAK_TFLOPS, "avg_launch_ms": e0.elapsed_time(e1) / 2}
+            # ... and the six-plane route, which the depth statistic picks for the SiLU-gated MLP statistic of a real Llama
+            # (the bench's Gaussian columns take five planes): a gated batch of the same shape through the same entry point
+            if shape["arch"] != "opt":
+                gen = torch.Generator(device=dev).manual_seed(4242)
+                g = torch.randn(h.shape, generator=gen, device=dev, dtype=torch.float32)
+                g = torch.nn.functional.silu(g).mul_(torch.randn(h.shape, generator=gen, device=dev, dtype=torch.float32))
+                hg = g.to(torch.bfloat16)
+                del g
+                scratch.zero_()
+                routes_before = dict(ops.I8_STATS)
+                used = ops.cov_accum_i8(scratch, hg, events=(e0, e1))
+                ms6 = []
+                for _ in range(2):
+                    used = ops.cov_accum_i8(scratch, hg, events=(e0, e1))
+                    torch.cuda.synchronize()
+                    ms6.append(e0.elapsed_time(e1))
+                ops.I8_STATS.update(routes_before)      # not part of the timed region's route count
+                pairs = {5: 15, 6: 21}.get(used)
+                if pairs:
+                    top = pairs * hg.shape[0] * shape["d_ff"] * (shape["d_ff"] + 1) / (sum(ms6) / len(ms6) * 1e-3) / 1e12
+                    out["roofline"]["gated_route"] = {
+                        "kernel": "i8_syrk_kernel on a SiLU-gated sigma_mlp batch of the same shape (outside the timed region)",
+                        "planes": used, "achieved": top, "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s",
+                        "frac": top / INT8_MFMA_PEAK_TOPS, "avg_launch_ms": sum(ms6) / len(ms6)}
+                del hg
             del scratch
         out["cpu_baseline"] = cpu_baseline(shape, layers[li], covs, 2048, n_texts * 2048, a.keep, ridges, gpu_out)
         if shape["arch"] != "opt":
