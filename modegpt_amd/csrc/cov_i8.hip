@@ -251,15 +251,17 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
                                    0, 0);
 }
 
-// Shape, occupancy and LDS ring per route.
-//   P = 5, NW = 8 (default): 128 x 128 tile worked by 8 waves (one workgroup of 512 threads = 2 waves per SIMD, <= 256 registers
-//     each: 160 accumulators + fragments fit), 2-stage ring of 40 KB stages -- 40 KB of L2->LDS traffic per k-step for 16384
-//     outputs where two 128 x 64 tiles move 60 KB.  The kernel is power-capped, so bytes moved per MFMA
-//     is what counts: probe (scripts/probes/i8_planes_syrk.hip, random bytes) 44.2 ms against 48.5 ms for the next shape.
-//   P = 5, NW = 4 (-DMDG_I8_WIDE5=0): 128 x 64 tile, 4 waves, TWO workgroups per CU with a 2-stage ring (2 x 30 KB each) --
-//     while one workgroup sits in its stage barrier / LDS fragment reads the other one's MFMAs run (45.8 -> 40.5 ms per call
-//     against one workgroup with a 4-stage ring).
-//   P = 6: 128 x 64 tile, 4 waves, one workgroup per CU (192 accumulators), 4 x 36 KB ring (two per CU measured 96 ms against 61).
+// Shape, occupancy and LDS ring per route (all with 2 waves per SIMD; the kernel is power-capped, DESIGN.md section 7, so
+// bytes moved per MFMA is what counts).
+//   P = 5, NW = 8 (default): 128 x 128 tile worked by 8 waves of 64 x 32 (one workgroup of 512 threads, <= 256 registers per wave:
+//     160 accumulators + fragments fit), 2-stage ring of 40 KB stages -- 40 KB of L2->LDS traffic per k-step for 16384 outputs
+//     where two 128 x 64 tiles move 60 KB (40.1 -> 35.5 ms, L2 misses 203 -> 98 GB per launch).
+//   P = 6, NW = 8 (default): 128 x 64 tile worked by 8 waves of 32 x 32 (96 accumulators), 2-stage ring of 36 KB (61 -> 52 ms).
+//   P = 5, NW = 4 (-DMDG_I8_WIDE5=0): 128 x 64 tile, 4 waves of 64 x 32, TWO workgroups per CU with a 2-stage ring (2 x 30 KB each)
+//     -- while one workgroup sits in its stage barrier / LDS fragment reads the other one's MFMAs run (45.8 -> 40.5 ms per
+//     call against one workgroup with a 4-stage ring, -DMDG_I8_OCC5=1).
+//   P = 6, NW = 4 (-DMDG_I8_WIDE6=0): 128 x 64 tile, 4 waves of 64 x 32 (192 accumulators), one workgroup per CU, 4 x 36 KB ring
+//     with counted waits (two workgroups per CU measured 96 ms against 61).
 #ifndef MDG_I8_WIDE6
 #define MDG_I8_WIDE6 1
 #endif
@@ -292,14 +294,15 @@ __global__ __launch_bounds__(64 * NW, (P == 5 && NW == 4) ? MDG_I8_OCC5 : 1) voi
   constexpr int PIECES = (GA + GB) * P;            // 1 KB pieces per stage
   constexpr int PER_WAVE_MIN = PIECES / NW;        // every wave issues at least this many LDS-DMA loads per stage
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  // Tile (bi, bj): bi = 128-row block, bj = 64-row block, lower region bj <= 2 bi + 1.
-  // P = 5, XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2, so workgroup w belongs to
-  // XCD w % 8 and is the (w / 8)-th one there.  The tiles are grouped into super-blocks of 4 x 8 tiles (512 x 512 features:
-  // 32 tiles = the 32 CUs of an XCD); a super-block lives on ONE XCD, so per k-step its tiles pull 5 x (512 + 512) x 32 B of
-  // distinct panel rows through that L2 instead of 32 x 30 KB (FETCH_SIZE 231 -> 132 GB per launch, 47.7 -> 44.8 ms with one workgroup per CU; with two the order matters less, 41.9 -> 39.7 ms).
-  // Super-blocks (R, C), C <= R, cover the lower region; tiles of a diagonal super-block that lie above it exit at once.
-  // P = 6 (8 waves of 32 x 32): super-blocks of 2 x 4 tiles (build flag MDG_I8_SB6; 52.1 ms against 54.9 row-major).  With the
-  // 4-wave shape every XCD-pinned grouping measured 84 - 87 ms against 60.8 ms row-major (not understood; waves parked 52 %).
+  // Tile (bi, bj): bi = 128-row block, bj = TJ-row block of the lower region (bj <= bi for 128 x 128 tiles, bj <= 2 bi + 1 for
+  // 128 x 64).  XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2, so workgroup w belongs
+  // to XCD w % 8 and is the (w / 8)-th one there.  The tiles are grouped into super-blocks that are square in features
+  // (SI x SI tiles of 128 x 128, SI x 2 SI tiles of 128 x 64; P = 5: 512 x 512 features, P = 6: 256 x 256); a super-block
+  // lives on ONE XCD, so per k-step its tiles pull each distinct panel row through that L2 once (first version, 4 x 8 tiles
+  // of 128 x 64, one workgroup per CU: FETCH_SIZE 231 -> 132 GB per launch, 47.7 -> 44.8 ms; 128 x 128 tiles: 40.0 ms
+  // row-major, 37.2 ms with 4 x 4 super-blocks).  Super-blocks (R, C), C <= R, cover the lower region; tiles of a diagonal
+  // super-block that lie above it exit at once.  P = 6: 2 x 4 tiles, 52.1 ms against 54.9 row-major (with the 4-wave shape
+  // every XCD-pinned grouping measured 84 - 87 ms against 60.8 ms row-major; not understood, waves parked 52 %).
   int bi, bj;
   constexpr int SI = P == 5 ? MDG_I8_SB5 : MDG_I8_SB6;   // super-block: SI x 2 SI tiles; 0 = plain row-major order
   if (TJ == 128) {
