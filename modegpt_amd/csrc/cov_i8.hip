@@ -262,6 +262,9 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 //     call against one workgroup with a 4-stage ring, -DMDG_I8_OCC5=1).
 //   P = 6, NW = 4 (-DMDG_I8_WIDE6=0): 128 x 64 tile, 4 waves of 64 x 32 (192 accumulators), one workgroup per CU, 4 x 36 KB ring
 //     with counted waits (two workgroups per CU measured 96 ms against 61).
+#ifndef MDG_I8_UNIFORM_WAVE
+#define MDG_I8_UNIFORM_WAVE 1
+#endif
 #ifndef MDG_I8_WIDE6
 #define MDG_I8_WIDE6 1
 #endif
@@ -344,9 +347,16 @@ __global__ __launch_bounds__(64 * NW, (P == 5 && NW == 4) ? MDG_I8_OCC5 : 1) voi
     bj = tile - bi * (bi + 1);
   }
   if (bi >= a.n / TI || bj * TJ > bi * TI + TI - 1) return;
-  // (the wave index deliberately NOT through readfirstlane: with a provably uniform wave index hipcc 7.2 makes the staging
-  // code scalar but puts an s_waitcnt vmcnt(0) in front of every LDS-DMA load, which serialises the 4-stage ring: 61 -> 165 ms)
+  // The wave index goes through readfirstlane where the ring has 2 stages: hipcc then knows it is wave-uniform and the staging
+  // code becomes scalar (SGPR piece addresses, s_cbranch on `p < PIECES`, M0 from SGPRs) instead of exec-masked branches with a
+  // v_readfirstlane per piece (35.6 -> 34.8 ms, P = 6: 51.4 -> 50.6).  hipcc 7.2 also puts an s_waitcnt vmcnt(0) in front of
+  // every LDS-DMA load once the index is uniform -- harmless with 2 stages (the loop drains the counter every step anyway), but
+  // it serialises a 4-stage ring (P = 6, 4 waves: 61 -> 165 ms), so those shapes keep the plain index.
+#if MDG_I8_UNIFORM_WAVE
+  const int wave = RING == 2 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+#else
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#endif
   const int wr = wave / WCOLS, wc = wave % WCOLS;
   const int64_t groups = a.n / 32;
   const int nk = a.nk;
