@@ -41,7 +41,10 @@ constexpr int NP = 6;            // digit planes written by the split pass; the 
 constexpr int TI = 128;           // output tile rows (rows of the I operand); its width TJ is 64 or 128, see i8_syrk_kernel
 constexpr int KS = 32;           // tokens per k-step (one v_mfma_i32_32x32x32_i8)
 constexpr int PA = TI * KS;      // bytes of one plane of the I operand in a stage
-constexpr int FLUSH_STEPS = 512;  // 16384 tokens: (k + 1) * 2^14 * 16384 < 2^31 for every class k <= 5
+#ifndef MDG_I8_FLUSH_STEPS          // (timing experiments only: anything above 512 can overflow the int32 classes)
+#define MDG_I8_FLUSH_STEPS 512
+#endif
+constexpr int FLUSH_STEPS = MDG_I8_FLUSH_STEPS;  // 16384 tokens: (k + 1) * 2^14 * 16384 < 2^31 for every class k <= 5
 constexpr int TOP_SHIFT = 8 * NP - 10;  // 38: the column maximum's significand sits below bit 46 of the 48-bit integer
 constexpr int DEEP_BINADES = 10;  // an element is "deep" when its exponent is at least this far below the column maximum
 
@@ -387,26 +390,33 @@ __global__ __launch_bounds__(64 * NW, (P == 5 && NW == 4) ? MDG_I8_OCC5 : 1) voi
   // sigma[i][j] += 2^(E_i + E_j - 344) * sum_k acc_k 256^(10 - k)  =  (sum_k acc_k 2^(80 - 8k)) * 2^(E_i - 172) * 2^(E_j - 172)
   auto flush = [&]() {
     const int col = bj * TJ + wc * 32 + (lane & 31);
+    int row0 = bi * TI + wr * 32 * WB + 4 * (lane >> 5);
+    // opaque to the optimiser: otherwise the 32 element addresses are computed once, ahead of the MFMA loop, spilled (the
+    // accumulators fill the register file there), and reloaded here behind one s_waitcnt vmcnt(0) each -- which turns the 16
+    // sigma loads of a block into 16 serialised memory round trips (26 us per flush and tile, 2 x 0.65 ms per launch)
+    asm volatile("" : "+v"(row0));
     const double sc_j = ldexp(1.0, a.emax[col] - 172);
-    // all 32 read-modify-writes of a lane: loads first (independent, in flight together), then the arithmetic and the stores;
+    // all read-modify-writes of a lane: loads first (independent, in flight together), then the arithmetic and the stores;
     // written as `*p += v` one by one the compiler must keep them in order and every element pays a full memory round trip
 #pragma unroll
-    for (int b = 0; b < WB; b++) {  // one 32-row block at a time: 16 loads in flight per lane, and no spills
+    for (int b = 0; b < WB; b++) {  // one 32-row block at a time: 16 loads in flight per lane
+      double* const p = a.sigma + (int64_t)(row0 + b * 32) * a.ld_sigma + col;
+      const int* const e = a.emax + row0 + b * 32;
       double old[16];
       int er[16];
 #pragma unroll
       for (int reg = 0; reg < 16; reg++) {
-        const int row = bi * TI + wr * 32 * WB + b * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-        old[reg] = a.sigma[(int64_t)row * a.ld_sigma + col];
-        er[reg] = a.emax[row];
+        const int off = (reg & 3) + 8 * (reg >> 2);
+        old[reg] = p[(int64_t)off * a.ld_sigma];
+        er[reg] = e[off];
       }
 #pragma unroll
       for (int reg = 0; reg < 16; reg++) {
-        const int row = bi * TI + wr * 32 * WB + b * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        const int off = (reg & 3) + 8 * (reg >> 2);
         double v = 0.;
 #pragma unroll
         for (int k = P - 1; k >= 0; k--) v += ldexp((double)acc[k][b][reg], 80 - 8 * k);
-        if (col <= row) a.sigma[(int64_t)row * a.ld_sigma + col] = old[reg] + v * sc_j * ldexp(1.0, er[reg] - 172);
+        if (col <= row0 + b * 32 + off) p[(int64_t)off * a.ld_sigma] = old[reg] + v * sc_j * ldexp(1.0, er[reg] - 172);
       }
     }
 #pragma unroll
