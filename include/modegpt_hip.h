@@ -78,8 +78,8 @@ size_t mdg_cov_accum_multi_ws_bytes(int n, const mdg_cov_problem* problems, int 
 int mdg_cov_accum_multi(int n, const mdg_cov_problem* problems, int dtype, void* ws, size_t ws_bytes, void* stream);
 /* The same accumulation for ONE bf16 matrix through the int8 matrix cores, exactly (csrc/cov_i8.hip): every bf16 value is
  * split into six balanced base-256 digits against a per-column power-of-two scale; the digit-plane products with
- * s + t < P are formed by v_mfma_i32_32x32x32_i8 with exact int32 accumulation and folded into sigma in fp64 every 16384
- * tokens.  Each call measures, per column, the share of its nonzero elements more than 10 binades below the column maximum and picks
+ * s + t < P are formed by v_mfma_i32_32x32x32_i8 with exact int32 accumulation and folded into sigma in fp64 every 65504
+ * tokens (the exact int32 bound).  Each call measures, per column, the share of its nonzero elements more than 10 binades below the column maximum and picks
  * P = 5 (share <= 1/64 everywhere: within ~2e-13 of sigma's scale), P = 6 (<= 1/4: <= ~1e-13 on gated activations) or
  * runs mdg_cov_accum on the batch itself (heavier tails, columns dominated by a few massive activations).
  * *used_i8 (host, optional) reports the route: 5, 6, or 0 for the fp64 kernel.  n_feat must be a multiple of 128.

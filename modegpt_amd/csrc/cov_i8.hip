@@ -25,7 +25,7 @@
 //                      fit); P = 6: 128 x 64 tile, wave tile 32 x 32 (96).  Per k-step of 32 tokens ONE set of fragment reads
 //                      feeds all P (P + 1) / 2 plane-pair products of the wave tile (3x less LDS traffic per MFMA than separate
 //                      GEMMs, which is what lets it pass the library's int8 rate); 2-stage LDS ring filled by LDS-DMA, one raw
-//                      barrier per stage; every 16384 tokens the int32 classes are folded into sigma in fp64.  The P = 5
+//                      barrier per stage; every 2047 k-steps (65504 tokens, the int32 bound) the classes are folded into sigma in fp64.  The P = 5
 //                      variant reads the top five of the six planes (a balanced-digit truncation).  The 4-wave shapes of
 //                      the first versions (128 x 64 tile, 64 x 32 wave tiles, 4-stage ring with counted waits) stay available
 //                      behind -DMDG_I8_WIDE5=0 / -DMDG_I8_WIDE6=0.
@@ -41,10 +41,15 @@ constexpr int NP = 6;            // digit planes written by the split pass; the 
 constexpr int TI = 128;           // output tile rows (rows of the I operand); its width TJ is 64 or 128, see i8_syrk_kernel
 constexpr int KS = 32;           // tokens per k-step (one v_mfma_i32_32x32x32_i8)
 constexpr int PA = TI * KS;      // bytes of one plane of the I operand in a stage
-#ifndef MDG_I8_FLUSH_STEPS          // (timing experiments only: anything above 512 can overflow the int32 classes)
-#define MDG_I8_FLUSH_STEPS 512
+// k-steps between folds of the int32 classes into sigma.  An element is an 8-bit significand at some shift, so its balanced
+// digits are two full digits and a carry digit at most, and a class sum grows by at most 32768 per token (enumerated over
+// every digit vector the split pass can produce: scripts/probes/i8_int32_bound.py) -- 65535 tokens = 2047 k-steps stay below
+// 2^31.  (First versions: 512, from the cruder bound 6 pairs x 128 x 128 per token; one fold per launch costs 0.65 ms at the
+// sigma_mlp shape.)
+#ifndef MDG_I8_FLUSH_STEPS
+#define MDG_I8_FLUSH_STEPS 2047
 #endif
-constexpr int FLUSH_STEPS = MDG_I8_FLUSH_STEPS;  // 16384 tokens: (k + 1) * 2^14 * 16384 < 2^31 for every class k <= 5
+constexpr int FLUSH_STEPS = MDG_I8_FLUSH_STEPS;
 constexpr int TOP_SHIFT = 8 * NP - 10;  // 38: the column maximum's significand sits below bit 46 of the 48-bit integer
 constexpr int DEEP_BINADES = 10;  // an element is "deep" when its exponent is at least this far below the column maximum
 

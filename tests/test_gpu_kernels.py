@@ -529,10 +529,11 @@ def test_rope_strided_input_and_errors(ops, dev):
 
 
 # ---------------------------------------------------------------- int8 digit-plane covariance
-@pytest.mark.parametrize("tokens,feat", [(777, 256), (4096, 128), (33, 384), (20000, 256)])
+@pytest.mark.parametrize("tokens,feat", [(777, 256), (4096, 128), (33, 384), (20000, 256), (65504 + 3000, 128)])
 def test_cov_i8_matches_the_fp64_oracle(ops, dev, tokens, feat):
     """The error-free int8 route against the oracle's fp64 X^T X: 1e-12 of |sigma| (the route's own bound on such data is
-    ~1e-13), lower triangle; a second call accumulates; 20000 tokens cross the 16384-token int32 flush."""
+    ~1e-13), lower triangle; a second call accumulates; 68504 tokens cross the int32 fold boundary (2047 k-steps = 65504
+    tokens, the exact bound enumerated by scripts/probes/i8_int32_bound.py)."""
     gen = torch.Generator().manual_seed(tokens + feat)
     X = acts(gen, tokens, feat)
     ref = torch.zeros(feat, feat, dtype=F64)
