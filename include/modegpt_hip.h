@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MDG_ABI_VERSION 2 /* 2: w_dtype on mdg_nystrom_down / mdg_vo_compress, mdg_rope_gather added */
+#define MDG_ABI_VERSION 3 /* 2: w_dtype on mdg_nystrom_down / mdg_vo_compress, mdg_rope_gather added; 3: mdg_cov_accum_i8_stats added */
 
 enum mdg_status {
   MDG_OK = 0,
@@ -89,6 +89,12 @@ int mdg_cov_accum_multi(int n, const mdg_cov_problem* problems, int dtype, void*
 size_t mdg_cov_accum_i8_ws_bytes(int64_t n_tokens, int64_t n_feat);
 int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat, int64_t ld, double* sigma, int64_t ld_sigma, void* ws,
                      size_t ws_bytes, int* used_i8, void* ev_start, void* ev_stop, void* stream);
+/* v_mfma instructions the product kernel of the LAST mdg_cov_accum_i8 call on workspace `ws` executed (0 after a call that
+ * fell back to mdg_cov_accum).  The split pass records, per k-step and 32-row group, which digit planes hold a nonzero
+ * there; the product kernel neither loads nor multiplies planes that are all-zero over a tile panel, so the count is at
+ * most -- and on real activations well below -- the dense (tiles) x (k-steps) x (waves) x (MFMAs per step).  Copies 8 bytes
+ * device -> host on `stream` and synchronises it.  bench.py prices the kernel with this count. */
+int mdg_cov_accum_i8_stats(const void* ws, int64_t n_tokens, int64_t n_feat, unsigned long long* executed_mfma, void* stream);
 /* sigma[b] <- scale * sigma[b] on the lower triangle, mirrored into the upper.  scale = 1/(n_texts*2048)
  * reproduces calibration.py:141-146. */
 int mdg_cov_finalize(double* sigma, int64_t n, int64_t batch, int64_t ld_sigma, int64_t sigma_batch_stride,

@@ -76,11 +76,26 @@ __global__ __launch_bounds__(256) void i8_colmax_kernel(const bf16_t* x, int64_t
   if (j < n) atomicMax(emax + j, best);
 }
 
+// Piece mask: one byte per (k-step, 32-row group), bit s set when the 1 KB piece of plane s there holds any nonzero digit.  An
+// element is two full digits and a carry digit (see FLUSH_STEPS), so on real activations whole pieces of the lower planes are
+// zero -- Gaussian columns: plane 3 in 90 % of the pieces, planes 4 and 5 always; SiLU-gated: plane 4 in 98 % -- and the
+// product kernel neither loads nor multiplies those.  Called with the 32 rows of a piece in the 32 lanes of a half-wave.
+__device__ __forceinline__ void write_piece_mask(const unsigned (&any)[NP], unsigned char* zmask, int64_t index) {
+  unsigned byte = 0;
+#pragma unroll
+  for (int s = 0; s < NP; s++) {
+    const unsigned long long b = __ballot(any[s] != 0);
+    const unsigned half = (threadIdx.x & 32) ? (unsigned)(b >> 32) : (unsigned)b;
+    byte |= (half != 0) << s;
+  }
+  if ((threadIdx.x & 31) == 0) zmask[index] = (unsigned char)byte;
+}
+
 // One thread = one feature row of a 32-row group x one k-step (32 tokens) at a time: two 16-byte stores per plane and
 // k-step.  A workgroup walks SPLIT_STEPS k-steps of its row group, 8 at a time.
 constexpr int SPLIT_STEPS = 64;
 __global__ __launch_bounds__(256) void i8_split_kernel(const bf16_t* x, int64_t ld, int64_t T, int n, int nk, const int* emax,
-                                                       signed char* planes, int* deep_cnt, int* nz_cnt) {
+                                                       signed char* planes, int* deep_cnt, int* nz_cnt, unsigned char* zmask) {
   __shared__ int deep_lds[32], nz_lds[32];
   const int r = threadIdx.x & 31;
   const int G = blockIdx.x;
@@ -93,6 +108,7 @@ __global__ __launch_bounds__(256) void i8_split_kernel(const bf16_t* x, int64_t 
   for (int kq = 0; kq < SPLIT_STEPS; kq += 8) {
     const int kt = blockIdx.y * SPLIT_STEPS + kq + (threadIdx.x >> 5);
     if (kt >= nk) break;
+    unsigned any[NP] = {};       // per plane: does this row hold a nonzero digit in this k-step
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       unsigned dig[NP][4] = {};  // 16 bytes per plane
@@ -124,8 +140,10 @@ __global__ __launch_bounds__(256) void i8_split_kernel(const bf16_t* x, int64_t 
       for (int s = 0; s < NP; s++) {
         signed char* piece = planes + ((s * groups + G) * (int64_t)nk + kt) * 1024;
         *(i32x4*)(piece + h * 512 + r * 16) = (i32x4){(int)dig[s][0], (int)dig[s][1], (int)dig[s][2], (int)dig[s][3]};
+        any[s] |= dig[s][0] | dig[s][1] | dig[s][2] | dig[s][3];
       }
     }
+    write_piece_mask(any, zmask, (int64_t)kt * groups + G);   // the 32 lanes of a half-wave hold the 32 rows of the piece
   }
   if (deep) atomicAdd(&deep_lds[r], deep);
   if (nz) atomicAdd(&nz_lds[r], nz);
@@ -169,7 +187,7 @@ __global__ __launch_bounds__(256) void i8_colmax_vec_kernel(const bf16_t* x, int
 // workgroup = 128 features (4 row groups) x 64 tokens (2 k-steps): the tile goes through LDS, one thread then owns one
 // feature of one k-step
 __global__ __launch_bounds__(256) void i8_split_vec_kernel(const bf16_t* x, int64_t ld, int64_t T, int n, int nk, const int* emax,
-                                                           signed char* planes, int* deep_cnt, int* nz_cnt) {
+                                                           signed char* planes, int* deep_cnt, int* nz_cnt, unsigned char* zmask) {
   __shared__ __attribute__((aligned(16))) bf16_t tile[64 * 128];
   __shared__ int deep_lds[128], nz_lds[128];
   const int f0 = blockIdx.x * 128;
@@ -191,7 +209,8 @@ __global__ __launch_bounds__(256) void i8_split_vec_kernel(const bf16_t* x, int6
   const int64_t groups = n / 32;
   const int G = (f0 + f) >> 5, r = f & 31;
   int deep = 0, nz = 0;
-  if (kt < nk) {
+  if (kt < nk) {   // (uniform per wave: a wave holds 64 features of ONE k-step)
+    unsigned any[NP] = {};
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       unsigned dig[NP][4] = {};
@@ -222,8 +241,10 @@ __global__ __launch_bounds__(256) void i8_split_vec_kernel(const bf16_t* x, int6
       for (int s2 = 0; s2 < NP; s2++) {
         signed char* piece = planes + ((s2 * groups + G) * (int64_t)nk + kt) * 1024;
         *(i32x4*)(piece + h * 512 + r * 16) = (i32x4){(int)dig[s2][0], (int)dig[s2][1], (int)dig[s2][2], (int)dig[s2][3]};
+        any[s2] |= dig[s2][0] | dig[s2][1] | dig[s2][2] | dig[s2][3];
       }
     }
+    write_piece_mask(any, zmask, (int64_t)kt * groups + G);
   }
   if (deep) atomicAdd(&deep_lds[f], deep);
   if (nz) atomicAdd(&nz_lds[f], nz);
@@ -246,12 +267,16 @@ __global__ __launch_bounds__(256) void i8_depth_kernel(const int* deep_cnt, cons
   if (bits) atomicOr(flag, bits);
 }
 
+template <int V> struct ic { static constexpr int value = V; };
+
 struct SyrkArgs {
   const signed char* planes;
   const int* emax;
   double* sigma;
   int64_t ld_sigma;
   int n, nk;
+  const unsigned char* zmask;          // [nk][n / 32] piece masks written by the split pass (write_piece_mask)
+  unsigned long long* mfma_count;      // += v_mfma instructions this launch executed (the dense count is known on the host)
 };
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
@@ -270,6 +295,9 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 //     call against one workgroup with a 4-stage ring, -DMDG_I8_OCC5=1).
 //   P = 6, NW = 4 (-DMDG_I8_WIDE6=0): 128 x 64 tile, 4 waves of 64 x 32 (192 accumulators), one workgroup per CU, 4 x 36 KB ring
 //     with counted waits (two workgroups per CU measured 96 ms against 61).
+#ifndef MDG_I8_SKIP_ZERO
+#define MDG_I8_SKIP_ZERO 1    // skip the LDS-DMA load, the fragment read and the MFMAs of all-zero pieces (2-stage rings only)
+#endif
 #ifndef MDG_I8_UNIFORM_WAVE
 #define MDG_I8_UNIFORM_WAVE 1
 #endif
@@ -304,6 +332,11 @@ __global__ __launch_bounds__(64 * NW, (P == 5 && NW == 4) ? MDG_I8_OCC5 : 1) voi
   constexpr int STAGE_BYTES = P * (PA + PB);       // 30 / 36 KB (40 KB for the 128 x 128 tile)
   constexpr int PIECES = (GA + GB) * P;            // 1 KB pieces per stage
   constexpr int PER_WAVE_MIN = PIECES / NW;        // every wave issues at least this many LDS-DMA loads per stage
+  // Five-plane kernel only (and 2-stage rings only: the counted waits of the deeper rings need a fixed load count).  On the
+  // six-plane kernel the same code measured SLOWER on SiLU-gated data (51.1 -> 61.8 ms although 27 % of the MFMAs and a third
+  // of the loads go away): its steps are already as short as the LDS-DMA round trip a 2-stage ring has to cover, and deeper
+  // rings with load counts that vary per stage (switch over s_waitcnt immediates; tried) lose more in L2 than they gain.
+  constexpr bool SKIP = MDG_I8_SKIP_ZERO && RING == 2 && P == 5;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   // Tile (bi, bj): bi = 128-row block, bj = TJ-row block of the lower region (bj <= bi for 128 x 128 tiles, bj <= 2 bi + 1 for
   // 128 x 64).  XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2, so workgroup w belongs
@@ -370,7 +403,9 @@ __global__ __launch_bounds__(64 * NW, (P == 5 && NW == 4) ? MDG_I8_OCC5 : 1) voi
   const int nk = a.nk;
 
   // staging: (GA + GB) P pieces of 1 KB per stage (A: P planes x 4 row groups, B: P planes x 2 or 4); wave w issues pieces w, w + NW, ...
-  auto issue_stage = [&](int kt, int buf) {
+  // dA / dB: plane depth of the stage's A and B panels -- planes >= depth are all-zero over the panel's rows in this k-step
+  // and are neither loaded nor multiplied (see depth_of below)
+  auto issue_stage = [&](int kt, int buf, int dA, int dB) {
 #pragma unroll
     for (int q = 0; q < (PIECES + NW - 1) / NW; q++) {
       const int p = wave + NW * q;
@@ -378,6 +413,7 @@ __global__ __launch_bounds__(64 * NW, (P == 5 && NW == 4) ? MDG_I8_OCC5 : 1) voi
         const bool isA = p < GA * P;
         const int pp = isA ? p : p - GA * P;
         const int s = isA ? pp / GA : pp / GB, g = isA ? pp % GA : pp % GB;
+        if (SKIP && s >= (isA ? dA : dB)) continue;   // an all-zero piece: nothing will read it
         const int64_t G = (isA ? bi * (TI / 32) : bj * (TJ / 32)) + g;
         const signed char* src = a.planes + ((s * groups + G) * (int64_t)nk + kt) * 1024 + lane * 16;
         unsigned char* dst = lds + buf * STAGE_BYTES + (isA ? s * PA : P * PA + s * PB) + g * 1024;
@@ -435,7 +471,35 @@ __global__ __launch_bounds__(64 * NW, (P == 5 && NW == 4) ? MDG_I8_OCC5 : 1) voi
 
   // two loops: the int32 classes are folded into sigma between runs of FLUSH_STEPS k-steps, outside the MFMA loop (a
   // conditional flush inside it makes the compiler shuttle all 160 accumulators between AGPRs and VGPRs every step)
-  for (int p = 0; p < RING - 1 && p < nk; p++) issue_stage(p, p);
+  // piece masks: uniform-address loads, one step ahead of the stage they describe (complete at the next step's vmcnt(0))
+  const int64_t mgroups = a.n / 32;
+  auto load_masks = [&](int kt, unsigned& va, unsigned& vb) {
+    const unsigned* z = (const unsigned*)(a.zmask + (int64_t)kt * mgroups);   // n / 32 is a multiple of 4: dword-aligned rows
+    va = z[bi];                                                               // groups 4 bi .. 4 bi + 3
+    vb = TJ == 128 ? z[bj] : (z[bj >> 1] >> ((bj & 1) * 16)) & 0xFFFFu;       // groups 4 bj .. + 3, or 2 bj, 2 bj + 1
+  };
+  // depth of a panel = 1 + deepest plane with a nonzero piece in any of its row groups, but at least MIN_DEPTH: the planes
+  // below MIN_DEPTH form the unconditional, straight-line part of a step, each deeper plane a conditional block of its own
+  // (branching around single MFMAs / fragment reads instead makes hipcc put an lgkmcnt(0) in front of every LDS read; nine
+  // straight-line variants behind a switch make it spill the 160 accumulators at the merges)
+  constexpr int MIN_DEPTH = P - 2;
+  auto depth_of = [&](unsigned m) {
+    m = __builtin_amdgcn_readfirstlane(m);
+    m |= m >> 16;
+    m = (m | (m >> 8)) & 0xFFu;
+    return max(MIN_DEPTH, min(P, 32 - __builtin_clz(m | 1u)));
+  };
+  int dA_cur = P, dB_cur = P;
+  unsigned vA_next = ~0u, vB_next = ~0u;
+  unsigned executed = 0;
+  if (SKIP) {
+    unsigned va, vb;
+    load_masks(0, va, vb);
+    dA_cur = depth_of(va);
+    dB_cur = depth_of(vb);
+    if (nk > 1) load_masks(1, vA_next, vB_next);
+  }
+  for (int p = 0; p < RING - 1 && p < nk; p++) issue_stage(p, p, dA_cur, dB_cur);
   for (int k0 = 0; k0 < nk; k0 += FLUSH_STEPS) {
     const int k1 = min(nk, k0 + FLUSH_STEPS);
     for (int kt = k0; kt < k1; kt++) {
@@ -445,29 +509,74 @@ __global__ __launch_bounds__(64 * NW, (P == 5 && NW == 4) ? MDG_I8_OCC5 : 1) voi
       if (kt + RING - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * PER_WAVE_MIN) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (kt + RING - 1 < nk) issue_stage(kt + RING - 1, (kt + RING - 1) % RING);
+      int dA_nx = P, dB_nx = P;
+      if (SKIP) {   // (RING == 2) masks of stage kt + 1 arrived with the wait above; fetch those of kt + 2
+        dA_nx = depth_of(vA_next);
+        dB_nx = depth_of(vB_next);
+        if (kt + 2 < nk) load_masks(kt + 2, vA_next, vB_next);
+      }
+      if (kt + RING - 1 < nk) issue_stage(kt + RING - 1, (kt + RING - 1) % RING, dA_nx, dB_nx);
       const unsigned char* base = lds + buf * STAGE_BYTES;
       const int r = lane & 31, h = lane >> 5;
-      i32x4 fa[P][WB], fb[P];
+      // The step: planes below MIN_DEPTH of both panels unconditionally -- ONE set of fragment reads, all their pairs -- then,
+      // for each deeper plane that is present, a block of its own (fragment read + its pairs).  A deep plane only pairs with
+      // planes 0 (and 1) of the other panel (s + t < P), so the blocks are independent and simply add:
+      //   P = 5: 9 pairs + 2 [dA > 3] + 2 [dB > 3] + [dA > 4] + [dB > 4];   P = 6: 15 + 2 [dA > 4] + 2 [dB > 4] + [dA > 5] + [dB > 5]
+      i32x4 fa[MIN_DEPTH][WB], fb[MIN_DEPTH];
 #pragma unroll
-      for (int s = 0; s < P; s++) {
+      for (int s = 0; s < MIN_DEPTH; s++) {
 #pragma unroll
         for (int b = 0; b < WB; b++) fa[s][b] = *(const i32x4*)(base + s * PA + (wr * WB + b) * 1024 + h * 512 + r * 16);
         fb[s] = *(const i32x4*)(base + P * PA + s * PB + wc * 1024 + h * 512 + r * 16);
       }
+      int pairs = 0;
 #pragma unroll
-      for (int s = 0; s < P; s++)
+      for (int s = 0; s < MIN_DEPTH; s++)
 #pragma unroll
-        for (int t = 0; t < P - s; t++)
+        for (int t = 0; t < MIN_DEPTH; t++)
+          if (s + t < P) {
+            pairs++;
 #pragma unroll
-          for (int b = 0; b < WB; b++)
-            acc[s + t][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s][b], fb[t], acc[s + t][b], 0, 0, 0);
+            for (int b = 0; b < WB; b++)
+              acc[s + t][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s][b], fb[t], acc[s + t][b], 0, 0, 0);
+          }
+#pragma unroll
+      for (int d = MIN_DEPTH; d < P; d++) {
+        if (!SKIP || dA_cur > d) {   // plane d of the A panel with planes t < P - d of B (all below MIN_DEPTH, already in registers)
+          i32x4 fd[WB];
+#pragma unroll
+          for (int b = 0; b < WB; b++) fd[b] = *(const i32x4*)(base + d * PA + (wr * WB + b) * 1024 + h * 512 + r * 16);
+#pragma unroll
+          for (int t = 0; t < P - d; t++) {
+            pairs++;
+#pragma unroll
+            for (int b = 0; b < WB; b++)
+              acc[d + t][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fd[b], fb[t], acc[d + t][b], 0, 0, 0);
+          }
+        }
+        if (!SKIP || dB_cur > d) {   // plane d of the B panel with planes s < P - d of A
+          const i32x4 fd = *(const i32x4*)(base + P * PA + d * PB + wc * 1024 + h * 512 + r * 16);
+#pragma unroll
+          for (int s2 = 0; s2 < P - d; s2++) {
+            pairs++;
+#pragma unroll
+            for (int b = 0; b < WB; b++)
+              acc[s2 + d][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s2][b], fd, acc[s2 + d][b], 0, 0, 0);
+          }
+        }
+      }
+      executed += pairs * WB;
+      dA_cur = dA_nx;
+      dB_cur = dB_nx;
     }
     flush();
   }
+  if (a.mfma_count && lane == 0) atomicAdd(a.mfma_count, (unsigned long long)executed);
 }
 
 size_t planes_bytes(int64_t T, int64_t n) { return (size_t)NP * (size_t)n * (size_t)ceil_div(T, KS) * KS; }
+size_t ints_bytes(int64_t n) { return align_up((size_t)(3 * n + 4) * sizeof(int), 256); }   // emax, deep, nz, flag[2] + mfma count
+size_t zmask_bytes(int64_t T, int64_t n) { return align_up((size_t)ceil_div(T, KS) * (size_t)(n / 32), 256); }
 
 }  // namespace
 }  // namespace mdg
@@ -477,7 +586,7 @@ using namespace mdg;
 extern "C" size_t mdg_cov_accum_i8_ws_bytes(int64_t n_tokens, int64_t n_feat) {
   if (n_tokens <= 0 || n_feat <= 0) return 0;
   const size_t fallback = mdg_cov_accum_ws_bytes(n_tokens, n_feat, 1);
-  return align_up(planes_bytes(n_tokens, n_feat), 256) + align_up((size_t)(3 * n_feat + 4) * sizeof(int), 256) + fallback + 256;
+  return align_up(planes_bytes(n_tokens, n_feat), 256) + ints_bytes(n_feat) + zmask_bytes(n_tokens, n_feat) + fallback + 256;
 }
 
 extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat, int64_t ld, double* sigma, int64_t ld_sigma,
@@ -502,7 +611,9 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
   int* deep_cnt = emax + n;
   int* nz_cnt = deep_cnt + n;
   int* flag = nz_cnt + n;
-  void* fb_ws = (char*)emax + align_up((size_t)(3 * n + 4) * sizeof(int), 256);
+  unsigned long long* mfma_count = (unsigned long long*)(flag + 2);   // 8-byte aligned (n is a multiple of 128); zeroed below
+  unsigned char* zmask = (unsigned char*)emax + ints_bytes(n);
+  void* fb_ws = zmask + zmask_bytes(n_tokens, n);
   MDG_HIP(hipMemsetAsync(emax, 0, (size_t)(3 * n + 4) * sizeof(int), st));
   const bool vec = ((uintptr_t)x % 16 == 0) && (ld % 8 == 0);
   {
@@ -516,10 +627,10 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
   }
   if (vec)
     hipLaunchKernelGGL(i8_split_vec_kernel, dim3((unsigned)(n / 128), (unsigned)ceil_div(nk, 2)), dim3(256), 0, st,
-                       (const bf16_t*)x, ld, n_tokens, n, nk, emax, planes, deep_cnt, nz_cnt);
+                       (const bf16_t*)x, ld, n_tokens, n, nk, emax, planes, deep_cnt, nz_cnt, zmask);
   else
     hipLaunchKernelGGL(i8_split_kernel, dim3((unsigned)(n / 32), (unsigned)ceil_div(nk, SPLIT_STEPS)), dim3(256), 0, st,
-                       (const bf16_t*)x, ld, n_tokens, n, nk, emax, planes, deep_cnt, nz_cnt);
+                       (const bf16_t*)x, ld, n_tokens, n, nk, emax, planes, deep_cnt, nz_cnt, zmask);
   hipLaunchKernelGGL(i8_depth_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, deep_cnt, nz_cnt, emax, n, flag);
   MDG_LAUNCH_CHECK();
   int depth = 0;
@@ -529,7 +640,7 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
     return mdg_cov_accum(x, MDG_BF16, n_tokens, n_feat, 1, ld, 0, sigma, ld_sigma, 0, fb_ws,
                          ws_bytes - (size_t)((char*)fb_ws - (char*)ws), stream);
   SyrkArgs a;
-  a.planes = planes; a.emax = emax; a.sigma = sigma; a.ld_sigma = ld_sigma; a.n = n; a.nk = nk;
+  a.planes = planes; a.emax = emax; a.sigma = sigma; a.ld_sigma = ld_sigma; a.n = n; a.nk = nk; a.zmask = zmask; a.mfma_count = mfma_count;
   const int rb = n / TI;
   int planes_used = (depth & 1) ? 6 : 5;
   if (const char* ev = getenv("MDG_I8_PLANES"))  // experiment knob (scripts/bench_kernels.py): force the 6-plane product
@@ -551,5 +662,17 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
   MDG_LAUNCH_CHECK();
   if (ev_stop) MDG_HIP(hipEventRecord((hipEvent_t)ev_stop, st));
   if (used_i8) *used_i8 = planes_used;
+  return MDG_OK;
+}
+
+extern "C" int mdg_cov_accum_i8_stats(const void* ws, int64_t n_tokens, int64_t n_feat, unsigned long long* executed_mfma,
+                                      void* stream) {
+  MDG_CLEAR();
+  MDG_CHECK_ARG(ws && executed_mfma && n_tokens > 0 && n_feat > 0 && n_feat % TI == 0, "mdg_cov_accum_i8_stats: bad arguments");
+  const char* ints = (const char*)ws + align_up(planes_bytes(n_tokens, n_feat), 256);
+  const void* src = ints + (size_t)(3 * n_feat + 2) * sizeof(int);
+  hipStream_t st = (hipStream_t)stream;
+  MDG_HIP(hipMemcpyAsync(executed_mfma, src, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  MDG_HIP(hipStreamSynchronize(st));
   return MDG_OK;
 }

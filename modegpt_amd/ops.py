@@ -73,12 +73,14 @@ def cov_accum(sigma: torch.Tensor, x: torch.Tensor, n_heads: int = 1, relu: bool
                                 sigma.data_ptr(), feat, feat * feat, wsp, nbytes, _stream(x)), "mdg_cov_accum")
 
 
-def cov_accum_i8(sigma: torch.Tensor, x: torch.Tensor, events=None) -> int:
+def cov_accum_i8(sigma: torch.Tensor, x: torch.Tensor, events=None, mfma_stats: Optional[dict] = None) -> int:
     """sigma (lower triangle) += X^T X for one bf16 matrix through the int8 digit-plane kernel (csrc/cov_i8.hip).
     Returns the number of digit planes the product used (5 or 6), or 0 when the per-column depth statistic sent the batch
     to the fp64 kernel (the result is valid either way; I8_STATS counts the routes).  Feature count must be a multiple
     of 128.  events: optional pair of torch.cuda.Event(enable_timing=True), each recorded once already, re-recorded
-    around the product kernel alone."""
+    around the product kernel alone.  mfma_stats: optional dict; its "executed" entry is increased by the number of
+    v_mfma instructions the product kernel issued (it skips digit planes that are all-zero over a tile panel) and "dense"
+    by what a kernel without that skipping issues -- costs a stream synchronisation, for measurement only."""
     _need_gpu(sigma, x)
     lib = _lib.load()
     if sigma.dtype != torch.float64 or not sigma.is_contiguous() or sigma.dim() != 2:
@@ -98,8 +100,22 @@ def cov_accum_i8(sigma: torch.Tensor, x: torch.Tensor, events=None) -> int:
         check(lib.mdg_cov_accum_i8(x2.data_ptr(), x2.shape[0], n, x2.stride(0), sigma.data_ptr(), sigma.stride(0), wsp, nbytes,
                                    C.byref(used), None if events is None else events[0].cuda_event,
                                    None if events is None else events[1].cuda_event, _stream(x)), "mdg_cov_accum_i8")
+        if mfma_stats is not None and used.value in (5, 6):
+            done = C.c_ulonglong(0)
+            check(lib.mdg_cov_accum_i8_stats(wsp, x2.shape[0], n, C.byref(done), _stream(x)), "mdg_cov_accum_i8_stats")
+            mfma_stats["executed"] = mfma_stats.get("executed", 0) + done.value
+            mfma_stats["dense"] = mfma_stats.get("dense", 0) + i8_dense_mfma_count(x2.shape[0], n, used.value)
     I8_STATS[{5: "i8_5", 6: "i8_6"}.get(used.value, "fallback_f64")] += 1
     return used.value
+
+
+def i8_dense_mfma_count(n_tokens: int, n: int, planes: int) -> int:
+    """v_mfma_i32_32x32x32_i8 instructions of the digit-plane product without zero-plane skipping: every 32 x 32 block of
+    the tiles covering the lower triangle (128 x 128 tiles for five planes, 128 x 64 for six; the diagonal tiles whole), per
+    k-step of 32 tokens, planes (planes + 1) / 2 plane pairs."""
+    rb, nk = n // 128, -(-n_tokens // 32)
+    blocks = rb * (rb + 1) // 2 * 16 if planes == 5 else rb * (rb + 1) * 8
+    return blocks * nk * (planes * (planes + 1) // 2)
 
 
 # Which matrix cores accumulate the large covariances of a layer: "f64" (v_mfma_f64, the accumulation order of the

@@ -704,3 +704,44 @@ def test_cov_accum_multi_side_stream_overlap_changes_nothing(ops, dev, monkeypat
         O.cov_accum_heads(ref, q.cpu(), nh, hd)
     low = torch.tril(torch.ones(hd, hd, dtype=torch.bool))
     assert ((a[1].cpu() - ref)[:, low].abs().max() / ref.abs().max()).item() < 1e-12
+
+
+def test_cov_i8_zero_plane_skipping_is_exact(ops, dev):
+    """The product kernel skips digit planes that are all-zero over a tile panel in a k-step (piece masks written by the
+    split pass).  Data built so that the plane depth differs between row groups, between k-steps and between the two panels
+    of a tile -- blocks of tiny values (deep planes only there), blocks of exact zeros, single deep elements -- must still
+    match the fp64 kernel, and the executed-MFMA count must sit below the dense count yet above the three-plane floor."""
+    gen = torch.Generator().manual_seed(31)
+    T, n = 4096 + 17, 384
+    X = torch.randn(T, n, generator=gen)
+    X[:, 40:72] *= 2.0 ** -2                     # a 32-column group 2 binades down...
+    X[0, 40:72] = 1.0                            # ...against a column maximum of 1
+    X[1024:2048, 128:256] = 0                    # a whole tile panel of zeros over 32 k-steps
+    X[2048:2080, 300] = 2.0 ** -20               # a few deep elements: plane 3 / 4 in one piece only
+    X[3000, 10] = 2.0 ** -30
+    X = X.to(torch.bfloat16).to(dev)
+    S8 = torch.zeros(n, n, dtype=F64, device=dev)
+    S64 = torch.zeros_like(S8)
+    stats = {}
+    planes = ops.cov_accum_i8(S8, X, mfma_stats=stats)
+    assert planes == 5          # (the six-plane kernel multiplies every piece: skipping measured slower there)
+    ops.cov_accum(S64, X)
+    d = torch.sqrt(torch.diag(S64))
+    low = torch.tril(torch.ones(n, n, dtype=torch.bool, device=dev))
+    err = (((S8 - S64).abs() / (d[:, None] * d[None]))[low]).max().item()
+    assert err < 1e-12, err
+    pairs, floor_pairs = {5: (15, 9), 6: (21, 15)}[planes]
+    assert stats["dense"] == ops.i8_dense_mfma_count(T, n, planes)
+    assert stats["dense"] * floor_pairs // pairs <= stats["executed"] < stats["dense"], stats
+    # dense data of full depth in every piece: nothing to skip
+    Y = (torch.randn(2048, 128, generator=gen) * torch.pow(2.0, -torch.randint(0, 36, (2048, 128), generator=gen).float()))
+    Y = Y.to(torch.bfloat16).to(dev)
+    S = torch.zeros(128, 128, dtype=F64, device=dev)
+    st2 = {}
+    if ops.cov_accum_i8(S, Y, mfma_stats=st2):
+        assert st2["executed"] == st2["dense"], st2
+    # the six-plane route reports the dense count
+    g, u = torch.randn(3000, 256, generator=gen), torch.randn(3000, 256, generator=gen)
+    Z = (torch.nn.functional.silu(g) * u).to(torch.bfloat16).to(dev)
+    S6, st6 = torch.zeros(256, 256, dtype=F64, device=dev), {}
+    assert ops.cov_accum_i8(S6, Z, mfma_stats=st6) == 6 and st6["executed"] == st6["dense"] == ops.i8_dense_mfma_count(3000, 256, 6)
