@@ -256,14 +256,32 @@ def main():
     }
     if i8:
         f = shape["d_ff"]
+        # The five-plane kernel skips digit planes that are all-zero over a tile panel; `achieved` prices the MFMA work it
+        # actually issued.  The executed / dense instruction ratio of the timed launches is read back from the library on a
+        # replay of the same batches (the data is deterministic), outside the timed region.
+        stats, routes_before = {}, dict(ops.I8_STATS)
+        replay = torch.zeros(f, f, dtype=torch.float64, device=dev)
+        for b in batches:
+            ops.cov_accum_i8(replay, b["h"], mfma_stats=stats)
+        del replay
+        ops.I8_STATS.update(routes_before)
+        executed_fraction = stats["executed"] / stats["dense"] if stats.get("dense") else 1.0
+        dense_equivalent = achieved
+        achieved = achieved * executed_fraction
         out["roofline"] = {
             "bound": "mfma", "achieved": achieved, "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s",
-            "frac": achieved / INT8_MFMA_PEAK_TOPS, "traffic": traffic,
+            "frac": achieved / INT8_MFMA_PEAK_TOPS, "executed_fraction": executed_fraction,
+            "dense_equivalent_tops": dense_equivalent,
+            "achieved_is": "int8 ops of the v_mfma instructions the kernel issued (mdg_cov_accum_i8_stats: executed / dense "
+                           "instruction count of these batches x the dense op count below) / their summed durations; "
+                           "dense_equivalent_tops counts the skipped all-zero planes as if multiplied",
+            "traffic": traffic,
             "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), profiles/r01_cov_i8_hbm_traffic.json",
             "kernel": "i8_syrk_kernel on sigma_mlp (v_mfma_i32_32x32x32_i8; the 15 (5 planes) or 21 (6 planes) digit-plane "
                       "pair products of one calibration batch per launch, timed alone by events the library records around it)",
             "launches": n_launch, "avg_launch_ms": ms / n_launch, "op_per_launch": flops / n_launch,
-            "op_count": "plane pairs (15 or 21, see routes) x tokens x n (n + 1): the SYRK count of each product, 2 ops per multiply-add",
+            "op_count": "dense count: plane pairs (15 or 21, see routes) x tokens x n (n + 1), the SYRK count of each product, "
+                        "2 ops per multiply-add",
             "fp64_syrk_equivalent_tflops": n_launch * batches[0]["h"].shape[0] * f * (f + 1) / (ms * 1e-3) / 1e12,
             "routes": dict(ops.I8_STATS),
             "note": "sigma_x goes through the same kernel; sigma_q / sigma_k (1.4 % of the work) and any batch whose columns the "
