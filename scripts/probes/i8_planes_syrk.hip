@@ -40,7 +40,11 @@ constexpr int TJ = (NW == 8 && WBLK == 2) ? 128 : 64;
 constexpr int WCOLS = TJ / 32;               // waves along J
 constexpr int BK = 32;        // tokens per stage = one MFMA k-step
 constexpr int PANEL_A = TILE * BK, PANEL_B = TJ * BK;   // bytes of one plane of an operand in a stage
-constexpr int STAGE = S * (PANEL_A + PANEL_B);          // 30 KB
+#ifndef KSUB
+#define KSUB 1      // MFMA k-steps (32 tokens) per LDS stage: -DKSUB=2 halves the number of barriers / LDS-DMA round trips per token
+#endif
+constexpr int SUBSTAGE = S * (PANEL_A + PANEL_B);       // 30 KB
+constexpr int STAGE = KSUB * SUBSTAGE;
 constexpr int NBUF = NBUF_;                  // LDS ring: NBUF - 1 stages in flight behind the one being consumed
 constexpr int GA = TILE / 32, GB = TJ / 32;  // 32-row groups per operand
 constexpr int PIECES = S * (GA + GB);
@@ -80,17 +84,18 @@ __global__ __launch_bounds__(64 * NW, OCC) void planes_syrk(const int8_t* __rest
   // an MFMA k-half read 512 contiguous bytes
   auto issue_stage = [&](int kt, int buf) {
 #pragma unroll
-    for (int q = 0; q < (PIECES + NW - 1) / NW; q++) {
-      const int p = wave + NW * q;
-      if (p < PIECES) {
+    for (int q = 0; q < (KSUB * PIECES + NW - 1) / NW; q++) {
+      const int pu = wave + NW * q;
+      const int u = pu / PIECES, p = pu % PIECES;
+      if (pu < KSUB * PIECES) {
         const bool isA = p < GA * S;
         const int pp = isA ? p : p - GA * S;
         const int s = isA ? pp / GA : pp / GB, g = isA ? pp % GA : pp % GB;
         // blocked plane layout written by the split pass: [plane][row group of 32][k-step][half][row][16 B] -- a piece is
         // 1 KB contiguous in memory (8 full cache lines per wave instruction instead of 32 quarter-used ones)
         const int64_t G = (isA ? bi * (TILE / 32) : bj * (TJ / 32)) + g;
-        const int8_t* src = planes + ((s * (int64_t)(n / 32) + G) * (T / BK) + kt) * 1024 + lane * 16;
-        unsigned char* dst = lds + buf * STAGE + (isA ? s * PANEL_A : S * PANEL_A + s * PANEL_B) + g * 1024;
+        const int8_t* src = planes + ((s * (int64_t)(n / 32) + G) * (T / BK) + kt * KSUB + u) * 1024 + lane * 16;
+        unsigned char* dst = lds + buf * STAGE + u * SUBSTAGE + (isA ? s * PANEL_A : S * PANEL_A + s * PANEL_B) + g * 1024;
         glds16(src, dst);
       }
     }
@@ -102,17 +107,19 @@ __global__ __launch_bounds__(64 * NW, OCC) void planes_syrk(const int8_t* __rest
 #pragma unroll
     for (int a = 0; a < WBLK; a++) acc[k][a] = (i32x16)0;
 
-  const int nk = T / BK;
+  const int nk = T / BK / KSUB;   // stages
   for (int p = 0; p < NBUF - 1 && p < nk; p++) issue_stage(p, p);
   for (int kt = 0; kt < nk; kt++) {
     const int buf = kt % NBUF;
     // waves 0,1 issue 8 glds per stage, waves 2,3 issue 7; stages kt+1, kt+2 may stay in flight: at most 14 outstanding
     // retires stage kt on every wave (the tail drains everything)
-    if (kt + NBUF - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * (PIECES / NW)) : "memory");
+    if (kt + NBUF - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * (KSUB * PIECES / NW)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (kt + NBUF - 1 < nk) issue_stage(kt + NBUF - 1, (kt + NBUF - 1) % NBUF);
-    const unsigned char* base = lds + buf * STAGE;
+#pragma unroll
+    for (int u = 0; u < KSUB; u++) {
+    const unsigned char* base = lds + buf * STAGE + u * SUBSTAGE;
     const int r = lane & 31, h = lane >> 5;
     i32x4 fa[S][WBLK], fb[S];
 #pragma unroll
@@ -129,6 +136,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void planes_syrk(const int8_t* __rest
 #pragma unroll
         for (int a = 0; a < WBLK; a++)
           acc[s + t][a] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s][a], fb[t], acc[s + t][a], 0, 0, 0);
+    }
   }
 
   if (out) {
@@ -230,7 +238,7 @@ int main() {
     CK(hipGetLastError());
     CK(hipFuncSetAttribute((const void*)planes_syrk, hipFuncAttributeMaxDynamicSharedMemorySize, NBUF * STAGE));
     const double ops = (S * (S + 1) / 2) * 2.0 * (double)tiles * TILE * TJ * T;   // 15 plane pairs, 2 ops per MAC (128 x 64 tiles incl. the diagonal's upper halves)
-    printf("waves %d, tile 128 x %d, %d workgroup(s) per CU, ring %d: ", NW, TJ, OCC, NBUF);
+    printf("planes %d, waves %d, tile 128 x %d, %d workgroup(s) per CU, ring %d x %d tokens: ", S, NW, TJ, OCC, NBUF, 32 * KSUB);
     printf("n=%d T=%d: %.2f ms  %.0f int8 TOP/s (%.1f%% of 5000) incl. the diagonal tiles' upper halves; useful (SYRK count) %.0f TOP/s\n", n, T,
            best, ops / best / 1e9, ops / best / 1e9 / 50.0, (S * (S + 1) / 2) * (double)n * (n + 1) * T / best / 1e9);
   }
