@@ -403,9 +403,14 @@ __global__ __launch_bounds__(64 * NW, (P == 5 && NW == 4) ? MDG_I8_OCC5 : 1) voi
   const int nk = a.nk;
 
   // staging: (GA + GB) P pieces of 1 KB per stage (A: P planes x 4 row groups, B: P planes x 2 or 4); wave w issues pieces w, w + NW, ...
-  // dA / dB: plane depth of the stage's A and B panels -- planes >= depth are all-zero over the panel's rows in this k-step
-  // and are neither loaded nor multiplied (see depth_of below)
-  auto issue_stage = [&](int kt, int buf, int dA, int dB) {
+  // mA / mB: piece masks of the stage's A and B row groups, one byte per 32-row group; planes at or beyond a group's depth
+  // (group_depth below) are all-zero there in this k-step and are neither loaded nor multiplied
+  constexpr int MIN_DEPTH = P - 2;
+  auto group_depth = [&](unsigned m, int g) {   // 1 + deepest plane with a nonzero in group g, but at least MIN_DEPTH
+    const unsigned byte = (m >> (8 * g)) & 0xFFu;
+    return max(MIN_DEPTH, min(P, 32 - __builtin_clz(byte | 1u)));
+  };
+  auto issue_stage = [&](int kt, int buf, unsigned mA, unsigned mB) {
 #pragma unroll
     for (int q = 0; q < (PIECES + NW - 1) / NW; q++) {
       const int p = wave + NW * q;
@@ -413,7 +418,7 @@ __global__ __launch_bounds__(64 * NW, (P == 5 && NW == 4) ? MDG_I8_OCC5 : 1) voi
         const bool isA = p < GA * P;
         const int pp = isA ? p : p - GA * P;
         const int s = isA ? pp / GA : pp / GB, g = isA ? pp % GA : pp % GB;
-        if (SKIP && s >= (isA ? dA : dB)) continue;   // an all-zero piece: nothing will read it
+        if (SKIP && s >= group_depth(isA ? mA : mB, g)) continue;   // an all-zero piece: nothing will read it
         const int64_t G = (isA ? bi * (TI / 32) : bj * (TJ / 32)) + g;
         const signed char* src = a.planes + ((s * groups + G) * (int64_t)nk + kt) * 1024 + lane * 16;
         unsigned char* dst = lds + buf * STAGE_BYTES + (isA ? s * PA : P * PA + s * PB) + g * 1024;
@@ -478,28 +483,18 @@ __global__ __launch_bounds__(64 * NW, (P == 5 && NW == 4) ? MDG_I8_OCC5 : 1) voi
     va = z[bi];                                                               // groups 4 bi .. 4 bi + 3
     vb = TJ == 128 ? z[bj] : (z[bj >> 1] >> ((bj & 1) * 16)) & 0xFFFFu;       // groups 4 bj .. + 3, or 2 bj, 2 bj + 1
   };
-  // depth of a panel = 1 + deepest plane with a nonzero piece in any of its row groups, but at least MIN_DEPTH: the planes
-  // below MIN_DEPTH form the unconditional, straight-line part of a step, each deeper plane a conditional block of its own
-  // (branching around single MFMAs / fragment reads instead makes hipcc put an lgkmcnt(0) in front of every LDS read; nine
-  // straight-line variants behind a switch make it spill the 160 accumulators at the merges)
-  constexpr int MIN_DEPTH = P - 2;
-  auto depth_of = [&](unsigned m) {
-    m = __builtin_amdgcn_readfirstlane(m);
-    m |= m >> 16;
-    m = (m | (m >> 8)) & 0xFFu;
-    return max(MIN_DEPTH, min(P, 32 - __builtin_clz(m | 1u)));
-  };
-  int dA_cur = P, dB_cur = P;
-  unsigned vA_next = ~0u, vB_next = ~0u;
+  // The planes below MIN_DEPTH form the unconditional, straight-line part of a step, each deeper plane of each 32-row block a
+  // conditional block of its own (branching around single MFMAs / fragment reads instead makes hipcc put an lgkmcnt(0) in front
+  // of every LDS read; nine straight-line variants behind a switch make it spill the 160 accumulators at the merges)
+  unsigned mA_cur = ~0u, mB_cur = ~0u, vA_next = ~0u, vB_next = ~0u;
   unsigned executed = 0;
   if (SKIP) {
-    unsigned va, vb;
-    load_masks(0, va, vb);
-    dA_cur = depth_of(va);
-    dB_cur = depth_of(vb);
+    load_masks(0, mA_cur, mB_cur);
+    mA_cur = __builtin_amdgcn_readfirstlane(mA_cur);
+    mB_cur = __builtin_amdgcn_readfirstlane(mB_cur);
     if (nk > 1) load_masks(1, vA_next, vB_next);
   }
-  for (int p = 0; p < RING - 1 && p < nk; p++) issue_stage(p, p, dA_cur, dB_cur);
+  for (int p = 0; p < RING - 1 && p < nk; p++) issue_stage(p, p, mA_cur, mB_cur);
   for (int k0 = 0; k0 < nk; k0 += FLUSH_STEPS) {
     const int k1 = min(nk, k0 + FLUSH_STEPS);
     for (int kt = k0; kt < k1; kt++) {
@@ -509,13 +504,17 @@ __global__ __launch_bounds__(64 * NW, (P == 5 && NW == 4) ? MDG_I8_OCC5 : 1) voi
       if (kt + RING - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * PER_WAVE_MIN) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      int dA_nx = P, dB_nx = P;
+      unsigned mA_nx = ~0u, mB_nx = ~0u;
       if (SKIP) {   // (RING == 2) masks of stage kt + 1 arrived with the wait above; fetch those of kt + 2
-        dA_nx = depth_of(vA_next);
-        dB_nx = depth_of(vB_next);
+        mA_nx = __builtin_amdgcn_readfirstlane(vA_next);
+        mB_nx = __builtin_amdgcn_readfirstlane(vB_next);
         if (kt + 2 < nk) load_masks(kt + 2, vA_next, vB_next);
       }
-      if (kt + RING - 1 < nk) issue_stage(kt + RING - 1, (kt + RING - 1) % RING, dA_nx, dB_nx);
+      if (kt + RING - 1 < nk) issue_stage(kt + RING - 1, (kt + RING - 1) % RING, mA_nx, mB_nx);
+      int dAb[WB];
+#pragma unroll
+      for (int b = 0; b < WB; b++) dAb[b] = SKIP ? group_depth(mA_cur, wr * WB + b) : P;
+      const int dBw = SKIP ? group_depth(mB_cur, wc) : P;
       const unsigned char* base = lds + buf * STAGE_BYTES;
       const int r = lane & 31, h = lane >> 5;
       // The step: planes below MIN_DEPTH of both panels unconditionally -- ONE set of fragment reads, all their pairs -- then,
@@ -540,34 +539,31 @@ __global__ __launch_bounds__(64 * NW, (P == 5 && NW == 4) ? MDG_I8_OCC5 : 1) voi
             for (int b = 0; b < WB; b++)
               acc[s + t][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s][b], fb[t], acc[s + t][b], 0, 0, 0);
           }
+      int deep_mfmas = 0;
 #pragma unroll
       for (int d = MIN_DEPTH; d < P; d++) {
-        if (!SKIP || dA_cur > d) {   // plane d of the A panel with planes t < P - d of B (all below MIN_DEPTH, already in registers)
-          i32x4 fd[WB];
 #pragma unroll
-          for (int b = 0; b < WB; b++) fd[b] = *(const i32x4*)(base + d * PA + (wr * WB + b) * 1024 + h * 512 + r * 16);
+        for (int b = 0; b < WB; b++)
+          if (dAb[b] > d) {   // plane d of A block b with planes t < P - d of B (all below MIN_DEPTH: already in registers)
+            const i32x4 fd = *(const i32x4*)(base + d * PA + (wr * WB + b) * 1024 + h * 512 + r * 16);
 #pragma unroll
-          for (int t = 0; t < P - d; t++) {
-            pairs++;
-#pragma unroll
-            for (int b = 0; b < WB; b++)
-              acc[d + t][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fd[b], fb[t], acc[d + t][b], 0, 0, 0);
+            for (int t = 0; t < P - d; t++) acc[d + t][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fd, fb[t], acc[d + t][b], 0, 0, 0);
+            deep_mfmas += P - d;
           }
-        }
-        if (!SKIP || dB_cur > d) {   // plane d of the B panel with planes s < P - d of A
+        if (dBw > d) {        // plane d of the B block with planes s < P - d of both A blocks
           const i32x4 fd = *(const i32x4*)(base + P * PA + d * PB + wc * 1024 + h * 512 + r * 16);
 #pragma unroll
-          for (int s2 = 0; s2 < P - d; s2++) {
-            pairs++;
+          for (int s2 = 0; s2 < P - d; s2++)
 #pragma unroll
             for (int b = 0; b < WB; b++)
               acc[s2 + d][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s2][b], fd, acc[s2 + d][b], 0, 0, 0);
-          }
+          deep_mfmas += (P - d) * WB;
         }
       }
+      executed += deep_mfmas;
       executed += pairs * WB;
-      dA_cur = dA_nx;
-      dB_cur = dB_nx;
+      mA_cur = mA_nx;
+      mB_cur = mB_nx;
     }
     flush();
   }
