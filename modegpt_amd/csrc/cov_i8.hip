@@ -336,7 +336,10 @@ __global__ __launch_bounds__(64 * NW, (P == 5 && NW == 4) ? MDG_I8_OCC5 : 1) voi
   // six-plane kernel the same code measured SLOWER on SiLU-gated data (51.1 -> 61.8 ms although 27 % of the MFMAs and a third
   // of the loads go away): its steps are already as short as the LDS-DMA round trip a 2-stage ring has to cover, and deeper
   // rings with load counts that vary per stage (switch over s_waitcnt immediates; tried) lose more in L2 than they gain.
-  constexpr bool SKIP = MDG_I8_SKIP_ZERO && RING == 2 && P == 5;
+#ifndef MDG_I8_SKIP_ZERO6
+#define MDG_I8_SKIP_ZERO6 0
+#endif
+  constexpr bool SKIP = MDG_I8_SKIP_ZERO && RING == 2 && (P == 5 || MDG_I8_SKIP_ZERO6);
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   // Tile (bi, bj): bi = 128-row block, bj = TJ-row block of the lower region (bj <= bi for 128 x 128 tiles, bj <= 2 bi + 1 for
   // 128 x 64).  XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2, so workgroup w belongs
