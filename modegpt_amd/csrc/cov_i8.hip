@@ -311,7 +311,7 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 #define MDG_I8_OCC5 2
 #endif
 #ifndef MDG_I8_SB5
-#define MDG_I8_SB5 4
+#define MDG_I8_SB5 2    // 2 x 2 tiles of 128 x 128 (with zero-plane skipping: 26.7 ms against 27.5 for 4 x 4, 27.6 row-major)
 #endif
 #ifndef MDG_I8_SB6
 #define MDG_I8_SB6 2
