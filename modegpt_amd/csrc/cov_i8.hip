@@ -332,12 +332,11 @@ __global__ __launch_bounds__(64 * NW, (P == 5 && NW == 4) ? MDG_I8_OCC5 : 1) voi
   constexpr int STAGE_BYTES = P * (PA + PB);       // 30 / 36 KB (40 KB for the 128 x 128 tile)
   constexpr int PIECES = (GA + GB) * P;            // 1 KB pieces per stage
   constexpr int PER_WAVE_MIN = PIECES / NW;        // every wave issues at least this many LDS-DMA loads per stage
-  // Five-plane kernel only (and 2-stage rings only: the counted waits of the deeper rings need a fixed load count).  On the
-  // six-plane kernel the same code measured SLOWER on SiLU-gated data (51.1 -> 61.8 ms although 27 % of the MFMAs and a third
-  // of the loads go away): its steps are already as short as the LDS-DMA round trip a 2-stage ring has to cover, and deeper
-  // rings with load counts that vary per stage (switch over s_waitcnt immediates; tried) lose more in L2 than they gain.
+  // 2-stage rings only (the counted waits of the deeper rings need a fixed load count).  Both routes: five planes 35.5 -> 26.5
+  // ms on Gaussian columns, six planes 51.8 -> 44.6 ms on SiLU-gated ones (the six-plane kernel first measured SLOWER, 62 ms:
+  // see b_half below -- one shift applied to a just-loaded mask exposed a full memory round trip per step).
 #ifndef MDG_I8_SKIP_ZERO6
-#define MDG_I8_SKIP_ZERO6 0
+#define MDG_I8_SKIP_ZERO6 1
 #endif
   constexpr bool SKIP = MDG_I8_SKIP_ZERO && RING == 2 && (P == 5 || MDG_I8_SKIP_ZERO6);
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -408,7 +407,10 @@ __global__ __launch_bounds__(64 * NW, (P == 5 && NW == 4) ? MDG_I8_OCC5 : 1) voi
   // staging: (GA + GB) P pieces of 1 KB per stage (A: P planes x 4 row groups, B: P planes x 2 or 4); wave w issues pieces w, w + NW, ...
   // mA / mB: piece masks of the stage's A and B row groups, one byte per 32-row group; planes at or beyond a group's depth
   // (group_depth below) are all-zero there in this k-step and are neither loaded nor multiplied
-  constexpr int MIN_DEPTH = P - 2;
+#ifndef MDG_I8_MIN_DEPTH6
+#define MDG_I8_MIN_DEPTH6 4   // (experiments: 6 runs the six-plane kernel's mask machinery without skipping anything)
+#endif
+  constexpr int MIN_DEPTH = P == 6 ? MDG_I8_MIN_DEPTH6 : P - 2;
   auto group_depth = [&](unsigned m, int g) {   // 1 + deepest plane with a nonzero in group g, but at least MIN_DEPTH
     const unsigned byte = (m >> (8 * g)) & 0xFFu;
     return max(MIN_DEPTH, min(P, 32 - __builtin_clz(byte | 1u)));
@@ -421,7 +423,9 @@ __global__ __launch_bounds__(64 * NW, (P == 5 && NW == 4) ? MDG_I8_OCC5 : 1) voi
         const bool isA = p < GA * P;
         const int pp = isA ? p : p - GA * P;
         const int s = isA ? pp / GA : pp / GB, g = isA ? pp % GA : pp % GB;
+#ifndef MDG_I8_EXPERIMENT_LOAD_ALL   // (timing experiment: skip the MFMAs only)
         if (SKIP && s >= group_depth(isA ? mA : mB, g)) continue;   // an all-zero piece: nothing will read it
+#endif
         const int64_t G = (isA ? bi * (TI / 32) : bj * (TJ / 32)) + g;
         const signed char* src = a.planes + ((s * groups + G) * (int64_t)nk + kt) * 1024 + lane * 16;
         unsigned char* dst = lds + buf * STAGE_BYTES + (isA ? s * PA : P * PA + s * PB) + g * 1024;
@@ -484,8 +488,12 @@ __global__ __launch_bounds__(64 * NW, (P == 5 && NW == 4) ? MDG_I8_OCC5 : 1) voi
   auto load_masks = [&](int kt, unsigned& va, unsigned& vb) {
     const unsigned* z = (const unsigned*)(a.zmask + (int64_t)kt * mgroups);   // n / 32 is a multiple of 4: dword-aligned rows
     va = z[bi];                                                               // groups 4 bi .. 4 bi + 3
-    vb = TJ == 128 ? z[bj] : (z[bj >> 1] >> ((bj & 1) * 16)) & 0xFFFFu;       // groups 4 bj .. + 3, or 2 bj, 2 bj + 1
+    vb = TJ == 128 ? z[bj] : z[bj >> 1];   // groups 4 bj .. + 3; or 2 bj, 2 bj + 1 in one half of the dword (see b_half)
   };
+  // 128 x 64 tiles: the B panel's two mask bytes are one half of the loaded dword.  Taken when the value is USED, a step after
+  // the load -- applied to the load's result at once, the shift makes hipcc wait for the load on the spot (the six-plane kernel
+  // measured 62 instead of 51 ms that way, whatever it skipped)
+  auto b_half = [&](unsigned m) { return TJ == 128 ? m : (m >> ((bj & 1) * 16)) & 0xFFFFu; };
   // The planes below MIN_DEPTH form the unconditional, straight-line part of a step, each deeper plane of each 32-row block a
   // conditional block of its own (branching around single MFMAs / fragment reads instead makes hipcc put an lgkmcnt(0) in front
   // of every LDS read; nine straight-line variants behind a switch make it spill the 160 accumulators at the merges)
@@ -494,7 +502,7 @@ __global__ __launch_bounds__(64 * NW, (P == 5 && NW == 4) ? MDG_I8_OCC5 : 1) voi
   if (SKIP) {
     load_masks(0, mA_cur, mB_cur);
     mA_cur = __builtin_amdgcn_readfirstlane(mA_cur);
-    mB_cur = __builtin_amdgcn_readfirstlane(mB_cur);
+    mB_cur = b_half(__builtin_amdgcn_readfirstlane(mB_cur));
     if (nk > 1) load_masks(1, vA_next, vB_next);
   }
   for (int p = 0; p < RING - 1 && p < nk; p++) issue_stage(p, p, mA_cur, mB_cur);
@@ -510,14 +518,19 @@ __global__ __launch_bounds__(64 * NW, (P == 5 && NW == 4) ? MDG_I8_OCC5 : 1) voi
       unsigned mA_nx = ~0u, mB_nx = ~0u;
       if (SKIP) {   // (RING == 2) masks of stage kt + 1 arrived with the wait above; fetch those of kt + 2
         mA_nx = __builtin_amdgcn_readfirstlane(vA_next);
-        mB_nx = __builtin_amdgcn_readfirstlane(vB_next);
+        mB_nx = b_half(__builtin_amdgcn_readfirstlane(vB_next));
         if (kt + 2 < nk) load_masks(kt + 2, vA_next, vB_next);
       }
       if (kt + RING - 1 < nk) issue_stage(kt + RING - 1, (kt + RING - 1) % RING, mA_nx, mB_nx);
       int dAb[WB];
 #pragma unroll
+#ifdef MDG_I8_EXPERIMENT_MULTIPLY_ALL   // (timing experiment, wrong results: skip the loads only)
+      for (int b = 0; b < WB; b++) dAb[b] = P;
+      const int dBw = P;
+#else
       for (int b = 0; b < WB; b++) dAb[b] = SKIP ? group_depth(mA_cur, wr * WB + b) : P;
       const int dBw = SKIP ? group_depth(mB_cur, wc) : P;
+#endif
       const unsigned char* base = lds + buf * STAGE_BYTES;
       const int r = lane & 31, h = lane >> 5;
       // The step: planes below MIN_DEPTH of both panels unconditionally -- ONE set of fragment reads, all their pairs -- then,
