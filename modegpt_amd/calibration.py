@@ -19,7 +19,7 @@ import torch
 
 from . import ops
 from .adapters.model_adapter import ModelAdapter
-from .model_utils import calib_device, dtype_p
+from .model_utils import dtype_p, local_device
 
 logger = logging.getLogger("MoDeGPT")
 
@@ -35,12 +35,13 @@ class SigmaBuffers:
 
     KINDS = ("mlp", "q", "k", "x")
 
-    def __init__(self, adapter: ModelAdapter, target_layers: Sequence[int], device=calib_device):
+    def __init__(self, adapter: ModelAdapter, target_layers: Sequence[int], device=None):
         L = adapter.n_layers
         hd, d, f = adapter.head_dim, adapter.d_model, adapter.get_n_inner()
         shapes = {"mlp": (f, f), "q": (adapter.n_heads, hd, hd), "k": (adapter.n_kv_heads, hd, hd), "x": (d, d)}
         self.lists: Dict[str, List[Optional[torch.Tensor]]] = {k: [None] * L for k in self.KINDS}
         self.layers = list(target_layers)
+        device = device or local_device()          # this rank's own GPU (calib_device upstream: src/calibration.py:83)
         for i in self.layers:
             for kind, shp in shapes.items():
                 self.lists[kind][i] = torch.zeros(*shp, dtype=dtype_p, device=device)
@@ -56,8 +57,9 @@ class SigmaBuffers:
 class BlockInfluence:
     """bi[l] = (1/n_texts) * sum over batches of mean_T sum_B (1 - cos(h_l, h_{l+1}))  (src/calibration.py:118-136)."""
 
-    def __init__(self, n_layers: int, device=calib_device):
+    def __init__(self, n_layers: int, device=None):
         self.n_layers = n_layers
+        device = device or local_device()
         self.acc = torch.zeros(n_layers, dtype=torch.float64, device=device)
 
     def add_batch(self, hidden_states) -> None:

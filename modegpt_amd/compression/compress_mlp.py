@@ -9,7 +9,7 @@ from torch import Tensor
 
 from .. import ops
 from ..adapters.model_adapter import MLPComponents, ModelAdapter
-from ..model_utils import d2, dtype_p
+from ..model_utils import dtype_p, local_device
 
 logger = logging.getLogger("MoDeGPT")
 
@@ -23,7 +23,7 @@ def _fl32(x: float) -> float:
 def get_ridge_scores(C: Tensor, layer_idx: int, ridge_lambda=1e-2) -> Tensor:
     """diag((C + fl32(lambda) I)^-1)  (compress_mlp.py:13-25) -- blocked Cholesky + triangular inverse on the
     fp64 MFMA, column norms of L^-1 instead of forming the inverse."""
-    C = C.to(dtype=dtype_p, device=d2)
+    C = C.to(dtype=dtype_p, device=local_device())
     return ops.ridge_scores(C, _fl32(ridge_lambda))
 
 
@@ -31,17 +31,17 @@ def get_ridge_scores(C: Tensor, layer_idx: int, ridge_lambda=1e-2) -> Tensor:
 def compress_weights(comps: MLPComponents, C: Tensor, keep_ratio: float, layer_idx: int, ridge_lambda: float):
     """compress_mlp.py:28-64.  Returns (W_u'^T [d, r], W_d' [r, d], W_g'^T [d, r] or None, rank), bf16 --
     the same orientation the reference returns (transposed views of the saved layout)."""
-    C = C.to(dtype=dtype_p, device=d2)
+    C = C.to(dtype=dtype_p, device=local_device())
     scores = get_ridge_scores(C, layer_idx=layer_idx, ridge_lambda=ridge_lambda)
     rank = int(C.shape[0] * keep_ratio)
     idx = ops.select_smallest_sorted(scores, rank)                    # topk(largest=False) + sort  (:45-47)
-    W_u = comps.up_proj.weight.detach().to(device=d2, dtype=torch.bfloat16)
+    W_u = comps.up_proj.weight.detach().to(device=local_device(), dtype=torch.bfloat16)
     up = ops.gather_rows(W_u, idx)                                    # W_u[topk, :]               (:49)
     gate = None
     if comps.gate_proj is not None:
-        W_g = comps.gate_proj.weight.detach().to(device=d2, dtype=torch.bfloat16)
+        W_g = comps.gate_proj.weight.detach().to(device=local_device(), dtype=torch.bfloat16)
         gate = ops.gather_rows(W_g, idx)                              # W_g[topk, :]               (:50)
-    W_d = comps.down_proj.weight.detach().to(device=d2)              # bf16 as is; fp16/fp32 widen exactly to fp64
+    W_d = comps.down_proj.weight.detach().to(device=local_device())              # bf16 as is; fp16/fp32 widen exactly to fp64
     down = ops.nystrom_down(C, idx, W_d, eps=1e-6)                    # [d, r] bf16                (:52-62)
     return up.T, down.T, (None if gate is None else gate.T), rank
 

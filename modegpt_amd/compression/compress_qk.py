@@ -9,7 +9,7 @@ from torch import Tensor
 
 from .. import _lib, ops
 from ..adapters.model_adapter import ModelAdapter
-from ..model_utils import d2, dtype_p
+from ..model_utils import dtype_p, local_device
 
 logger = logging.getLogger("MoDeGPT")
 
@@ -46,11 +46,11 @@ def compress_layer(adapter: ModelAdapter, layer_idx: int, rank: int, cov_q_list:
     n_heads, head_dim, arch, n_kv = adapter.n_heads, adapter.head_dim, adapter.arch, adapter.n_kv_heads
     comps = adapter.get_qk_components(layer_idx=layer_idx)
     mode, ridge_q, ridge_k = qk_mode_and_ridges(arch, n_kv != n_heads, adapter.config.ridge_qk)
-    cq = cov_q_list.to(device=d2, dtype=dtype_p)
-    ck = cov_k_list.to(device=d2, dtype=dtype_p)
+    cq = cov_q_list.to(device=local_device(), dtype=dtype_p)
+    ck = cov_k_list.to(device=local_device(), dtype=dtype_p)
     mask, q_rows, k_rows = ops.qk_select(cq, ck, rank, mode, ridge_q, ridge_k)
-    W_q = comps.query_proj.weight.detach().to(device=d2, dtype=torch.bfloat16)
-    W_k = comps.key_proj.weight.detach().to(device=d2, dtype=torch.bfloat16)
+    W_q = comps.query_proj.weight.detach().to(device=local_device(), dtype=torch.bfloat16)
+    W_k = comps.key_proj.weight.detach().to(device=local_device(), dtype=torch.bfloat16)
     Q_heads = ops.gather_rows(W_q, q_rows)   # [n_heads*rank, d]
     K_heads = ops.gather_rows(W_k, k_rows)   # [n_kv*rank, d]
     if (arch == "llama" or "qwen" in arch) and slice_dims:
@@ -78,8 +78,8 @@ def compress_head_llama_grouped(kv_head_idx: int, kv_head_ratio: int, cov_q_laye
     (K statistics with `ridge_lambda`, Q with sqrt_M's default), keep rank/2 pairs in score order, append the kept
     rows of K and of every query head of the group, and the mask.  Same kernel as compress_layer, one head at a time."""
     q0 = kv_head_idx * kv_head_ratio
-    cq = torch.stack([c.to(device=d2, dtype=dtype_p) for c in cov_q_layer[q0:q0 + kv_head_ratio]])
-    ck = cov_k_layer[kv_head_idx].to(device=d2, dtype=dtype_p)[None]
+    cq = torch.stack([c.to(device=local_device(), dtype=dtype_p) for c in cov_q_layer[q0:q0 + kv_head_ratio]])
+    ck = cov_k_layer[kv_head_idx].to(device=local_device(), dtype=dtype_p)[None]
     mask, _, _ = ops.qk_select(cq, ck, rank, _lib.MDG_QK_ROPE_GROUPED, _SQRT_M_DEFAULT_RIDGE, ridge_lambda)
     rows = mask[0]
     K_heads_out.append(_kept_rows(Wk_heads[kv_head_idx], rows.to(Wk_heads.device), slice_dims))
@@ -93,8 +93,8 @@ def compress_head_llama(C_q: Tensor, C_k: Tensor, Q_head: Tensor, K_head: Tensor
                         layer_rotary_mask: list, rank: int, slice_dims=True):
     """One head of an MHA Llama layer (compress_qk.py:387-436): default ridges for both statistics; the kept rows go
     to the lists as CPU bf16 tensors, as upstream."""
-    cq = C_q.to(device=d2, dtype=dtype_p)[None]
-    ck = C_k.to(device=d2, dtype=dtype_p)[None]
+    cq = C_q.to(device=local_device(), dtype=dtype_p)[None]
+    ck = C_k.to(device=local_device(), dtype=dtype_p)[None]
     mask, _, _ = ops.qk_select(cq, ck, rank, _lib.MDG_QK_ROPE_MHA, _SQRT_M_DEFAULT_RIDGE, _SQRT_M_DEFAULT_RIDGE)
     rows = mask[0]
     Q_heads_out.append(_kept_rows(Q_head, rows.to(Q_head.device), slice_dims).to(device="cpu", dtype=torch.bfloat16))
@@ -107,8 +107,8 @@ def compress_head_opt(C_q: Tensor, C_k: Tensor, Q_head: Tensor, K_head: Tensor, 
                       out_Q_heads: list, out_K_heads: list, out_Q_bias: list, out_K_bias: list, rank: int):
     """One OPT head (compress_qk.py:439-476): score_j = |sqrt(Cq)[:, j]| * |sqrt(Ck)[:, j]|, top-`rank` columns in score
     order; rows (to the CPU, as upstream) and the matching bias entries are appended."""
-    cq = C_q.to(device=d2, dtype=dtype_p)[None]
-    ck = C_k.to(device=d2, dtype=dtype_p)[None]
+    cq = C_q.to(device=local_device(), dtype=dtype_p)[None]
+    ck = C_k.to(device=local_device(), dtype=dtype_p)[None]
     mask, _, _ = ops.qk_select(cq, ck, rank, _lib.MDG_QK_OPT, _SQRT_M_DEFAULT_RIDGE, _SQRT_M_DEFAULT_RIDGE)
     rows = mask[0]
     out_Q_heads.append(Q_head[rows.to(Q_head.device)].to(device="cpu"))

@@ -9,7 +9,7 @@ from torch import Tensor
 
 from .. import ops
 from ..adapters.model_adapter import ModelAdapter
-from ..model_utils import d2, dtype_p
+from ..model_utils import dtype_p, local_device
 
 logger = logging.getLogger("MoDeGPT")
 
@@ -27,7 +27,7 @@ def vo_rank_rule(head_dim: int, keep_ratio: float, arch: str) -> int:
 def _regularised_cov(sqrt_C: Tensor) -> Tensor:
     """The per-head functions of the reference receive sqrt(C + ridge I) (and its inverse) from their caller; the kernel
     works from C + ridge I itself: one fp64-MFMA product recovers it."""
-    S = sqrt_C.to(device=d2, dtype=dtype_p).contiguous()
+    S = sqrt_C.to(device=local_device(), dtype=dtype_p).contiguous()
     C = torch.empty_like(S)
     ops.gemm(S, S, C)
     return C
@@ -44,8 +44,8 @@ def compress_head_grouped(kv_head_idx: int, kv_head_ratio: int, head_dim: int, r
     if kv_head_ratio < 2:
         raise NotImplementedError("a group of one query head is the MHA case: use compress_head")
     r0, c0 = kv_head_idx * head_dim, kv_head_idx * kv_head_ratio * head_dim
-    Wv_h = W_v[r0:r0 + head_dim, :].detach().to(d2)
-    Wo_g = W_o[:, c0:c0 + kv_head_ratio * head_dim].detach().to(d2)
+    Wv_h = W_v[r0:r0 + head_dim, :].detach().to(local_device())
+    Wo_g = W_o[:, c0:c0 + kv_head_ratio * head_dim].detach().to(local_device())
     _, _, v64, o64 = ops.vo_compress(_regularised_cov(sqrt_C), Wv_h, Wo_g, kv_head_ratio, 1, head_dim, rank, 0.0,
                                      want_f64=True)
     if slice_dims:
@@ -70,8 +70,8 @@ def compress_head(head_idx: int, head_dim: int, rank_i: int, W_v: Tensor, W_o: T
     """One head of an MHA layer (compress_vo.py:162-223): the two-SVD variant; appends W_v' [rank, d] and W_o' [d, rank]
     (fp64), or with slice_dims=False writes them zero-padded into W_v / W_o in place."""
     s0 = head_idx * head_dim
-    Wv_h = W_v[s0:s0 + head_dim, :].detach().to(d2)
-    Wo_h = W_o[:, s0:s0 + head_dim].detach().to(d2)
+    Wv_h = W_v[s0:s0 + head_dim, :].detach().to(local_device())
+    Wo_h = W_o[:, s0:s0 + head_dim].detach().to(local_device())
     _, _, v64, o64 = ops.vo_compress(_regularised_cov(sqrt_C), Wv_h, Wo_h, 1, 1, head_dim, rank_i, 0.0, want_f64=True)
     if slice_dims:
         new_heads_V.append(v64)
@@ -96,14 +96,14 @@ def compress_vo(adapter: ModelAdapter, cov: List[Tensor], keep_ratios=None, slic
     n_heads, head_dim, arch, n_kv = adapter.n_heads, adapter.head_dim, adapter.arch, adapter.n_kv_heads
     for layer in target_layers:
         rank_i = vo_rank_rule(head_dim, keep_ratios[layer], arch)
-        C = cov[layer].to(device=d2, dtype=dtype_p)
+        C = cov[layer].to(device=local_device(), dtype=dtype_p)
         try:
             comps = adapter.get_attn_components(layer)
             W_v, W_o = comps.v_proj.weight, comps.o_proj.weight
         except Exception as e:  # same tolerance as compress_vo.py:47-53
             logger.warning(f"[VO] Layer {layer}: cannot access v_proj/o_proj: {e}")
             continue
-        V_heads, O_heads = ops.vo_compress(C, W_v.detach().to(d2), W_o.detach().to(d2), n_heads, n_kv, head_dim, rank_i,
+        V_heads, O_heads = ops.vo_compress(C, W_v.detach().to(local_device()), W_o.detach().to(local_device()), n_heads, n_kv, head_dim, rank_i,
                                            adapter.config.ridge_vo)
         adapter.save_layer(output_dir=adapter.config.temp_storage_dir, suffix="vo",
                            weights={"v_proj": V_heads, "o_proj": O_heads}, layer_idx=layer)

@@ -22,8 +22,24 @@ dtype_p = torch.float64      # statistics and factorizations
 dtype_f = torch.float16      # legacy "final" dtype (the artefacts are bf16)
 parallel = False             # the reference's two-GPU stub; multi-GPU here is sharding.py, not this flag
 conservative = True
-d1 = "cuda:0"
-d2 = "cuda:1" if parallel else "cuda:0"
+
+
+def local_rank() -> int:
+    """This process's GPU on the node: LOCAL_RANK under torchrun / bench.py's own launcher, else 0."""
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def local_device() -> str:
+    """Device string of this rank's GPU, evaluated at CALL time (one process per GPU: rank g works on cuda:g; the
+    reference is single-process and says "cuda:0" everywhere, src/model_utils.py:25-31)."""
+    return f"cuda:{local_rank()}"
+
+
+# The reference's names, kept because adapters / compressors import them by name.  Under torchrun LOCAL_RANK is in the
+# environment before this module is imported, so the constants already point at the rank's own GPU; code in this package
+# that can run before the environment is final (tests spawning ranks in-process) calls local_device() instead.
+d1 = local_device()
+d2 = "cuda:1" if parallel else local_device()
 calib_device = d2
 
 # architecture -> modeling file the checkpoint ships with (this engine's own, modegpt_amd/patchers/; file and class
@@ -60,8 +76,11 @@ def start_memory_usage_worker(path: str = "./.mem-usage", period_s: float = 1.0)
 
 
 def _causal_lm(source: str):
+    """device_map="auto" as upstream when this is the only process; one process per GPU keeps the whole model on its own card."""
     from transformers import AutoModelForCausalLM
-    return AutoModelForCausalLM.from_pretrained(source, device_map="auto", trust_remote_code=True, torch_dtype="auto")
+    sharded = int(os.environ.get("WORLD_SIZE", "1")) > 1
+    device_map = {"": local_rank()} if (sharded and torch.cuda.is_available()) else "auto"
+    return AutoModelForCausalLM.from_pretrained(source, device_map=device_map, trust_remote_code=True, torch_dtype="auto")
 
 
 def _tokenizer(source: str):
@@ -80,14 +99,14 @@ def load_model(model_name: str, device: int = 0):
     return model, _tokenizer(model_name), model.config
 
 
-def reload_compressed_model(model_dir: str, device="cuda:0", tokenizer_source: str = ""):
+def reload_compressed_model(model_dir: str, device=None, tokenizer_source: str = ""):
     """Load an original OR compressed checkpoint; a compressed one names its tokenizer in tokenizer_source.txt and
     its modeling file through config.auto_map (trust_remote_code)."""
     logger.info(f"Reloading compressed model from: {model_dir}")
     marker = os.path.join(model_dir, "tokenizer_source.txt")
     if not tokenizer_source:
         tokenizer_source = open(marker).read().strip() if os.path.exists(marker) else model_dir
-    model = _causal_lm(model_dir).to(device).eval()
+    model = _causal_lm(model_dir).to(device or local_device()).eval()
     return model, _tokenizer(tokenizer_source)
 
 

@@ -84,8 +84,9 @@ def main(trial=None, config: Optional[CompressionConfig] = None):
     model, tokenizer = reload_compressed_model(config.model)
     adapter = ModelAdapter.from_model(model=model, tokenizer=tokenizer)
     adapter.config = config
-    adapter.metrics["baseline-ppl"] = compute_perplexity(model, tokenizer, dataset=config.dataset, adapter=adapter)
-    logger.info(f"Baseline ppl: {adapter.metrics['baseline-ppl']}")
+    if rank == 0:   # (every rank holds the model; the metric is rank 0's business)
+        adapter.metrics["baseline-ppl"] = compute_perplexity(model, tokenizer, dataset=config.dataset, adapter=adapter)
+        logger.info(f"Baseline ppl: {adapter.metrics['baseline-ppl']}")
     _free()
 
     rotary_masks = []
@@ -93,8 +94,12 @@ def main(trial=None, config: Optional[CompressionConfig] = None):
         chunk = list(range(first, min(adapter.n_layers, first + LAYERS_PER_STEP)))
         rotary_masks.extend(compress_chunk(adapter, config, chunk, rank, world))
 
+    # All artefacts of all layers are now in temp_storage_dir as rank 0 needs them (its own + the gathered ones, the
+    # latter written by rank 0 alone: sharding.gather_layer_artifacts).  One barrier closes the collective phase -- no rank
+    # is still packing / writing when rank 0 starts reading -- and the process group is released here, so that the other
+    # ranks do not sit in a collective (and its timeout) while rank 0 converts, saves and evaluates.
+    sharding.finalize()
     if rank != 0:  # rank 0 alone writes the checkpoint
-        sharding.finalize()
         return None
     save_dir = os.path.join(config.output_dir, "model")
     adapter.convert_model(saved_layers_dir=config.temp_storage_dir)
@@ -108,7 +113,6 @@ def main(trial=None, config: Optional[CompressionConfig] = None):
     adapter.metrics[f"ppl-{config.dataset}"] = ppl
     adapter.save_metrics()
     logger.info(f"Compressed (PPL): {ppl}")
-    sharding.finalize()
     return ppl
 
 

@@ -125,10 +125,14 @@ def allgather_records(records: List[torch.Tensor], per_rank: int, world: int, fo
     return [recv[i, PRE:] for i in range(world * per_rank) if used[i] == 1]
 
 
-def gather_layer_artifacts(adapter, chunk: Sequence[int], mine: Sequence[int], rotary_masks, rank: int, world: int):
-    """After this rank compressed `mine`: all-gather everybody's layers of `chunk`, write the artefacts this rank
-    did not produce into temp_storage_dir (so convert_model finds layer_<i>_{mlp,qk,vo} for every i), and return
-    the chunk's rotary masks in layer order."""
+def gather_layer_artifacts(adapter, chunk: Sequence[int], mine: Sequence[int], rotary_masks, rank: int, world: int,
+                           writer_rank: int = 0):
+    """After this rank compressed `mine`: all-gather everybody's layers of `chunk` and return the chunk's rotary masks in
+    layer order.  ONLY `writer_rank` -- the rank that goes on to convert_model (run_modegpt.py) -- writes the artefacts it did
+    not produce into temp_storage_dir, so that it finds layer_<i>_{mlp,qk,vo} for every i.  All ranks may share one
+    temp_storage_dir (they do under torchrun: same --temp_storage_dir flag): every file has exactly one writer at any time --
+    its owner before the all-gather (which orders the owner's write before any other rank's access), then at most
+    writer_rank, through a temporary name + os.replace so that a reader never sees a half-written file."""
     rms = list(rotary_masks or [])
     if world == 1:
         return rms
@@ -147,11 +151,21 @@ def gather_layer_artifacts(adapter, chunk: Sequence[int], mine: Sequence[int], r
     for rec in allgather_records(records, per, world):
         layer, tensors, mask = unpack_layer(rec)
         masks[layer] = mask
-        if layer in mine:
+        if layer in mine or rank != writer_rank:
             continue
         groups = {"mlp": ("up", "gate", "down"), "qk": ("q_proj", "k_proj"), "vo": ("v_proj", "o_proj")}
         for suffix, names in groups.items():
             w = {k: tensors[k].clone() for k in names if k in tensors}
             if w:
-                adapter.save_layer(output_dir=adapter.config.temp_storage_dir, suffix=suffix, weights=w, layer_idx=layer)
+                _write_artifact(d, layer, suffix, w)
     return [masks[l] for l in chunk if masks.get(l) is not None]
+
+
+def _write_artifact(directory: str, layer: int, suffix: str, weights: Dict[str, torch.Tensor]) -> None:
+    """save_layer's file (model_adapter.py:184-191: torch.save of {name: bf16 tensor} as layer_<i>_<suffix>), written
+    atomically."""
+    os.makedirs(directory, exist_ok=True)
+    final = os.path.join(directory, f"layer_{layer}_{suffix}")
+    tmp = f"{final}.tmp{os.getpid()}"
+    torch.save(weights, tmp)
+    os.replace(tmp, final)

@@ -1,0 +1,155 @@
+"""The int8 digit-plane covariance (the DEFAULT route for sigma_mlp / sigma_x, ops.I8_MIN_FEATURES = 2048 and up) checked at the
+widths the product actually sends to it: 2048, 4096, 5120 (Qwen3-14B d), 11008 (Llama-2-7B d_ff), 14336 (Llama-3-8B d_ff),
+17408 (Qwen3-14B d_ff), one calibration batch of 16 x 2048 tokens, on Gaussian columns (five planes) AND SiLU-gated columns
+(six planes: what a real Llama MLP feeds the hook, LlamaAdapter.py:127-136).
+
+What is compared with what:
+  * n = 2048, 4096: the CPU oracle's fp64 H^T H (oracle/modegpt_oracle.py:cov_accum_tokens) directly;
+  * every width: the v_mfma_f64 kernel (ops.cov_accum, itself held to 1e-13 of the oracle by test_cov_golden / test_cov_shapes
+    and spot-checked against torch at full size in test_gpu_e2e.py), ENTRY-WISE over the lower triangle, normalised by
+    sqrt(sigma_ii sigma_jj): <= 1e-12 (tolerance of the route);
+  * every width: spot blocks against a plain torch fp64 product of the same columns + the trace checksum sum(x^2);
+  * n = 14336: the MLP rank selection (ridge scores -> k smallest, sorted) from sigma_i8 must be IDENTICAL to the one from
+    sigma_f64 (north_star: "rank selections bit-identical"), at keep 0.7 and 0.6 (BASELINE configs 3 and 4).
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import modegpt_oracle as O
+
+pytestmark = pytest.mark.gpu
+F64 = torch.float64
+T_BATCH = 16 * 2048
+WIDTHS = [2048, 4096, 5120, 11008, 14336, 17408]
+
+
+@pytest.fixture(scope="module")
+def ops(dev):
+    from modegpt_amd import ops as _ops
+    return _ops
+
+
+def gaussian(dev, tokens, feat, seed):
+    """bench.py's generator: z * c_j, c_j log-uniform[0.05, 2]."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    c = torch.exp(torch.empty(feat, device=dev).uniform_(math.log(0.05), math.log(2.0), generator=g))
+    return (torch.randn(tokens, feat, device=dev, generator=g) * c).to(torch.bfloat16)
+
+
+def silu_gated(dev, tokens, feat, seed):
+    """silu(g) * u with per-column scales: the shape of act_fn(gate_proj(x)) * up_proj(x), the input of down_proj."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    c = torch.exp(torch.empty(feat, device=dev).uniform_(math.log(0.05), math.log(2.0), generator=g))
+    a = torch.nn.functional.silu(torch.randn(tokens, feat, device=dev, generator=g))
+    a.mul_(torch.randn(tokens, feat, device=dev, generator=g)).mul_(c)
+    return a.to(torch.bfloat16)
+
+
+def entrywise_err(S, R):
+    """max over the lower triangle of |S - R|_ij / sqrt(R_ii R_jj), in row chunks (17408^2 fp64 temporaries are 2.4 GB each)."""
+    n = R.shape[0]
+    d = torch.sqrt(torch.diagonal(R))
+    d = torch.where(d > 0, d, torch.ones_like(d))
+    worst = 0.0
+    for r0 in range(0, n, 2048):
+        r1 = min(n, r0 + 2048)
+        e = (S[r0:r1] - R[r0:r1]).abs() / (d[r0:r1, None] * d[None, :])
+        rows = torch.arange(r0, r1, device=R.device)[:, None]
+        cols = torch.arange(n, device=R.device)[None, :]
+        e = torch.where(cols <= rows, e, torch.zeros_like(e))
+        worst = max(worst, e.max().item())
+    return worst
+
+
+def spot_and_trace(S, X, step):
+    """Blocks of 192 columns (straddling 128-row tile and 2 x 2 super-block borders) against torch's fp64 product -- entry-wise
+    over sqrt(sigma_ii sigma_jj) like everything else here -- and the trace."""
+    n = S.shape[0]
+    starts = sorted({0, 64, n // 2 - 96, n - 192, (n // 128 // 2) * 128 - 64, 3 * step % (n - 192)})
+    Xd = {s: X[:, s:s + 192].double() for s in starts}
+    nrm = {s: torch.sqrt((Xd[s] ** 2).sum(0)) for s in starts}
+    worst = 0.0
+    for si in starts:
+        for sj in starts:
+            if sj > si:
+                continue
+            want = Xd[si].T @ Xd[sj]
+            got = S[si:si + 192, sj:sj + 192]
+            if si == sj:
+                got, want = torch.tril(got), torch.tril(want)
+            elif sj + 192 > si:       # overlapping column ranges: part of the block lies above the diagonal
+                rows = torch.arange(si, si + 192, device=S.device)[:, None]
+                cols = torch.arange(sj, sj + 192, device=S.device)[None, :]
+                keep = cols <= rows
+                got, want = got * keep, want * keep
+            worst = max(worst, ((got - want).abs() / (nrm[si][:, None] * nrm[sj][None, :])).max().item())
+    tr = sum((X[:, c0:c0 + 2048].double() ** 2).sum().item() for c0 in range(0, n, 2048))
+    return worst, abs(torch.diagonal(S).sum().item() - tr) / tr
+
+
+@pytest.mark.parametrize("kind,planes", [("gaussian", 5), ("silu_gated", 6)])
+@pytest.mark.parametrize("n", WIDTHS)
+def test_i8_route_at_product_widths(ops, dev, n, kind, planes):
+    X = (gaussian if kind == "gaussian" else silu_gated)(dev, T_BATCH, n, 100 + n)
+    S8 = torch.zeros(n, n, dtype=F64, device=dev)
+    S64 = torch.zeros_like(S8)
+    stats = {}
+    assert ops.cov_accum_i8(S8, X, mfma_stats=stats) == planes
+    assert 0 < stats["executed"] <= stats["dense"]
+    ops.cov_accum(S64, X)
+    err = entrywise_err(S8, S64)
+    assert err < 1e-12, (n, kind, err)
+    spot, trace = spot_and_trace(S8, X, n)
+    assert spot < 1e-12 and trace < 1e-13, (n, kind, spot, trace)
+    if n <= 4096:   # straight against the oracle (CPU fp64; seconds at these widths)
+        ref = torch.zeros(n, n, dtype=F64)
+        O.cov_accum_tokens(ref, X.cpu())
+        assert entrywise_err(S8.cpu(), ref) < 1e-12
+    # a second batch accumulates on top (the hook's +=), and the mirrored, normalised result is exactly symmetric
+    X2 = (gaussian if kind == "gaussian" else silu_gated)(dev, 4096 + 40, n, 7 + n)
+    assert ops.cov_accum_i8(S8, X2) in (5, 6)
+    ops.cov_accum(S64, X2)
+    assert entrywise_err(S8, S64) < 1e-12
+    ops.cov_finalize(S8, 1.0 / (T_BATCH + 4136))
+    assert torch.equal(S8, S8.T)
+
+
+@pytest.mark.parametrize("kind,planes", [("gaussian", 5), ("silu_gated", 6)])
+def test_i8_route_across_the_int32_fold_with_super_blocks(ops, dev, kind, planes):
+    """n = 4096 (32 row blocks -> 16 x 16 super-block rows on 8 XCDs) with 65504 + 4000 tokens: the int32 classes are folded
+    into sigma once inside the launch and once at its end."""
+    n, T = 4096, 65504 + 4000
+    X = (gaussian if kind == "gaussian" else silu_gated)(dev, T, n, 11)
+    S8 = torch.zeros(n, n, dtype=F64, device=dev)
+    S64 = torch.zeros_like(S8)
+    assert ops.cov_accum_i8(S8, X) == planes
+    ops.cov_accum(S64, X)
+    assert entrywise_err(S8, S64) < 1e-12
+    ref = torch.zeros(n, n, dtype=F64)
+    O.cov_accum_tokens(ref, X.cpu())
+    assert entrywise_err(S8.cpu(), ref) < 1e-12
+
+
+@pytest.mark.parametrize("kind", ["gaussian", "silu_gated"])
+def test_mlp_rank_selection_is_identical_on_both_routes(ops, dev, kind):
+    """Llama-3-8B d_ff: ridge scores of sigma_i8 vs sigma_f64 (compress_mlp.py:13-25 with the fp32-rounded ridge of the
+    tests.sh recipe) select the SAME index set at keep 0.7 (rank 10035) and keep 0.6 (rank 8601)."""
+    n = 14336
+    mk = gaussian if kind == "gaussian" else silu_gated
+    S8 = torch.zeros(n, n, dtype=F64, device=dev)
+    S64 = torch.zeros_like(S8)
+    for b in range(2):
+        X = mk(dev, T_BATCH, n, 500 + b)
+        assert ops.cov_accum_i8(S8, X) in (5, 6)
+        ops.cov_accum(S64, X)
+        del X
+    ops.cov_finalize(S8, 1.0 / (2 * T_BATCH))
+    ops.cov_finalize(S64, 1.0 / (2 * T_BATCH))
+    lam = float(torch.tensor(1e-4, dtype=torch.float32).double())
+    sc8, sc64 = ops.ridge_scores(S8, lam), ops.ridge_scores(S64, lam)
+    assert ((sc8 - sc64).abs() / sc64).max().item() < 1e-9
+    for keep in (0.7, 0.6):
+        r = int(n * keep)
+        assert torch.equal(ops.select_smallest_sorted(sc8, r), ops.select_smallest_sorted(sc64, r)), (kind, keep)
