@@ -2,7 +2,9 @@
 """bench.py -- layers compressed / second (covariance + decomposition + rebuild), Llama-3-8B @ 30 %.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under torch.distributed.run -- RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment -- or plainly as
+     above: with WORLD_SIZE unset the script starts its own N ranks as fresh child processes, one per GPU, BEFORE it touches the
+     GPU, waits for them and exits with the worst of their exit codes)
 
 One STEP = one transformer layer taken through the whole hot path on synthetic Llama-3-8B-shaped inputs
 (BASELINE.json configs[2]): 32 calibration batches of 16 x 2048 tokens (= 512 samples) pushed
@@ -21,12 +23,19 @@ The JSON line also carries
                   durations (HIP events around each launch)
   cpu_baseline -- this repo's CPU oracle (torch-CPU fp64 restatement of the reference) timed on the host cores
                   on a bounded sample of the same workload (N = 1, rank 0 only)
+  value_f64_route / value_gated -- the SAME step loop timed again (N = 1 only, after the headline): everything on v_mfma_f64
+                  (--cov-mode f64: the reference's accumulation, no int8 route), and with SiLU-gated sigma_mlp activations (what
+                  a real Llama MLP feeds the hook: the depth statistic then picks six digit planes instead of five)
+  roofline.decomposition -- the compress_nystrom / compress_qk / compress_vo chain of the timed steps: fp64 flops executed
+                  (model below) / HIP-event time / the fp64 MFMA peak
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,7 +45,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from modegpt_amd import engine, ops, sharding  # noqa: E402
+from modegpt_amd import engine, ops, sharding  # noqa: E402  (imports only: nothing here touches the GPU)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X public fp64-matrix spec; bench also reports the measured issue rate
 INT8_MFMA_PEAK_TOPS = 5000.0  # dense int8 = 2x the bf16 rate per clock (MI355X_MICROARCH.md, matrix cores table)
@@ -48,6 +57,7 @@ class LaunchTimer:
 
     def __init__(self):
         self.pairs = []
+        self.dec = []
 
     def run(self, flops, fn):
         e0 = torch.cuda.Event(enable_timing=True)
@@ -57,20 +67,59 @@ class LaunchTimer:
         e1.record()
         self.pairs.append((flops, e0, e1))
 
-    def run_i8(self, ops_count, sigma, x):
+    def run_i8(self, syrk_count, sigma, x):
+        """Enqueue only (the route is chosen on the device, nothing here waits for the host); the launch is priced afterwards,
+        once the replay outside the timed region has told how many digit planes this batch takes: price_i8()."""
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()      # materialise the HIP events; the library re-records them around its product kernel
+        e0.record()      # materialise the HIP events; the library re-records them around its product launches
         e1.record()
-        planes = ops.cov_accum_i8(sigma, x, events=(e0, e1))
-        if planes:
-            self.pairs.append((ops_count * planes * (planes + 1) // 30, e0, e1))   # ops_count is quoted for 5 planes = 15 pairs
+        ops.cov_accum_i8(sigma, x, events=(e0, e1), report=False)
+        self.pairs.append((syrk_count, e0, e1))
+
+    def price_i8(self, planes_per_batch):
+        """SYRK count -> int8 ops: x plane pairs (15 for five planes, 21 for six) of the batch each launch worked on (launches
+        cycle through the batches in order); launches whose batch fell back to the fp64 kernel are dropped."""
+        nb, priced = len(planes_per_batch), []
+        for i, (cnt, e0, e1) in enumerate(self.pairs):
+            p = planes_per_batch[i % nb]
+            if p:
+                priced.append((cnt * (p * (p + 1) // 2), e0, e1))
+        self.pairs = priced
+
+    def run_decomposition(self, flops, fn):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self.dec.append((flops, e0, e1))
+        return out
 
     def summary(self):
         torch.cuda.synchronize()
         ms = sum(a.elapsed_time(b) for _, a, b in self.pairs)
         fl = sum(f for f, _, _ in self.pairs)
         return len(self.pairs), fl, ms
+
+    def decomposition_summary(self):
+        torch.cuda.synchronize()
+        return len(self.dec), sum(f for f, _, _ in self.dec), sum(a.elapsed_time(b) for _, a, b in self.dec)
+
+
+def decomposition_flops(shape, keep):
+    """fp64 flops the compress_* chain EXECUTES for one layer (this engine's formulation, DESIGN.md sections 3 and 5), big
+    terms only: ridge scores = Cholesky n^3/3 + triangular inverse n^3/3 (compress_mlp.py:13-25); Nystrom = gathered product
+    C[idx,:] W_d^T 2 r n d + Cholesky of C_kk r^3/3 + two triangular solves 2 r^2 d (compress_mlp.py:52-62); VO through the
+    Gram route = W_v C 2 (n_kv hd) d^2 + per-head Grams and factor products (compress_vo.py:112-223).  QK is a selection."""
+    n, d, nh, nkv, hd = shape["d_ff"], shape["d"], shape["n_heads"], shape["n_kv_heads"], shape["head_dim"]
+    r = int(n * keep)
+    from modegpt_amd.compression.compress_qk import qk_rank_rule
+    rv = qk_rank_rule(hd, keep, shape["arch"])
+    ridge = 2.0 * n ** 3 / 3.0
+    nystrom = 2.0 * r * n * d + r ** 3 / 3.0 + 2.0 * r * r * d
+    vo = 2.0 * nkv * hd * d * d + nkv * 2.0 * hd * d * hd + nkv * 2.0 * rv * hd * d + nh * 2.0 * d * hd * rv
+    return ridge + nystrom + vo
 
 
 def step(shape, adapter, layer_idx, batches, keep, n_texts, timer=None):
@@ -88,31 +137,54 @@ def step(shape, adapter, layer_idx, batches, keep, n_texts, timer=None):
             timer.run(flops, lambda: engine.accumulate(covs, b, shape))
         else:  # engine.accumulate's i8 route spelled out, so that the dominant kernel (i8_syrk_kernel on sigma_mlp) can be
             #    timed alone: the library records the two events right around that launch
-            timer.run_i8(15 * t * f * (f + 1), covs["mlp"], b["h"])     # 15 plane-pair products, SYRK count each
+            timer.run_i8(t * f * (f + 1), covs["mlp"], b["h"])          # SYRK count; x 15 or 21 plane-pair products afterwards
             ops.cov_accum_multi([(covs["x"], b["x"], 1), (covs["q"], b["q"], nh), (covs["k"], b["k"], nkv)], mode="i8")
     engine.finalize(covs, n_texts)
-    tensors, mask = engine.compress_layer(adapter, layer_idx, covs, keep)
+    if timer is None:
+        tensors, mask = engine.compress_layer(adapter, layer_idx, covs, keep)
+    else:
+        tensors, mask = timer.run_decomposition(decomposition_flops(shape, keep),
+                                                lambda: engine.compress_layer(adapter, layer_idx, covs, keep))
     return tensors, mask, covs
 
 
-def cpu_baseline(shape, weights, covs_dev, sample_tokens, n_tokens_full, keep, ridges, gpu_out):
-    """Oracle timed on the host: covariance on `sample_tokens` tokens (cost is exactly linear in tokens, scaled to
-    the full count), decomposition + rebuild in full on the sigma of the GPU run (copied back), so the same call
-    doubles as a full-size parity check of the GPU result."""
+def entrywise_err(S, R):
+    """max over the lower triangle of |S - R|_ij / sqrt(R_ii R_jj) (row chunks: the temporaries of a 14336^2 matrix are 1.6 GB)."""
+    n = R.shape[-1]
+    d = torch.sqrt(torch.diagonal(R, dim1=-2, dim2=-1))
+    d = torch.where(d > 0, d, torch.ones_like(d))
+    worst = 0.0
+    for r0 in range(0, n, 2048):
+        r1 = min(n, r0 + 2048)
+        e = (S[..., r0:r1, :] - R[..., r0:r1, :]).abs() / (d[..., r0:r1, None] * d[..., None, :])
+        rows = torch.arange(r0, r1, device=R.device)[:, None]
+        cols = torch.arange(n, device=R.device)[None, :]
+        worst = max(worst, torch.where(cols <= rows, e, torch.zeros_like(e)).max().item())
+    return worst
+
+
+def cpu_baseline(shape, weights, covs_dev, sample, n_tokens_full, keep, ridges, gpu_out, gpu_sig_sample):
+    """Oracle timed on the host: covariance of the four hooks on `sample` (the first rows of calibration batch 0, copied to
+    the host; the cost is exactly linear in tokens and is scaled to the full count), decomposition + rebuild in full on the
+    sigma of the GPU run (copied back) -- so the same call doubles as a full-size parity check of the GPU result: the oracle's
+    sigma of the sample against what the GPU's default route (gpu_sig_sample) made of the same rows, entry-wise, and the
+    oracle's compressed tensors against the GPU's."""
     from oracle import modegpt_oracle as O
-    g = torch.Generator().manual_seed(7)
     f, d, nh, nkv, hd = shape["d_ff"], shape["d"], shape["n_heads"], shape["n_kv_heads"], shape["head_dim"]
-    acts = {k: torch.randn(sample_tokens, n, generator=g).to(torch.bfloat16)
-            for k, n in (("h", f), ("x", d), ("q", nh * hd), ("k", nkv * hd))}
+    sample_tokens = sample["h"].shape[0]
     sig = {"mlp": torch.zeros(f, f, dtype=torch.float64), "x": torch.zeros(d, d, dtype=torch.float64),
            "q": torch.zeros(nh, hd, hd, dtype=torch.float64), "k": torch.zeros(nkv, hd, hd, dtype=torch.float64)}
     t0 = time.perf_counter()
-    O.cov_accum_tokens(sig["mlp"], acts["h"])
-    O.cov_accum_tokens(sig["x"], acts["x"].view(1, sample_tokens, d))
-    O.cov_accum_heads(sig["q"], acts["q"], nh, hd)
-    O.cov_accum_heads(sig["k"], acts["k"], nkv, hd)
+    if shape["arch"] == "opt":
+        O.cov_accum_tokens_relu(sig["mlp"], sample["h"])
+    else:
+        O.cov_accum_tokens(sig["mlp"], sample["h"])
+    O.cov_accum_tokens(sig["x"], sample["x"].view(1, sample_tokens, d))
+    O.cov_accum_heads(sig["q"], sample["q"], nh, hd)
+    O.cov_accum_heads(sig["k"], sample["k"], nkv, hd)
     t_cov_sample = time.perf_counter() - t0
-    del sig, acts
+    sigma_err = {k: entrywise_err(gpu_sig_sample[k].cpu(), sig[k]) for k in sig}
+    del sig
     covs = {k: v.cpu() for k, v in covs_dev.items()}
     w = {k: v.cpu() for k, v in weights.items()}
     t0 = time.perf_counter()
@@ -120,6 +192,10 @@ def cpu_baseline(shape, weights, covs_dev, sample_tokens, n_tokens_full, keep, r
     t_dec = time.perf_counter() - t0
     t_cov_full = t_cov_sample * (n_tokens_full / sample_tokens)
     parity = {
+        "sigma_vs_oracle_entrywise_max": sigma_err,
+        "sigma_check": (f"the four statistics of the first {sample_tokens} tokens of batch 0 through the engine's default route "
+                        "(int8 digit planes for sigma_mlp / sigma_x unless --cov-mode f64) against the oracle's fp64 H^T H of the "
+                        "same rows: max over the lower triangle of |diff| / sqrt(s_ii s_jj)"),
         "mlp_idx_identical": bool(torch.equal(out["aux"]["mlp"][0], gpu_out["mlp_idx"].cpu())),
         "qk_mask_identical": bool(torch.equal(out["mask"], gpu_out["mask"].cpu())),
         "up_identical": bool(torch.equal(out["mlp"]["up"], gpu_out["up"].cpu())),
@@ -167,7 +243,7 @@ def rope_gather_roofline(shape, keep, dev, launches=20):
             "workload": f"q projection [16, 2048, {n_h} x {r}] of {hd}-wide heads, {n_kv} kv masks"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
@@ -177,16 +253,97 @@ def main():
     ap.add_argument("--batch_size", type=int, default=16, help="samples of 2048 tokens per batch")
     ap.add_argument("--keep", type=float, default=0.7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip value_f64_route / value_gated (the same step loop on the fp64 route and on SiLU-gated data)")
     ap.add_argument("--cov-mode", default=None, choices=["f64", "i8"],
-                    help="matrix cores for sigma_mlp / sigma_x: f64 (v_mfma_f64) or i8 (exact digit planes on v_mfma_i32_i8); "
-                         "default: ops.COV_MODE (env MODEGPT_COV_MODE, else f64)")
-    a = ap.parse_args()
+                    help="matrix cores for sigma_mlp / sigma_x: i8 (fp64 result emulated by digit planes on v_mfma_i32_i8, <= 1e-12; "
+                         "the default, ops.COV_MODE / env MODEGPT_COV_MODE) or f64 (v_mfma_f64, the reference's accumulation)")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="no kernels: launcher, rendezvous, record packing and the one all-gather on synthetic records "
+                         "(runs on CPU / gloo; prints value null)")
+    return ap.parse_args(argv)
 
+
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a torchrun environment: start N ranks of this same command line as FRESH child
+    processes (one per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment), wait,
+    and return the worst exit code.  Called before this process has made any GPU call: the parent never initialises HIP, the
+    children start from a clean interpreter (no fork of a GPU context, no exec from an initialised one)."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst, pending = 0, set(range(n))
+    while pending:
+        for r in sorted(pending):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            pending.discard(r)
+            if rc != 0:
+                worst = worst or rc
+                for o in pending:            # one rank failed: the others would sit in a collective until its timeout
+                    procs[o].terminate()
+        time.sleep(0.2)
+    return worst
+
+
+def plumbing_only(a, rank, world):
+    """Everything around the kernels on synthetic records: rendezvous, barrier, pack_layer, the padded all-gather, unpack."""
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))) if torch.cuda.is_available() else torch.device("cpu")
+    g = torch.Generator().manual_seed(100 + rank)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    records = []
+    for i in range(a.steps):
+        li, r = rank * a.steps + i, 8 + rank + i            # ragged: ranks differ per layer
+        t = {k: torch.randn(r, 16, generator=g).to(torch.bfloat16).to(dev) for k in ("up", "gate", "q_proj", "k_proj", "v_proj")}
+        t["down"] = torch.randn(16, r, generator=g).to(torch.bfloat16).to(dev)
+        t["o_proj"] = torch.randn(16, r, generator=g).to(torch.bfloat16).to(dev)
+        records.append(sharding.pack_layer(li, t, torch.arange(r).reshape(1, r) + li))
+    gathered = sharding.allgather_records(records, a.steps, world)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    layers = sorted(sharding.unpack_layer(rec)[0] for rec in gathered)
+    assert layers == list(range(world * a.steps)), layers
+    if rank == 0:
+        print(json.dumps({"metric": "transformer layers compressed/sec (covariance+decomp+rebuild), Llama-3-8B @30%", "value": None,
+                          "unit": "layers/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "plumbing_only": True,
+                          "backend": dist.get_backend() if world > 1 else None, "gathered_layers": len(layers),
+                          "allgather_s": elapsed}))
+    sharding.finalize()
+
+
+def timed_steps(shape, adapter, layer_ids, batches, keep, n_texts, timer=None):
+    """K steps back to back between two synchronisations; returns (seconds, per-step outputs)."""
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = [(li,) + step(shape, adapter, li, batches, keep, n_texts, timer) for li in layer_ids]
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, outs
+
+
+def main():
+    a = parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a.gpus))
     if a.cov_mode:
         ops.COV_MODE = a.cov_mode
     rank, world = sharding.init_from_env()
     if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.plumbing_only:
+        return plumbing_only(a, rank, world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py measures the HIP path and there is no GPU here (no CPU fallback exists by design); "
+                         "--plumbing-only exercises the launcher and the all-gather without kernels")
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -224,31 +381,58 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     assert len(gathered) == world * a.steps
+    del gathered, records
 
+    i8 = ops.COV_MODE == "i8" and shape["arch"] != "opt"
+    stats = {}
+    if i8:
+        # The product kernel skips digit planes that are all-zero over a tile panel; `achieved` prices the MFMA work it
+        # actually issued.  Route and executed / dense instruction ratio of the timed launches are read back from the library
+        # on a replay of the same batches (the data and the integer route statistic are deterministic), outside the timed region.
+        replay = torch.zeros(shape["d_ff"], shape["d_ff"], dtype=torch.float64, device=dev)
+        routes_before = dict(ops.I8_STATS)
+        planes_per_batch = [ops.cov_accum_i8(replay, b["h"], mfma_stats=stats) for b in batches]
+        ops.I8_STATS.update(routes_before)
+        del replay
+        timer.price_i8(planes_per_batch)
     n_launch, flops, ms = timer.summary()
-    i8 = ops.COV_MODE == "i8" and shape["arch"] != "opt" and n_launch > 0
-    achieved = flops / (ms * 1e-3) / 1e12
+    n_dec, dec_flops, dec_ms = timer.decomposition_summary()
+    i8 = i8 and n_launch > 0
+    achieved = flops / (ms * 1e-3) / 1e12 if n_launch else 0.0
     # HBM bytes per launch come from a separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run of the same kernel on the
-    # same four launch shapes (PMC passes cannot ride along a timed run); only valid for the default workload.
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_cov_i8_hbm_traffic.json" if i8 else "r01_cov_hbm_traffic.json")
-    if os.path.exists(tpath) and a.model == "llama-3-8b" and a.batch_size == 16:
-        with open(tpath) as f:
-            traffic = json.load(f)["hbm_bytes_per_launch"]
+    # same launch shape (PMC passes cannot ride along a timed run); only valid for the default workload.
+    traffic, tfile = None, None
+    for cand in (("r02_cov_i8_hbm_traffic.json", "r01_cov_i8_hbm_traffic.json") if i8 else ("r01_cov_hbm_traffic.json",)):
+        tpath = os.path.join(ROOT, "profiles", cand)
+        if os.path.exists(tpath) and a.model == "llama-3-8b" and a.batch_size == 16:
+            with open(tpath) as f:
+                traffic, tfile = json.load(f)["hbm_bytes_per_launch"], cand
+            break
+    dec_tf = dec_flops / (dec_ms * 1e-3) / 1e12 if n_dec else None
+    decomposition = None if not n_dec else {
+        "bound": "mfma", "achieved": dec_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dec_tf / FP64_MFMA_PEAK_TFLOPS,
+        "kernel": "the compress_nystrom + compress_qk + compress_vo chain of one layer (potrf / triangular inverse / gathered GEMM / "
+                  "potrs / Gram-route VO: gemm_f64_kernel around potrf_diag_kernel and syevj_kernel), HIP events around the chain",
+        "avg_ms_per_layer": dec_ms / n_dec, "flop_per_layer": dec_flops / n_dec, "layers": n_dec,
+        "flop_count": "executed: 2 n^3 / 3 (Cholesky + triangular inverse for the ridge scores) + 2 r n d + r^3 / 3 + 2 r^2 d (Nystrom) "
+                      "+ 2 (n_kv hd) d^2 + head-sized products (VO Gram route); bench.py decomposition_flops()",
+        "share_of_step": dec_ms / n_dec / (elapsed / a.steps * 1e3)}
     out = {
         "metric": "transformer layers compressed/sec (covariance+decomp+rebuild), Llama-3-8B @30%",
         "value": world * a.steps / elapsed, "unit": "layers/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "i8 digit planes of the bf16 activations (int32 accumulate, folded in f64; exact)" if i8 else "f64",
+        "dtype": ("fp64 result emulated on int8 MFMA digit planes (int32 accumulate, folded in f64; <= 1e-12 entry-wise of the "
+                  "fp64 product, measured per run in cpu_baseline.full_size_parity_vs_oracle)") if i8 else "f64",
         "data": "synthetic",
         "config": {"workload": f"{a.model} shapes, {n_texts} calibration samples x 2048 tokens in {a.batches} batches "
                                f"of {a.batch_size}, keep ratio {a.keep} (compression {1 - a.keep:.0%}), ridges "
                                f"{ridges}, one layer per step per GPU", "layers_per_gpu": a.steps,
+                   "activations": "Gaussian columns x per-feature scale log-uniform[0.05, 2] (SURVEY 8d's generator); the same "
+                                  "loop on SiLU-gated sigma_mlp activations: value_gated",
                    "parallelism": f"layer-sharded x{world}, one all-gather"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                     "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), "
-                                     "profiles/r01_cov_hbm_traffic.json",
+                     "traffic_unit": f"HBM bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), profiles/{tfile}",
                      "kernel": "cov_accum_multi_kernel (v_mfma_f64_16x16x4_f64; sigma_mlp + sigma_x + sigma_q + sigma_k of "
                                "one calibration batch in one launch)", "launches": n_launch,
                      "avg_launch_ms": ms / n_launch, "flop_per_launch": flops / n_launch,
@@ -256,15 +440,6 @@ def main():
     }
     if i8:
         f = shape["d_ff"]
-        # The five-plane kernel skips digit planes that are all-zero over a tile panel; `achieved` prices the MFMA work it
-        # actually issued.  The executed / dense instruction ratio of the timed launches is read back from the library on a
-        # replay of the same batches (the data is deterministic), outside the timed region.
-        stats, routes_before = {}, dict(ops.I8_STATS)
-        replay = torch.zeros(f, f, dtype=torch.float64, device=dev)
-        for b in batches:
-            ops.cov_accum_i8(replay, b["h"], mfma_stats=stats)
-        del replay
-        ops.I8_STATS.update(routes_before)
         executed_fraction = stats["executed"] / stats["dense"] if stats.get("dense") else 1.0
         dense_equivalent = achieved
         achieved = achieved * executed_fraction
@@ -276,19 +451,21 @@ def main():
                            "instruction count of these batches x the dense op count below) / their summed durations; "
                            "dense_equivalent_tops counts the skipped all-zero planes as if multiplied",
             "traffic": traffic,
-            "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), profiles/r01_cov_i8_hbm_traffic.json",
+            "traffic_unit": f"HBM bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), profiles/{tfile}",
             "kernel": "i8_syrk_kernel on sigma_mlp (v_mfma_i32_32x32x32_i8; the 15 (5 planes) or 21 (6 planes) digit-plane "
                       "pair products of one calibration batch per launch, timed alone by events the library records around it)",
             "launches": n_launch, "avg_launch_ms": ms / n_launch, "op_per_launch": flops / n_launch,
             "op_count": "dense count: plane pairs (15 or 21, see routes) x tokens x n (n + 1), the SYRK count of each product, "
                         "2 ops per multiply-add",
             "fp64_syrk_equivalent_tflops": n_launch * batches[0]["h"].shape[0] * f * (f + 1) / (ms * 1e-3) / 1e12,
-            "routes": dict(ops.I8_STATS),
+            "routes": ops.i8_route_counts(dev),
+            "routes_are": "every int8-route request of this process so far (warm-up, timed steps, the replay above), counted on "
+                          "the device by the kernel that ran",
             "note": "sigma_x goes through the same kernel; sigma_q / sigma_k (1.4 % of the work) and any batch whose columns the "
-                    "per-column depth statistic finds too heavy-tailed for six planes go through the v_mfma_f64 kernel (--cov-mode f64 runs everything there: "
-                    "0.909 of the fp64 peak, DESIGN.md section 7)",
+                    "per-column depth statistic finds too heavy-tailed for six planes go through the v_mfma_f64 kernel (--cov-mode f64 runs everything there)",
             "power_note": "while this kernel loops the device sits at its power cap (rocm-smi: 1330 W, sclk 1.94 GHz instead of 2.4; "
                           "scripts/probes/i8_clock_power.py): at that clock the int8 pipe peaks at 4.0 POP/s; `peak` above is the guide's 2.4 GHz figure"}
+    out["roofline"]["decomposition"] = decomposition
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         li, tensors, mask, covs = last
         gpu_out = dict(tensors)
@@ -298,9 +475,9 @@ def main():
         sc = ops.ridge_scores(covs["mlp"], _fl32(ridges["nystrom_ridge"]))
         gpu_out["mlp_idx"] = ops.select_smallest_sorted(sc, int(shape["d_ff"] * a.keep))
         out["roofline"]["measured_mfma_f64_issue_rate_tflops"] = ops.probe_mfma_f64(4096)
-        if i8:  # the same sigma_mlp batch through the v_mfma_f64 kernel, for the record
+        h = batches[0]["h"]
+        if i8:  # the same sigma_mlp batch through the v_mfma_f64 kernel, for the record, and the two routes against each other
             scratch = torch.zeros_like(covs["mlp"])
-            h = batches[0]["h"]
             ops.cov_accum(scratch, h)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -312,40 +489,66 @@ def main():
             out["roofline"]["f64_route"] = {"kernel": "cov_accum_kernel (v_mfma_f64_16x16x4_f64) on the same sigma_mlp batch",
                                             "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                             "frac": tf / FP64_MFMA_PEAK_TFLOPS, "avg_launch_ms": e0.elapsed_time(e1) / 2}
-            # ... and the six-plane route, which the depth statistic picks for the SiLU-gated MLP statistic of a real Llama
-            # (the bench's Gaussian columns take five planes): a gated batch of the same shape through the same entry point
-            if shape["arch"] != "opt":
-                gen = torch.Generator(device=dev).manual_seed(4242)
-                g = torch.randn(h.shape, generator=gen, device=dev, dtype=torch.float32)
-                g = torch.nn.functional.silu(g).mul_(torch.randn(h.shape, generator=gen, device=dev, dtype=torch.float32))
-                hg = g.to(torch.bfloat16)
-                del g
-                scratch.zero_()
-                routes_before = dict(ops.I8_STATS)
-                st6 = {}
-                used = ops.cov_accum_i8(scratch, hg, events=(e0, e1), mfma_stats=st6)
-                frac6 = st6["executed"] / st6["dense"] if st6.get("dense") else 1.0
-                ms6 = []
-                for _ in range(2):
-                    used = ops.cov_accum_i8(scratch, hg, events=(e0, e1))
-                    torch.cuda.synchronize()
-                    ms6.append(e0.elapsed_time(e1))
-                ops.I8_STATS.update(routes_before)      # not part of the timed region's route count
-                pairs = {5: 15, 6: 21}.get(used)
-                if pairs:
-                    top = pairs * hg.shape[0] * shape["d_ff"] * (shape["d_ff"] + 1) / (sum(ms6) / len(ms6) * 1e-3) / 1e12
-                    out["roofline"]["gated_route"] = {
-                        "kernel": "i8_syrk_kernel on a SiLU-gated sigma_mlp batch of the same shape (outside the timed region)",
-                        "planes": used, "achieved": top * frac6, "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s",
-                        "frac": top * frac6 / INT8_MFMA_PEAK_TOPS, "executed_fraction": frac6, "dense_equivalent_tops": top,
-                        "avg_launch_ms": sum(ms6) / len(ms6)}
-                del hg
-            del scratch
-        out["cpu_baseline"] = cpu_baseline(shape, layers[li], covs, 2048, n_texts * 2048, a.keep, ridges, gpu_out)
+            s8 = torch.zeros_like(scratch)
+            for _ in range(3):
+                ops.cov_accum_i8(s8, h, report=False)
+            out["roofline"]["sigma_i8_vs_f64_entrywise_max"] = entrywise_err(s8, scratch)   # one full batch x 3, both routes
+            del scratch, s8
+        # the first rows of batch 0 through the engine's default route, for the sigma check against the oracle
+        n_sample = min(8192, h.shape[0])
+        sample_dev = {k: batches[0][k][:n_sample] for k in ("h", "x", "q", "k")}
+        sig_sample = engine.new_covs(shape, dev)
+        engine.accumulate(sig_sample, sample_dev, shape)
+        sample = {k: v.cpu() for k, v in sample_dev.items()}
+        out["cpu_baseline"] = cpu_baseline(shape, layers[li], covs, sample, n_texts * 2048, a.keep, ridges, gpu_out, sig_sample)
+        del sig_sample
         if shape["arch"] != "opt":
             out["next_rows"] = {"rope_gather": rope_gather_roofline(shape, a.keep, dev)}
     elif rank == 0:
         out["cpu_baseline"] = None
+    del last
+    if rank == 0 and world == 1 and not a.no_extra_legs and shape["arch"] != "opt":
+        ids = [first + a.warmup + i for i in range(a.steps)]
+        if i8:
+            # (1) the faithful route: the SAME step loop with every covariance on v_mfma_f64 (SURVEY section 7's parity path)
+            ops.COV_MODE = "f64"
+            t64 = LaunchTimer()
+            sec, _ = timed_steps(shape, adapter, ids, batches, a.keep, n_texts, t64)
+            nl, fl, msl = t64.summary()
+            out["value_f64_route"] = {"value": len(ids) / sec, "unit": "layers/s", "ms_per_step": sec / len(ids) * 1e3, "steps": len(ids),
+                                      "dtype": "f64", "cov_kernel_tflops": fl / (msl * 1e-3) / 1e12,
+                                      "cov_kernel_frac_of_fp64_peak": fl / (msl * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                                      "avg_launch_ms": msl / nl,
+                                      "what": "same workload and loop, --cov-mode f64: cov_accum_multi_kernel (v_mfma_f64) for all four statistics"}
+            ops.COV_MODE = "i8"
+            # (2) SiLU-gated sigma_mlp activations, what a real Llama MLP feeds the hook (LlamaAdapter.py:127-136): six planes
+            gated = []
+            for b, bt in enumerate(batches):
+                gen = torch.Generator(device=dev).manual_seed(4242 + b)
+                g = torch.nn.functional.silu(torch.randn(bt["h"].shape, generator=gen, device=dev, dtype=torch.float32))
+                g.mul_(torch.randn(bt["h"].shape, generator=gen, device=dev, dtype=torch.float32))
+                gated.append({"h": g.to(torch.bfloat16), "x": bt["x"], "q": bt["q"], "k": bt["k"]})
+                del g
+            before = ops.i8_route_counts(dev)
+            step(shape, adapter, ids[0], gated, a.keep, n_texts)                                  # warm-up of the six-plane kernel
+            tg = LaunchTimer()
+            sec, _ = timed_steps(shape, adapter, ids, gated, a.keep, n_texts, tg)
+            after = ops.i8_route_counts(dev)
+            st6 = {}
+            scratch = torch.zeros(f, f, dtype=torch.float64, device=dev)
+            used = ops.cov_accum_i8(scratch, gated[0]["h"], mfma_stats=st6)
+            del scratch, gated
+            nl, _, msl = tg.summary()
+            frac6 = st6["executed"] / st6["dense"] if st6.get("dense") else 1.0
+            pairs = {5: 15, 6: 21}.get(used, 15)
+            tops_dense = pairs * nl * tokens * f * (f + 1) / (msl * 1e-3) / 1e12
+            out["value_gated"] = {"value": len(ids) / sec, "unit": "layers/s", "ms_per_step": sec / len(ids) * 1e3, "steps": len(ids),
+                                  "planes": used, "avg_launch_ms": msl / nl, "executed_fraction": frac6,
+                                  "achieved": tops_dense * frac6, "peak": INT8_MFMA_PEAK_TOPS, "unit_kernel": "TOP/s",
+                                  "frac": tops_dense * frac6 / INT8_MFMA_PEAK_TOPS, "dense_equivalent_tops": tops_dense,
+                                  "routes": {k: after[k] - before[k] for k in after},
+                                  "what": "same loop, sigma_mlp activations silu(g) * u (g, u ~ N(0,1)) instead of Gaussian columns; "
+                                          "sigma_x / sigma_q / sigma_k inputs unchanged"}
     if rank == 0:
         print(json.dumps(out))
     sharding.finalize()

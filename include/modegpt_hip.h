@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define MDG_ABI_VERSION 3 /* 2: w_dtype on mdg_nystrom_down / mdg_vo_compress, mdg_rope_gather added; 3: mdg_cov_accum_i8_stats added */
+#define MDG_ABI_VERSION 4 /* 2: w_dtype on mdg_nystrom_down / mdg_vo_compress, mdg_rope_gather added; 3: mdg_cov_accum_i8_stats added;
+                             4: mdg_cov_accum_i8 chooses its route on the device (route_counts argument, no host synchronisation) */
 
 enum mdg_status {
   MDG_OK = 0,
@@ -82,13 +83,19 @@ int mdg_cov_accum_multi(int n, const mdg_cov_problem* problems, int dtype, void*
  * tokens (the exact int32 bound).  Each call measures, per column, the share of its nonzero elements more than 10 binades below the column maximum and picks
  * P = 5 (share <= 1/64 everywhere: within ~2e-13 of sigma's scale), P = 6 (<= 1/4: <= ~1e-13 on gated activations) or
  * runs mdg_cov_accum on the batch itself (heavier tails, columns dominated by a few massive activations).
- * *used_i8 (host, optional) reports the route: 5, 6, or 0 for the fp64 kernel.  n_feat must be a multiple of 128.
- * SYNCHRONISES once (the route decision).  ws: mdg_cov_accum_i8_ws_bytes (about 6 bytes per element of x).
- * ev_start / ev_stop: optional hipEvent_t recorded on `stream` right before / after the product kernel (bench.py times the
- * dominant kernel alone with them); NULL otherwise. */
+ * The route is chosen ON THE DEVICE: the call enqueues the five-plane product, the six-plane product and the fp64 kernel back to
+ * back, and the launches the depth statistic does not select exit at once -- the call only enqueues and never waits for the
+ * host (it can be captured in a hipGraph) when used_i8 is NULL.
+ * route_counts (DEVICE pointer to 3 ints, optional): [0] += 1 when five planes ran, [1] six planes, [2] the fp64 kernel; the
+ *   caller keeps it across calls and reads it whenever it likes (calibration reads it once, at the end).
+ * used_i8 (HOST pointer, optional; measurement and tests): receives the route of THIS call -- 5, 6, or 0 for the fp64 kernel --
+ *   at the price of one stream synchronisation.
+ * n_feat must be a multiple of 128.  ws: mdg_cov_accum_i8_ws_bytes (about 6 bytes per element of x).
+ * ev_start / ev_stop: optional hipEvent_t recorded on `stream` right before / after the two product launches (bench.py times
+ * the dominant kernel alone with them); NULL otherwise. */
 size_t mdg_cov_accum_i8_ws_bytes(int64_t n_tokens, int64_t n_feat);
 int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat, int64_t ld, double* sigma, int64_t ld_sigma, void* ws,
-                     size_t ws_bytes, int* used_i8, void* ev_start, void* ev_stop, void* stream);
+                     size_t ws_bytes, int* used_i8, int* route_counts, void* ev_start, void* ev_stop, void* stream);
 /* v_mfma instructions the product kernel of the LAST mdg_cov_accum_i8 call on workspace `ws` executed (0 after a call that
  * fell back to mdg_cov_accum).  The split pass records, per k-step and 32-row group, which digit planes hold a nonzero
  * there; the product kernel neither loads nor multiplies planes that are all-zero over a tile panel, so the count is at

@@ -114,6 +114,9 @@ def _calibrate_model(adapter: ModelAdapter, n_samples: int, batch_size: int, tar
     bi_scores = bi.scores(n_texts)
     adapter.bi_scores = bi_scores
     sig.finalize(n_texts)
+    if ops.COV_MODE == "i8":   # the route of every large-statistic launch was picked on the device; read the tally once
+        adapter.cov_routes = ops.i8_route_counts(reset=True)
+        logger.info(f"covariance routes (int8 five planes / six planes / fp64 fallback): {adapter.cov_routes}")
     logger.info("Finished calibration and computed BI scores.")
     return sig.lists["mlp"], sig.lists["q"], sig.lists["k"], sig.lists["x"], bi_scores
 

@@ -25,6 +25,10 @@ struct CovArgs {
   int64_t tokens_per_split;
   double* partial;
   int vec_ok;
+  // device-side route gate (mdg_cov_accum_i8's fp64 fallback): when set, every workgroup exits at once unless
+  // (*gate & gate_mask) == gate_want -- the launch is enqueued unconditionally and the DEVICE decides whether it runs
+  const int* gate;
+  int gate_mask, gate_want;
 };
 
 template <int DT> struct Stage {
@@ -264,6 +268,7 @@ __device__ __forceinline__ void cov_tile(const CovArgs& a, double* lds, int b, i
 template <int DT, bool RELU, bool FAST>
 __global__ __launch_bounds__(256, 2) void cov_accum_kernel(CovArgs a) {
   __shared__ double lds[4 * PANEL];  // As[2], Bs[2]
+  if (a.gate && (*a.gate & a.gate_mask) != a.gate_want) return;
   const int b = blockIdx.x / a.ntri, t = blockIdx.x % a.ntri;
   int bi, bj;
   tri_decode(t, bi, bj);
@@ -301,6 +306,7 @@ __global__ __launch_bounds__(256, 2) void cov_accum_multi_kernel(CovMulti m) {
 
 // sigma tile += sum over splits (fixed order) of the partial tiles.  grid = (tiles, 64): 256 elements per block.
 __global__ __launch_bounds__(256) void cov_reduce_kernel(CovArgs a) {
+  if (a.gate && (*a.gate & a.gate_mask) != a.gate_want) return;
   const int b = blockIdx.x / a.ntri, t = blockIdx.x % a.ntri;
   int bi, bj;
   tri_decode(t, bi, bj);
@@ -395,7 +401,8 @@ static int cov_ksplit(int64_t n_tokens, int64_t n_feat, int64_t batch, int64_t* 
   if (max_split > 256) max_split = 256;
   int64_t best = 1;
   double best_cost = 0.;
-  if (const char* ev = getenv("MDG_COV_KSPLIT")) {  // experiment knob (scripts/bench_kernels.py); not used by the engine
+#ifdef MDG_EXPERIMENT   // knob of scripts/bench_kernels.py; compiled out of the product library (no env var changes its arithmetic)
+  if (const char* ev = getenv("MDG_COV_KSPLIT")) {
     const int64_t f = atoll(ev);
     if (f >= 1 && f <= max_split) {
       const int64_t tps = (int64_t)align_up((size_t)ceil_div(n_tokens, f), BK);
@@ -403,6 +410,7 @@ static int cov_ksplit(int64_t n_tokens, int64_t n_feat, int64_t batch, int64_t* 
       return (int)ceil_div(n_tokens, tps);
     }
   }
+#endif
   for (int64_t ks = 1; ks <= max_split; ks++) {
     const int64_t tps = (int64_t)align_up((size_t)ceil_div(n_tokens, ks), BK);
     const int64_t real = ceil_div(n_tokens, tps);
@@ -449,6 +457,13 @@ extern "C" size_t mdg_cov_accum_ws_bytes(int64_t n_tokens, int64_t n_feat, int64
 extern "C" int mdg_cov_accum(const void* x, int dtype, int64_t n_tokens, int64_t n_feat, int64_t batch,
                              int64_t ld, int relu, double* sigma, int64_t ld_sigma, int64_t sigma_bs, void* ws,
                              size_t ws_bytes, void* stream) {
+  return mdg::cov_accum_gated(x, dtype, n_tokens, n_feat, batch, ld, relu, sigma, ld_sigma, sigma_bs, ws, ws_bytes, nullptr, 0, 0,
+                              stream);
+}
+
+int mdg::cov_accum_gated(const void* x, int dtype, int64_t n_tokens, int64_t n_feat, int64_t batch, int64_t ld, int relu,
+                         double* sigma, int64_t ld_sigma, int64_t sigma_bs, void* ws, size_t ws_bytes, const int* gate,
+                         int gate_mask, int gate_want, void* stream) {
   MDG_CLEAR();
   MDG_CHECK_ARG(n_tokens >= 0 && n_feat > 0 && batch > 0, "mdg_cov_accum: bad sizes (tokens=%lld feat=%lld batch=%lld)",
                 (long long)n_tokens, (long long)n_feat, (long long)batch);
@@ -475,6 +490,9 @@ extern "C" int mdg_cov_accum(const void* x, int dtype, int64_t n_tokens, int64_t
   a.sigma_bs = sigma_bs;
   a.ksplit = cov_ksplit(n_tokens, n_feat, batch, &a.tokens_per_split);
   a.partial = (double*)ws;
+  a.gate = gate;
+  a.gate_mask = gate_mask;
+  a.gate_want = gate_want;
   size_t esz = dtype_size(dtype);
   a.vec_ok = ((uintptr_t)x % 16 == 0) && ((ld * esz) % 16 == 0) && ((n_feat * esz) % 16 == 0 || batch == 1);
   if (a.ksplit > 1) {
@@ -526,6 +544,7 @@ static int multi_plan(int n, const mdg_cov_problem* pr, int dtype, CovMulti* m, 
     a.x = q.x; a.ld = q.ld; a.n_tokens = q.n_tokens; a.n_feat = (int)q.n_feat; a.batch = (int)q.batch;
     a.tiles = (int)(q.n_feat / TILE); a.ntri = a.tiles * (a.tiles + 1) / 2;
     a.sigma = q.sigma; a.ld_sigma = q.ld_sigma; a.sigma_bs = q.sigma_batch_stride; a.vec_ok = 1;
+    a.gate = nullptr; a.gate_mask = a.gate_want = 0;
     const int64_t tiles = (int64_t)a.batch * a.ntri;
     if (i == 0 && tiles >= 768) { a.ksplit = 1; a.tokens_per_split = (int64_t)align_up((size_t)q.n_tokens, BK); }
     else a.ksplit = multi_ksplit(q.n_tokens, &a.tokens_per_split);

@@ -281,6 +281,8 @@ struct SyrkArgs {
   int n, nk;
   const unsigned char* zmask;          // [nk][n / 32] piece masks written by the split pass (write_piece_mask)
   unsigned long long* mfma_count;      // += v_mfma instructions this launch executed (the dense count is known on the host)
+  const int* route_flag;               // written by i8_depth_kernel: 0 -> five planes, 1 -> six planes, bit 1 set -> the fp64 kernel
+  int* route_counts;                   // optional device counters [five planes, six planes, fp64 fallback], += 1 by the launch that runs
 };
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
@@ -288,31 +290,22 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
                                    0, 0);
 }
 
-// Shape, occupancy and LDS ring per route (all with 2 waves per SIMD; the kernel is power-capped, DESIGN.md section 7, so
-// bytes moved per MFMA is what counts).
-//   P = 5, NW = 8 (default): 128 x 128 tile worked by 8 waves of 64 x 32 (one workgroup of 512 threads, <= 256 registers per wave:
-//     160 accumulators + fragments fit), 2-stage ring of 40 KB stages -- 40 KB of L2->LDS traffic per k-step for 16384 outputs
-//     where two 128 x 64 tiles move 60 KB (40.1 -> 35.5 ms, L2 misses 203 -> 98 GB per launch).
-//   P = 6, NW = 8 (default): 128 x 64 tile worked by 8 waves of 32 x 32 (96 accumulators), 2-stage ring of 36 KB (61 -> 52 ms).
-//   P = 5, NW = 4 (-DMDG_I8_WIDE5=0): 128 x 64 tile, 4 waves of 64 x 32, TWO workgroups per CU with a 2-stage ring (2 x 30 KB each)
-//     -- while one workgroup sits in its stage barrier / LDS fragment reads the other one's MFMAs run (45.8 -> 40.5 ms per
-//     call against one workgroup with a 4-stage ring, -DMDG_I8_OCC5=1).
-//   P = 6, NW = 4 (-DMDG_I8_WIDE6=0): 128 x 64 tile, 4 waves of 64 x 32 (192 accumulators), one workgroup per CU, 4 x 36 KB ring
-//     with counted waits (two workgroups per CU measured 96 ms against 61).
+// Shape and LDS ring per route.  One workgroup of 8 waves per CU (two waves per SIMD, <= 256 registers each).  The kernel runs
+// at the power cap and is fed through L2 -> LDS, so what counts is bytes moved per MFMA and how much of a k-step's
+// bookkeeping hides behind the other wave's MFMAs.
+//   P = 5: 128 x 128 tile, wave tile 64 x 32 (160 accumulators), stages of 40 KB -- 40 KB of L2 -> LDS traffic per k-step for
+//          16384 outputs where two 128 x 64 tiles move 60 KB.
+//   P = 6: 128 x 64 tile, wave tile 32 x 32 (96 accumulators), stages of 36 KB.
+// Ring of 3 stages, filled two k-steps ahead by LDS-DMA.  The two waves of a SIMD take OPPOSITE orders inside a k-step
+// (roles by wave number >= 4, MI355X_MICROARCH.md "Two waves per SIMD" item 9): waves 4-7 issue their share of the stage
+// loads right after the barrier and multiply afterwards; waves 0-3 multiply first and issue their loads at the end of the
+// step.  With every wave in the same order (first versions: 2-stage ring, loads first) the matrix pipe idled through the
+// ~1000 cycles per k-step that eight waves spend side by side on mask decoding, address arithmetic and LDS-DMA issue -- MFMA
+// busy 0.50 -- now one wave's bookkeeping runs under its SIMD partner's MFMAs.  A wave waits for its own loads (vmcnt(0))
+// right before it issues the next ones, a whole k-step after they went out, so the wait is free and needs no load count (the
+// number of pieces a wave loads varies from step to step with the zero-plane skipping).
 #ifndef MDG_I8_SKIP_ZERO
-#define MDG_I8_SKIP_ZERO 1    // skip the LDS-DMA load, the fragment read and the MFMAs of all-zero pieces (2-stage rings only)
-#endif
-#ifndef MDG_I8_UNIFORM_WAVE
-#define MDG_I8_UNIFORM_WAVE 1
-#endif
-#ifndef MDG_I8_WIDE6
-#define MDG_I8_WIDE6 1
-#endif
-#ifndef MDG_I8_WIDE5
-#define MDG_I8_WIDE5 1
-#endif
-#ifndef MDG_I8_OCC5
-#define MDG_I8_OCC5 2
+#define MDG_I8_SKIP_ZERO 1    // skip the LDS-DMA load, the fragment read and the MFMAs of all-zero pieces
 #endif
 #ifndef MDG_I8_SB5
 #define MDG_I8_SB5 2    // 2 x 2 tiles of 128 x 128 (with zero-plane skipping: 26.7 ms against 27.5 for 4 x 4, 27.6 row-major)
@@ -320,63 +313,45 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 #ifndef MDG_I8_SB6
 #define MDG_I8_SB6 2
 #endif
-#ifndef MDG_I8_RING8
-#define MDG_I8_RING8 2
+#ifndef MDG_I8_ROLES
+#define MDG_I8_ROLES 1  // 0: every wave loads first (the lock-step order of the first versions)
 #endif
-template <int P, int NW> constexpr int ring_depth() { return NW == 8 ? MDG_I8_RING8 : (P == 5 ? (MDG_I8_OCC5 == 2 ? 2 : 4) : 4); }
+constexpr int NW = 8;     // waves per workgroup
+constexpr int RING = 3;   // LDS stages
 
-template <int P, int NW>  // planes used: 5 or 6; waves: 4 (128 x 64 tile) or 8 (128 x 128 tile)
-__global__ __launch_bounds__(64 * NW, (P == 5 && NW == 4) ? MDG_I8_OCC5 : 1) void i8_syrk_kernel(SyrkArgs a) {
-  constexpr int RING = ring_depth<P, NW>();
-  constexpr int WB = (NW == 8 && P == 6) ? 1 : 2;  // 32-row blocks of a wave tile: 64 x 32, or 32 x 32 (96 accumulators at P = 6)
-  constexpr int TJ = (NW == 8 && WB == 2) ? 128 : 64;  // tile columns (rows of the J operand); waves are laid out (128 / 32 WB) x (TJ / 32)
+template <int P>  // planes used: 5 or 6
+__global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
+  constexpr int WB = P == 6 ? 1 : 2;               // 32-row blocks of a wave tile: 64 x 32, or 32 x 32 (96 accumulators at P = 6)
+  constexpr int TJ = WB == 2 ? 128 : 64;           // tile columns (rows of the J operand); waves are laid out (128 / 32 WB) x (TJ / 32)
   constexpr int PB = TJ * KS;
   constexpr int GA = TI / 32, GB = TJ / 32;        // 32-row groups (1 KB pieces per plane and stage) of the two operands
   constexpr int WCOLS = TJ / 32;
-  constexpr int STAGE_BYTES = P * (PA + PB);       // 30 / 36 KB (40 KB for the 128 x 128 tile)
+  constexpr int STAGE_BYTES = P * (PA + PB);       // 40 KB (P = 5, 128 x 128) / 36 KB (P = 6, 128 x 64)
   constexpr int PIECES = (GA + GB) * P;            // 1 KB pieces per stage
-  constexpr int PER_WAVE_MIN = PIECES / NW;        // every wave issues at least this many LDS-DMA loads per stage
-  // 2-stage rings only (the counted waits of the deeper rings need a fixed load count).  Both routes: five planes 35.5 -> 26.5
-  // ms on Gaussian columns, six planes 51.8 -> 44.6 ms on SiLU-gated ones (the six-plane kernel first measured SLOWER, 62 ms:
-  // see b_half below -- one shift applied to a just-loaded mask exposed a full memory round trip per step).
-#ifndef MDG_I8_SKIP_ZERO6
-#define MDG_I8_SKIP_ZERO6 1
-#endif
-  constexpr bool SKIP = MDG_I8_SKIP_ZERO && RING == 2 && (P == 5 || MDG_I8_SKIP_ZERO6);
+  constexpr bool SKIP = MDG_I8_SKIP_ZERO;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  // The route is chosen on the DEVICE: mdg_cov_accum_i8 enqueues the five-plane product, the six-plane product and the fp64
+  // kernel back to back, and each exits at once unless the depth statistic of this call (i8_depth_kernel) selects it -- the
+  // host never waits for the flag.  The six-plane launch also books the fp64 fallback in the route counters.
+  {
+    const int route = *a.route_flag;
+    if (route != (P == 5 ? 0 : 1)) {
+      if (P == 6 && (route & 2) && a.route_counts && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.route_counts + 2, 1);
+      return;
+    }
+    if (a.route_counts && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.route_counts + (P == 5 ? 0 : 1), 1);
+  }
   // Tile (bi, bj): bi = 128-row block, bj = TJ-row block of the lower region (bj <= bi for 128 x 128 tiles, bj <= 2 bi + 1 for
   // 128 x 64).  XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2, so workgroup w belongs
   // to XCD w % 8 and is the (w / 8)-th one there.  The tiles are grouped into super-blocks that are square in features
-  // (SI x SI tiles of 128 x 128, SI x 2 SI tiles of 128 x 64; P = 5: 512 x 512 features, P = 6: 256 x 256); a super-block
-  // lives on ONE XCD, so per k-step its tiles pull each distinct panel row through that L2 once (first version, 4 x 8 tiles
-  // of 128 x 64, one workgroup per CU: FETCH_SIZE 231 -> 132 GB per launch, 47.7 -> 44.8 ms; 128 x 128 tiles: 40.0 ms
-  // row-major, 37.2 ms with 4 x 4 super-blocks).  Super-blocks (R, C), C <= R, cover the lower region; tiles of a diagonal
-  // super-block that lie above it exit at once.  P = 6: 2 x 4 tiles, 52.1 ms against 54.9 row-major (with the 4-wave shape
-  // every XCD-pinned grouping measured 84 - 87 ms against 60.8 ms row-major; not understood, waves parked 52 %).
+  // (SI x SI tiles of 128 x 128, SI x 2 SI tiles of 128 x 64); a super-block lives on ONE XCD, so per k-step its tiles pull
+  // each distinct panel row through that L2 once.  Super-blocks (R, C), C <= R, cover the lower region; tiles of a diagonal
+  // super-block that lie above it exit at once.
   int bi, bj;
-  constexpr int SI = P == 5 ? MDG_I8_SB5 : MDG_I8_SB6;   // super-block: SI x 2 SI tiles; 0 = plain row-major order
-  if (TJ == 128) {
-    // square 128 x 128 tiles, bj <= bi; super-blocks of SI x SI tiles dealt to the XCDs as below (SI = 0: row-major)
-    if (SI > 0) {
-      constexpr int TPS = SI * SI;
-      const int w = blockIdx.x;
-      const int q = w >> 3;
-      const int sb = q / TPS * 8 + (w & 7), t_in = q % TPS;
-      int R = (int)((sqrtf(8.f * sb + 1.f) - 1.f) * 0.5f);
-      while ((R + 1) * (R + 2) / 2 <= sb) R++;
-      while (R * (R + 1) / 2 > sb) R--;
-      const int C = sb - R * (R + 1) / 2;
-      bi = SI * R + t_in / SI;
-      bj = SI * C + t_in % SI;
-    } else {
-      const int tile = blockIdx.x;  // bi (bi + 1) / 2 tiles precede row bi
-      bi = (int)((sqrtf(8.f * tile + 1.f) - 1.f) * 0.5f);
-      while ((bi + 1) * (bi + 2) / 2 <= tile) bi++;
-      while (bi * (bi + 1) / 2 > tile) bi--;
-      bj = tile - bi * (bi + 1) / 2;
-    }
-  } else if (SI > 0) {
-    constexpr int TPS = SI * 2 * SI;            // tiles per super-block
+  constexpr int SI = P == 5 ? MDG_I8_SB5 : MDG_I8_SB6;   // super-block: SI x SI (or SI x 2 SI) tiles; 0 = plain row-major order
+  if (SI > 0) {
+    constexpr int TPS = TJ == 128 ? SI * SI : SI * 2 * SI;   // tiles per super-block
+    constexpr int SJ = TJ == 128 ? SI : 2 * SI;              // tile columns of a super-block
     const int w = blockIdx.x;
     const int q = w >> 3;
     const int sb = q / TPS * 8 + (w & 7), t_in = q % TPS;
@@ -384,8 +359,14 @@ __global__ __launch_bounds__(64 * NW, (P == 5 && NW == 4) ? MDG_I8_OCC5 : 1) voi
     while ((R + 1) * (R + 2) / 2 <= sb) R++;
     while (R * (R + 1) / 2 > sb) R--;
     const int C = sb - R * (R + 1) / 2;
-    bi = SI * R + t_in / (2 * SI);
-    bj = 2 * SI * C + t_in % (2 * SI);
+    bi = SI * R + t_in / SJ;
+    bj = SJ * C + t_in % SJ;
+  } else if (TJ == 128) {
+    const int tile = blockIdx.x;  // bi (bi + 1) / 2 tiles precede row bi
+    bi = (int)((sqrtf(8.f * tile + 1.f) - 1.f) * 0.5f);
+    while ((bi + 1) * (bi + 2) / 2 <= tile) bi++;
+    while (bi * (bi + 1) / 2 > tile) bi--;
+    bj = tile - bi * (bi + 1) / 2;
   } else {
     const int tile = blockIdx.x;  // bi (bi + 1) tiles precede row bi
     bi = (int)((sqrtf(4.f * tile + 1.f) - 1.f) * 0.5f);
@@ -394,16 +375,10 @@ __global__ __launch_bounds__(64 * NW, (P == 5 && NW == 4) ? MDG_I8_OCC5 : 1) voi
     bj = tile - bi * (bi + 1);
   }
   if (bi >= a.n / TI || bj * TJ > bi * TI + TI - 1) return;
-  // The wave index goes through readfirstlane where the ring has 2 stages: hipcc then knows it is wave-uniform and the staging
-  // code becomes scalar (SGPR piece addresses, s_cbranch on `p < PIECES`, M0 from SGPRs) instead of exec-masked branches with a
-  // v_readfirstlane per piece (35.6 -> 34.8 ms, P = 6: 51.4 -> 50.6).  hipcc 7.2 also puts an s_waitcnt vmcnt(0) in front of
-  // every LDS-DMA load once the index is uniform -- harmless with 2 stages (the loop drains the counter every step anyway), but
-  // it serialises a 4-stage ring (P = 6, 4 waves: 61 -> 165 ms), so those shapes keep the plain index.
-#if MDG_I8_UNIFORM_WAVE
-  const int wave = RING == 2 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
-#else
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#endif
+  // the wave index through readfirstlane: hipcc then knows it is wave-uniform and the staging code becomes scalar (SGPR piece
+  // addresses, s_cbranch on the piece tests, M0 from SGPRs) instead of exec-masked branches with a v_readfirstlane per piece
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const bool loads_first = MDG_I8_ROLES ? wave >= NW / 2 : true;
   const int wr = wave / WCOLS, wc = wave % WCOLS;
   const int64_t groups = a.n / 32;
   const int nk = a.nk;
@@ -427,9 +402,7 @@ __global__ __launch_bounds__(64 * NW, (P == 5 && NW == 4) ? MDG_I8_OCC5 : 1) voi
         const bool isA = p < GA * P;
         const int pp = isA ? p : p - GA * P;
         const int s = isA ? pp / GA : pp / GB, g = isA ? pp % GA : pp % GB;
-#ifndef MDG_I8_EXPERIMENT_LOAD_ALL   // (timing experiment: skip the MFMAs only)
         if (SKIP && s >= group_depth(isA ? mA : mB, g)) continue;   // an all-zero piece: nothing will read it
-#endif
         const int64_t G = (isA ? bi * (TI / 32) : bj * (TJ / 32)) + g;
         const signed char* src = a.planes + ((s * groups + G) * (int64_t)nk + kt) * 1024 + lane * 16;
         unsigned char* dst = lds + buf * STAGE_BYTES + (isA ? s * PA : P * PA + s * PB) + g * 1024;
@@ -480,67 +453,75 @@ __global__ __launch_bounds__(64 * NW, (P == 5 && NW == 4) ? MDG_I8_OCC5 : 1) voi
     for (int k = 0; k < P; k++)
 #pragma unroll
       for (int b = 0; b < WB; b++) acc[k][b] = (i32x16)0;
-    // the stores above share the VM counter with the LDS-DMA loads and may retire out of order with them: drain, so that
-    // the counted wait of the next stage again counts LDS-DMA loads only
+    // the stores above share the VM counter with the LDS-DMA loads: drain, so that the loop's waits see stage loads only
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
 
-  // two loops: the int32 classes are folded into sigma between runs of FLUSH_STEPS k-steps, outside the MFMA loop (a
-  // conditional flush inside it makes the compiler shuttle all 160 accumulators between AGPRs and VGPRs every step)
-  // piece masks: uniform-address loads, one step ahead of the stage they describe (complete at the next step's vmcnt(0))
+  // piece masks: uniform-address loads; issued together with a stage's loads, for the stage after it
   const int64_t mgroups = a.n / 32;
   auto load_masks = [&](int kt, unsigned& va, unsigned& vb) {
     const unsigned* z = (const unsigned*)(a.zmask + (int64_t)kt * mgroups);   // n / 32 is a multiple of 4: dword-aligned rows
     va = z[bi];                                                               // groups 4 bi .. 4 bi + 3
     vb = TJ == 128 ? z[bj] : z[bj >> 1];   // groups 4 bj .. + 3; or 2 bj, 2 bj + 1 in one half of the dword (see b_half)
   };
-  // 128 x 64 tiles: the B panel's two mask bytes are one half of the loaded dword.  Taken when the value is USED, a step after
-  // the load -- applied to the load's result at once, the shift makes hipcc wait for the load on the spot (the six-plane kernel
-  // measured 62 instead of 51 ms that way, whatever it skipped)
+  // 128 x 64 tiles: the B panel's two mask bytes are one half of the loaded dword
   auto b_half = [&](unsigned m) { return TJ == 128 ? m : (m >> ((bj & 1) * 16)) & 0xFFFFu; };
-  // The planes below MIN_DEPTH form the unconditional, straight-line part of a step, each deeper plane of each 32-row block a
-  // conditional block of its own (branching around single MFMAs / fragment reads instead makes hipcc put an lgkmcnt(0) in front
-  // of every LDS read; nine straight-line variants behind a switch make it spill the 160 accumulators at the merges)
-  unsigned mA_cur = ~0u, mB_cur = ~0u, vA_next = ~0u, vB_next = ~0u;
+  auto wait_loads = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+  // masks of stage kt (being multiplied), kt + 1 (landed or landing) -- SGPRs; vA / vB: the loaded dwords of stage kt + 2
+  unsigned mA0 = ~0u, mB0 = ~0u, mA1 = ~0u, mB1 = ~0u, vA = ~0u, vB = ~0u;
   unsigned executed = 0;
   if (SKIP) {
-    load_masks(0, mA_cur, mB_cur);
-    mA_cur = __builtin_amdgcn_readfirstlane(mA_cur);
-    mB_cur = b_half(__builtin_amdgcn_readfirstlane(mB_cur));
-    if (nk > 1) load_masks(1, vA_next, vB_next);
+    unsigned t0, t1;
+    load_masks(0, t0, t1);
+    mA0 = __builtin_amdgcn_readfirstlane(t0);
+    mB0 = b_half(__builtin_amdgcn_readfirstlane(t1));
+    if (nk > 1) {
+      load_masks(1, t0, t1);
+      mA1 = __builtin_amdgcn_readfirstlane(t0);
+      mB1 = b_half(__builtin_amdgcn_readfirstlane(t1));
+    }
+    if (nk > 2) load_masks(2, vA, vB);
   }
-  for (int p = 0; p < RING - 1 && p < nk; p++) issue_stage(p, p, mA_cur, mB_cur);
+  issue_stage(0, 0, mA0, mB0);
+  if (nk > 1) issue_stage(1, 1, mA1, mB1);
+  wait_loads();
+  int buf = 0;                 // kt % RING
+  // two loops: the int32 classes are folded into sigma between runs of FLUSH_STEPS k-steps, outside the MFMA loop (a
+  // conditional flush inside it makes the compiler shuttle all 160 accumulators between AGPRs and VGPRs every step)
   for (int k0 = 0; k0 < nk; k0 += FLUSH_STEPS) {
     const int k1 = min(nk, k0 + FLUSH_STEPS);
     for (int kt = k0; kt < k1; kt++) {
-      const int buf = kt % RING;
-      // stages kt+1 and kt+2 may stay in flight: "at most 2 x (loads a wave issues per stage, rounded down)" outstanding
-      // retires stage kt on every wave (P = 5: waves issue 8, 8, 7, 7 -> 14; P = 6: 9 each -> 18); the tail drains everything
-      if (kt + RING - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * PER_WAVE_MIN) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      unsigned mA_nx = ~0u, mB_nx = ~0u;
-      if (SKIP) {   // (RING == 2) masks of stage kt + 1 arrived with the wait above; fetch those of kt + 2
-        mA_nx = __builtin_amdgcn_readfirstlane(vA_next);
-        mB_nx = b_half(__builtin_amdgcn_readfirstlane(vB_next));
-        if (kt + 2 < nk) load_masks(kt + 2, vA_next, vB_next);
+      // A wave's share of stage kt + 1 went out a k-step ago (at this point of the previous step for the loads-first waves, at
+      // the end of the step before for the others); each wave has waited for its own before it arrives here.
+      if (loads_first) wait_loads();
+      __builtin_amdgcn_s_barrier();   // stage kt complete in LDS (every wave waited for its share), stage kt - 1 no longer read
+      unsigned mA2 = ~0u, mB2 = ~0u;
+      auto refill = [&]() {           // stage kt + 2 into the buffer stage kt - 1 just left; masks of kt + 3 behind it
+        if (SKIP) {
+          mA2 = __builtin_amdgcn_readfirstlane(vA);
+          mB2 = b_half(__builtin_amdgcn_readfirstlane(vB));
+        }
+        const int nb = buf == 0 ? 2 : buf - 1;   // (kt + 2) % 3
+        if (kt + 2 < nk) issue_stage(kt + 2, nb, mA2, mB2);
+        if (SKIP && kt + 3 < nk) load_masks(kt + 3, vA, vB);
+      };
+      if (loads_first) {
+        refill();
+        __builtin_amdgcn_sched_barrier(0);
       }
-      if (kt + RING - 1 < nk) issue_stage(kt + RING - 1, (kt + RING - 1) % RING, mA_nx, mB_nx);
       int dAb[WB];
 #pragma unroll
-#ifdef MDG_I8_EXPERIMENT_MULTIPLY_ALL   // (timing experiment, wrong results: skip the loads only)
-      for (int b = 0; b < WB; b++) dAb[b] = P;
-      const int dBw = P;
-#else
-      for (int b = 0; b < WB; b++) dAb[b] = SKIP ? group_depth(mA_cur, wr * WB + b) : P;
-      const int dBw = SKIP ? group_depth(mB_cur, wc) : P;
-#endif
+      for (int b = 0; b < WB; b++) dAb[b] = SKIP ? group_depth(mA0, wr * WB + b) : P;
+      const int dBw = SKIP ? group_depth(mB0, wc) : P;
       const unsigned char* base = lds + buf * STAGE_BYTES;
       const int r = lane & 31, h = lane >> 5;
       // The step: planes below MIN_DEPTH of both panels unconditionally -- ONE set of fragment reads, all their pairs -- then,
       // for each deeper plane that is present, a block of its own (fragment read + its pairs).  A deep plane only pairs with
       // planes 0 (and 1) of the other panel (s + t < P), so the blocks are independent and simply add:
       //   P = 5: 9 pairs + 2 [dA > 3] + 2 [dB > 3] + [dA > 4] + [dB > 4];   P = 6: 15 + 2 [dA > 4] + 2 [dB > 4] + [dA > 5] + [dB > 5]
+      // (branching around single MFMAs / fragment reads instead makes hipcc put an lgkmcnt(0) in front of every LDS read; nine
+      // straight-line variants behind a switch make it spill the 160 accumulators at the merges)
       i32x4 fa[MIN_DEPTH][WB], fb[MIN_DEPTH];
 #pragma unroll
       for (int s = 0; s < MIN_DEPTH; s++) {
@@ -582,8 +563,13 @@ __global__ __launch_bounds__(64 * NW, (P == 5 && NW == 4) ? MDG_I8_OCC5 : 1) voi
       }
       executed += deep_mfmas;
       executed += pairs * WB;
-      mA_cur = mA_nx;
-      mB_cur = mB_nx;
+      if (!loads_first) {
+        __builtin_amdgcn_sched_barrier(0);
+        wait_loads();       // this wave's share of stage kt + 1, issued at this point of the previous step
+        refill();
+      }
+      mA0 = mA1; mB0 = mB1; mA1 = mA2; mB1 = mB2;
+      buf = buf == RING - 1 ? 0 : buf + 1;
     }
     flush();
   }
@@ -606,7 +592,8 @@ extern "C" size_t mdg_cov_accum_i8_ws_bytes(int64_t n_tokens, int64_t n_feat) {
 }
 
 extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat, int64_t ld, double* sigma, int64_t ld_sigma,
-                                void* ws, size_t ws_bytes, int* used_i8, void* ev_start, void* ev_stop, void* stream) {
+                                void* ws, size_t ws_bytes, int* used_i8, int* route_counts, void* ev_start, void* ev_stop,
+                                void* stream) {
   MDG_CLEAR();
   if (used_i8) *used_i8 = 0;
   MDG_CHECK_ARG(n_tokens >= 0 && n_feat > 0, "mdg_cov_accum_i8: bad sizes (tokens=%lld feat=%lld)", (long long)n_tokens,
@@ -649,35 +636,48 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
                        (const bf16_t*)x, ld, n_tokens, n, nk, emax, planes, deep_cnt, nz_cnt, zmask);
   hipLaunchKernelGGL(i8_depth_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, deep_cnt, nz_cnt, emax, n, flag);
   MDG_LAUNCH_CHECK();
-  int depth = 0;
-  MDG_HIP(hipMemcpyAsync(&depth, flag, sizeof(int), hipMemcpyDeviceToHost, st));
-  MDG_HIP(hipStreamSynchronize(st));
-  if (depth & 2)  // some column is mostly far below its maximum: six planes do not carry fp64-level accuracy there
-    return mdg_cov_accum(x, MDG_BF16, n_tokens, n_feat, 1, ld, 0, sigma, ld_sigma, 0, fb_ws,
-                         ws_bytes - (size_t)((char*)fb_ws - (char*)ws), stream);
+  // All three routes are enqueued; the flag just written decides on the device which one does the work (the other launches'
+  // workgroups exit on their first instruction: ~10 us each at the sigma_mlp grid).  No host round trip, graph-capturable.
   SyrkArgs a;
   a.planes = planes; a.emax = emax; a.sigma = sigma; a.ld_sigma = ld_sigma; a.n = n; a.nk = nk; a.zmask = zmask; a.mfma_count = mfma_count;
+  a.route_flag = flag; a.route_counts = route_counts;
   const int rb = n / TI;
-  int planes_used = (depth & 1) ? 6 : 5;
-  if (const char* ev = getenv("MDG_I8_PLANES"))  // experiment knob (scripts/bench_kernels.py): force the 6-plane product
-    if (atoi(ev) == 6) planes_used = 6;
-  constexpr int NW5 = MDG_I8_WIDE5 ? 8 : 4;                                  // waves of the 5-plane kernel: 128 x 128 or 128 x 64 tiles
-  constexpr int NW6 = MDG_I8_WIDE6 ? 8 : 4;                                  // 6 planes: 8 waves of 32 x 32 or 4 of 64 x 32 on a 128 x 64 tile
-  const bool wide = planes_used == 5 && NW5 == 8;
-  const int tj = wide ? 128 : 64;
-  const size_t lds = (size_t)(planes_used == 5 ? ring_depth<5, NW5>() : ring_depth<6, NW6>()) * planes_used * (PA + tj * KS);
-  const int si = planes_used == 5 ? MDG_I8_SB5 : MDG_I8_SB6;                 // super-block rows (see the kernel); 0 = row-major
-  const int sr = si ? (rb + si - 1) / si : 0, nsb = sr * (sr + 1) / 2;       // super-block rows, super-blocks
-  const int tps = wide ? si * si : 2 * si * si;                              // tiles per super-block
-  const dim3 grid(si ? (unsigned)((nsb + 7) / 8 * 8 * tps) : (unsigned)(wide ? rb * (rb + 1) / 2 : rb * (rb + 1)));
-  if (planes_used == 6) MDG_HIP(hipFuncSetAttribute((const void*)i8_syrk_kernel<6, NW6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  else MDG_HIP(hipFuncSetAttribute((const void*)i8_syrk_kernel<5, NW5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (ev_start) MDG_HIP(hipEventRecord((hipEvent_t)ev_start, st));
-  if (planes_used == 6) hipLaunchKernelGGL((i8_syrk_kernel<6, NW6>), grid, dim3(64 * NW6), lds, st, a);
-  else hipLaunchKernelGGL((i8_syrk_kernel<5, NW5>), grid, dim3(64 * NW5), lds, st, a);
-  MDG_LAUNCH_CHECK();
+  for (int planes_used = 5; planes_used <= 6; planes_used++) {
+#ifdef MDG_EXPERIMENT   // knob of scripts/bench_kernels.py (force one product kernel); compiled out of the product library
+    if (const char* ev = getenv("MDG_I8_PLANES"))
+      if (atoi(ev) != planes_used) continue;
+#endif
+    const bool wide = planes_used == 5;                                        // 128 x 128 tiles; six planes: 128 x 64
+    const int tj = wide ? 128 : 64;
+    const size_t lds = (size_t)RING * planes_used * (PA + tj * KS);
+    const int si = planes_used == 5 ? MDG_I8_SB5 : MDG_I8_SB6;                 // super-block rows (see the kernel); 0 = row-major
+    const int sr = si ? (rb + si - 1) / si : 0, nsb = sr * (sr + 1) / 2;       // super-block rows, super-blocks
+    const int tps = wide ? si * si : 2 * si * si;                              // tiles per super-block
+    const dim3 grid(si ? (unsigned)((nsb + 7) / 8 * 8 * tps) : (unsigned)(wide ? rb * (rb + 1) / 2 : rb * (rb + 1)));
+    if (planes_used == 6) {
+      MDG_HIP(hipFuncSetAttribute((const void*)i8_syrk_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((i8_syrk_kernel<6>), grid, dim3(64 * NW), lds, st, a);
+    } else {
+      MDG_HIP(hipFuncSetAttribute((const void*)i8_syrk_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((i8_syrk_kernel<5>), grid, dim3(64 * NW), lds, st, a);
+    }
+    MDG_LAUNCH_CHECK();
+  }
   if (ev_stop) MDG_HIP(hipEventRecord((hipEvent_t)ev_stop, st));
-  if (used_i8) *used_i8 = planes_used;
+  // some column is mostly far below its maximum (flag bit 1): six planes do not carry fp64-level accuracy there
+  const int fb = cov_accum_gated(x, MDG_BF16, n_tokens, n_feat, 1, ld, 0, sigma, ld_sigma, 0, fb_ws,
+                                 ws_bytes - (size_t)((char*)fb_ws - (char*)ws), flag, 2, 2, stream);
+  if (fb != MDG_OK) return fb;
+  if (used_i8) {   // measurement / test mode: report the route this call took (costs the host a round trip)
+    int depth = 0;
+    MDG_HIP(hipMemcpyAsync(&depth, flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    MDG_HIP(hipStreamSynchronize(st));
+    *used_i8 = (depth & 2) ? 0 : ((depth & 1) ? 6 : 5);
+#ifdef MDG_EXPERIMENT
+    if (const char* ev = getenv("MDG_I8_PLANES")) if (!(depth & 2)) *used_i8 = atoi(ev);
+#endif
+  }
   return MDG_OK;
 }
 

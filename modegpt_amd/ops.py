@@ -73,14 +73,18 @@ def cov_accum(sigma: torch.Tensor, x: torch.Tensor, n_heads: int = 1, relu: bool
                                 sigma.data_ptr(), feat, feat * feat, wsp, nbytes, _stream(x)), "mdg_cov_accum")
 
 
-def cov_accum_i8(sigma: torch.Tensor, x: torch.Tensor, events=None, mfma_stats: Optional[dict] = None) -> int:
+def cov_accum_i8(sigma: torch.Tensor, x: torch.Tensor, events=None, mfma_stats: Optional[dict] = None,
+                 report: bool = True) -> Optional[int]:
     """sigma (lower triangle) += X^T X for one bf16 matrix through the int8 digit-plane kernel (csrc/cov_i8.hip).
-    Returns the number of digit planes the product used (5 or 6), or 0 when the per-column depth statistic sent the batch
-    to the fp64 kernel (the result is valid either way; I8_STATS counts the routes).  Feature count must be a multiple
-    of 128.  events: optional pair of torch.cuda.Event(enable_timing=True), each recorded once already, re-recorded
-    around the product kernel alone.  mfma_stats: optional dict; its "executed" entry is increased by the number of
-    v_mfma instructions the product kernel issued (it skips digit planes that are all-zero over a tile panel) and "dense"
-    by what a kernel without that skipping issues -- costs a stream synchronisation, for measurement only."""
+    The route -- five planes, six planes, or the fp64 kernel for batches whose per-column depth statistic is too heavy-tailed
+    -- is chosen on the device; the result is valid either way.  report=True (tests, measurements) returns the route of this
+    call (5, 6, or 0 for the fp64 kernel) at the price of one stream synchronisation and books it in I8_STATS;
+    report=False (the hooks: cov_accum_multi) only enqueues and returns None -- the per-device counters behind
+    i8_route_counts() are updated by the kernels themselves in both modes.  Feature count must be a multiple of 128.
+    events: optional pair of torch.cuda.Event(enable_timing=True), each recorded once already, re-recorded around the product
+    launches alone.  mfma_stats: optional dict; its "executed" entry is increased by the number of v_mfma instructions the
+    product kernel issued (it skips digit planes that are all-zero over a tile panel) and "dense" by what a kernel without
+    that skipping issues -- costs a stream synchronisation, for measurement only (implies report)."""
     _need_gpu(sigma, x)
     lib = _lib.load()
     if sigma.dtype != torch.float64 or not sigma.is_contiguous() or sigma.dim() != 2:
@@ -95,18 +99,45 @@ def cov_accum_i8(sigma: torch.Tensor, x: torch.Tensor, events=None, mfma_stats: 
         raise ValueError(f"shape mismatch: sigma {tuple(sigma.shape)}, x {tuple(x2.shape)}")
     nbytes = lib.mdg_cov_accum_i8_ws_bytes(x2.shape[0], n)
     ws, wsp = _ws(nbytes, x.device)
+    report = report or mfma_stats is not None
     used = C.c_int(0)
     with torch.cuda.device(x.device):
         check(lib.mdg_cov_accum_i8(x2.data_ptr(), x2.shape[0], n, x2.stride(0), sigma.data_ptr(), sigma.stride(0), wsp, nbytes,
-                                   C.byref(used), None if events is None else events[0].cuda_event,
+                                   C.byref(used) if report else None, _route_counters(x.device).data_ptr(),
+                                   None if events is None else events[0].cuda_event,
                                    None if events is None else events[1].cuda_event, _stream(x)), "mdg_cov_accum_i8")
         if mfma_stats is not None and used.value in (5, 6):
             done = C.c_ulonglong(0)
             check(lib.mdg_cov_accum_i8_stats(wsp, x2.shape[0], n, C.byref(done), _stream(x)), "mdg_cov_accum_i8_stats")
             mfma_stats["executed"] = mfma_stats.get("executed", 0) + done.value
             mfma_stats["dense"] = mfma_stats.get("dense", 0) + i8_dense_mfma_count(x2.shape[0], n, used.value)
+    if not report:
+        return None
     I8_STATS[{5: "i8_5", 6: "i8_6"}.get(used.value, "fallback_f64")] += 1
     return used.value
+
+
+_ROUTE_COUNTERS = {}
+
+
+def _route_counters(device) -> torch.Tensor:
+    """Per-device int32[3] the product kernels bump: [five planes, six planes, fp64 fallback] (mdg_cov_accum_i8 route_counts)."""
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _ROUTE_COUNTERS:
+        _ROUTE_COUNTERS[key] = torch.zeros(3, dtype=torch.int32, device=torch.device("cuda", key))
+    return _ROUTE_COUNTERS[key]
+
+
+def i8_route_counts(device=None, reset: bool = False) -> dict:
+    """How the int8-route requests on `device` (default: the current one) were served so far, counted on the device by the
+    kernels that ran: {"i8_5", "i8_6", "fallback_f64"}.  One small device -> host copy; calibration reads it once, at the end."""
+    key = torch.cuda.current_device() if device is None else (torch.device(device).index or 0)
+    t = _route_counters(torch.device("cuda", key))
+    v = t.cpu().tolist()
+    if reset:
+        t.zero_()
+    return {"i8_5": v[0], "i8_6": v[1], "fallback_f64": v[2]}
 
 
 def i8_dense_mfma_count(n_tokens: int, n: int, planes: int) -> int:
@@ -123,7 +154,7 @@ def i8_dense_mfma_count(n_tokens: int, n: int, planes: int) -> int:
 # anything it cannot take stay on the fp64 kernel, and every call falls back by itself on outlier-dominated columns).
 COV_MODE = os.environ.get("MODEGPT_COV_MODE", "i8")
 I8_MIN_FEATURES = 2048
-I8_STATS = {"i8_5": 0, "i8_6": 0, "fallback_f64": 0}      # how the "i8" requests of this process were served
+I8_STATS = {"i8_5": 0, "i8_6": 0, "fallback_f64": 0}      # routes of the REPORTING cov_accum_i8 calls (tests, bench); all calls: i8_route_counts()
 
 
 def cov_accum_multi(items, mode: Optional[str] = None) -> None:
@@ -152,17 +183,17 @@ def cov_accum_multi(items, mode: Optional[str] = None) -> None:
             # the small fp64 problems (per-head sigma_q / sigma_k) run on a side stream next to the LAST -- smallest -- int8
             # problem, whose few hundred tiles leave CUs idle in their final round; the large problem keeps the chip to itself
             for sigma, x in planes[:-1]:
-                cov_accum_i8(sigma, x)
+                cov_accum_i8(sigma, x, report=False)
             dev = planes[-1][1].device
             main, side = torch.cuda.current_stream(dev), _side_stream(dev)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 _cov_accum_fused(rest)
-            cov_accum_i8(*planes[-1])
+            cov_accum_i8(*planes[-1], report=False)
             main.wait_stream(side)       # later work on the caller's stream (and any reuse of these buffers) is ordered after both
             return
         for sigma, x in planes:
-            cov_accum_i8(sigma, x)
+            cov_accum_i8(sigma, x, report=False)
         items = rest
         if not items:
             return

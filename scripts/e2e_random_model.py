@@ -67,4 +67,4 @@ print(f"compressed model, in-process compressed attention: synthetic-token perpl
 print(f"TOTAL {t_cal + t_mlp + t_qk + t_vo:.1f} s for {L} layers = {L / (t_cal + t_mlp + t_qk + t_vo):.3f} layers/s (model forward and artefact IO included)")
 shutil.rmtree(tmp, ignore_errors=True)
 from modegpt_amd import ops as _ops
-print(f"covariance routes of the large statistics (mode {_ops.COV_MODE}): {_ops.I8_STATS}")
+print(f"covariance routes of the large statistics (mode {_ops.COV_MODE}; counted on the device): {getattr(ad, 'cov_routes', None)}")

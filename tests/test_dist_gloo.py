@@ -1,12 +1,19 @@
-"""CPU, world_size 2 over gloo: the N > 1 path -- block partition of layers, one padded all-gather of the packed
-records, artefacts of the other rank written into temp_storage_dir."""
+"""CPU, world_size 2 over gloo: the N > 1 path -- block partition of layers, one padded all-gather of the packed records, and
+the artefact hand-over to rank 0 through ONE temp_storage_dir shared by all ranks (what torchrun gives them: the same
+--temp_storage_dir flag), driven through run_modegpt.compress_chunk itself with the GPU stages replaced by writers of
+deterministic artefacts.  Plus bench.py's own launcher (`python bench.py --gpus 2` without torchrun)."""
+import json
 import os
 import socket
+import subprocess
+import sys
 import tempfile
 
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
@@ -27,44 +34,110 @@ def _layer(i):
     return t, torch.arange(r).reshape(1, r) + i
 
 
+N_LAYERS = 5      # over 2 ranks: 3 + 2 (ragged)
+
+
 def _worker(rank, world, port, tmp):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from modegpt_amd import sharding as S
+    from modegpt_amd import model_utils, run_modegpt as R, sharding as S
     from modegpt_amd.adapters.CompressionConfig import CompressionConfig
 
+    # one process per GPU: everything this rank allocates goes to ITS card, whatever the reference's "cuda:0" literals say
+    assert model_utils.local_rank() == rank and model_utils.local_device() == f"cuda:{rank}"
+
+    shared = os.path.join(tmp, "layers")          # ONE directory for all ranks
+
     class A:
-        config = CompressionConfig(temp_storage_dir=os.path.join(tmp, f"rank{rank}"))
+        config = CompressionConfig(temp_storage_dir=shared, calib_size=4, calibs_batch_size=2, compression_ratio=0.3)
+        n_layers = N_LAYERS
 
         def save_layer(self, output_dir, suffix, weights, layer_idx):
             os.makedirs(output_dir, exist_ok=True)
             torch.save(weights, os.path.join(output_dir, f"layer_{layer_idx}_{suffix}"))
 
     ad = A()
-    chunk = list(range(5))  # 5 layers over 2 ranks: 3 + 2 (ragged)
+    calibrated = []
+
+    # the GPU stages of compress_chunk, replaced: same signatures, deterministic artefacts written through adapter.save_layer
+    def load_calibs(adapter, n_samples, batch_size, dataset, target_layers):
+        calibrated.append(list(target_layers))
+        none = [None] * N_LAYERS
+        return none, none, none, none, [0.1 * (i + 1) for i in range(N_LAYERS)]     # BI for ALL layers, on every rank
+
+    def allocate(bi, **kw):
+        return [0.7] * N_LAYERS
+
+    def nystrom(adapter, cov, keep_ratios, target_layers):
+        for i in target_layers:
+            adapter.save_layer(adapter.config.temp_storage_dir, "mlp", {k: _layer(i)[0][k] for k in ("up", "gate", "down")}, i)
+
+    def qk(adapter, cov, keep_ratios, target_layers):
+        for i in target_layers:
+            adapter.save_layer(adapter.config.temp_storage_dir, "qk", {k: _layer(i)[0][k] for k in ("q_proj", "k_proj")}, i)
+        return [_layer(i)[1] for i in target_layers]
+
+    def vo(adapter, cov, keep_ratios, target_layers):
+        for i in target_layers:
+            adapter.save_layer(adapter.config.temp_storage_dir, "vo", {k: _layer(i)[0][k] for k in ("v_proj", "o_proj")}, i)
+
+    R.load_calibs, R.allocate_global_sparsity, R.compress_nystrom, R.compress_qk, R.compress_vo = load_calibs, allocate, nystrom, qk, vo
+    R._free = lambda: None
+    written = []
+    real_write = S._write_artifact
+    S._write_artifact = lambda d, layer, suffix, w: (written.append((layer, suffix)), real_write(d, layer, suffix, w))[1]
+
+    chunk = list(range(N_LAYERS))
     mine = S.my_layers(chunk, rank, world)
     assert mine == ([0, 1, 2] if rank == 0 else [3, 4])
-    masks = []
-    for i in mine:
-        t, m = _layer(i)
-        ad.save_layer(ad.config.temp_storage_dir, "mlp", {k: t[k] for k in ("up", "gate", "down")}, i)
-        ad.save_layer(ad.config.temp_storage_dir, "qk", {k: t[k] for k in ("q_proj", "k_proj")}, i)
-        ad.save_layer(ad.config.temp_storage_dir, "vo", {k: t[k] for k in ("v_proj", "o_proj")}, i)
-        masks.append(m)
-    all_masks = S.gather_layer_artifacts(ad, chunk, mine, masks, rank, world)
-    assert len(all_masks) == 5
-    for i in chunk:
-        t, m = _layer(i)
-        assert torch.equal(all_masks[i], m)
-        got = {}
-        for suffix in ("mlp", "qk", "vo"):
-            got.update(torch.load(os.path.join(ad.config.temp_storage_dir, f"layer_{i}_{suffix}")))
-        for k, v in t.items():
-            assert torch.equal(got[k], v), (rank, i, k)
-    dist.barrier()
-    dist.destroy_process_group()
+    for rep in range(3):                              # several chunks back to back: ordering must hold every time
+        all_masks = R.compress_chunk(ad, ad.config, chunk, rank, world)
+        assert calibrated[-1] == mine                 # hooks only for this rank's layers
+        assert len(all_masks) == N_LAYERS
+        for i in chunk:
+            assert torch.equal(all_masks[i], _layer(i)[1])
+        if rank == 0:
+            # what convert_model does next, with NO barrier in between: every layer's three files must be whole and right
+            for i in chunk:
+                got = {}
+                for suffix in ("mlp", "qk", "vo"):
+                    got.update(torch.load(os.path.join(shared, f"layer_{i}_{suffix}")))
+                for k, v in _layer(i)[0].items():
+                    assert torch.equal(got[k], v), (rep, i, k)
+    # only the consumer wrote artefacts it does not own; the others wrote nothing beyond their own layers
+    if rank == 0:
+        assert sorted(set(written)) == sorted((i, s) for i in (3, 4) for s in ("mlp", "qk", "vo")) and len(written) == 3 * 6
+    else:
+        assert written == []
+    assert not [f for f in os.listdir(shared) if ".tmp" in f]
+    S.finalize()                                      # barrier + destroy: the collective phase ends here for every rank
+    assert not dist.is_initialized()
 
 
-def test_two_rank_gather():
+def test_two_rank_compress_chunk_with_a_shared_artefact_directory():
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_worker, args=(2, _free_port(), tmp), nprocs=2, join=True)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment: the script spawns two fresh ranks itself (here on CPU over gloo,
+    plumbing only -- the kernels need a GPU), rank 0 prints the one JSON line, exit code 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--plumbing-only"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["plumbing_only"] and out["gathered_layers"] == 6 and out["backend"] == "gloo"
+
+
+def test_bench_launcher_propagates_a_failing_rank():
+    """A child that dies must fail the whole command (here: the kernels' refusal to run without a GPU)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    if torch.cuda.is_available():
+        return
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "no GPU here" in p.stderr
