@@ -283,27 +283,50 @@ struct SyrkArgs {
   unsigned long long* mfma_count;      // += v_mfma instructions this launch executed (the dense count is known on the host)
   const int* route_flag;               // written by i8_depth_kernel: 0 -> five planes, 1 -> six planes, bit 1 set -> the fp64 kernel
   int* route_counts;                   // optional device counters [five planes, six planes, fp64 fallback], += 1 by the launch that runs
+#ifdef MDG_I8_STAMPS
+  unsigned long long* stamps;          // diagnostic build only: per (workgroup, wave) cycle sums of the k-step phases
+#endif
 };
+#ifdef MDG_I8_STAMPS
+#define MDG_STAMP(x) x = __builtin_amdgcn_s_memtime()
+constexpr int STAMP_WGS = 1024;
+#else
+#define MDG_STAMP(x)
+#endif
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16,
                                    0, 0);
 }
 
-// Shape and LDS ring per route.  One workgroup of 8 waves per CU (two waves per SIMD, <= 256 registers each).  The kernel runs
-// at the power cap and is fed through L2 -> LDS, so what counts is bytes moved per MFMA and how much of a k-step's
-// bookkeeping hides behind the other wave's MFMAs.
+// Shape and LDS ring per route.  One workgroup of 8 waves per CU (two waves per SIMD, <= 256 registers each).
 //   P = 5: 128 x 128 tile, wave tile 64 x 32 (160 accumulators), stages of 40 KB -- 40 KB of L2 -> LDS traffic per k-step for
-//          16384 outputs where two 128 x 64 tiles move 60 KB.
-//   P = 6: 128 x 64 tile, wave tile 32 x 32 (96 accumulators), stages of 36 KB.
-// Ring of 3 stages, filled two k-steps ahead by LDS-DMA.  The two waves of a SIMD take OPPOSITE orders inside a k-step
-// (roles by wave number >= 4, MI355X_MICROARCH.md "Two waves per SIMD" item 9): waves 4-7 issue their share of the stage
-// loads right after the barrier and multiply afterwards; waves 0-3 multiply first and issue their loads at the end of the
-// step.  With every wave in the same order (first versions: 2-stage ring, loads first) the matrix pipe idled through the
-// ~1000 cycles per k-step that eight waves spend side by side on mask decoding, address arithmetic and LDS-DMA issue -- MFMA
-// busy 0.50 -- now one wave's bookkeeping runs under its SIMD partner's MFMAs.  A wave waits for its own loads (vmcnt(0))
-// right before it issues the next ones, a whole k-step after they went out, so the wait is free and needs no load count (the
-// number of pieces a wave loads varies from step to step with the zero-plane skipping).
+//          16384 outputs where two 128 x 64 tiles move 60 KB.  Ring of 3 stages, filled two k-steps ahead.
+//   P = 6: 128 x 64 tile, wave tile 32 x 32 (96 accumulators), stages of 36 KB.  Ring of 4 stages, filled three k-steps ahead;
+//          a stage is therefore complete one barrier before it is multiplied, and a wave reads the next step's fragments right
+//          after its last MFMA of this one (their latency runs under its load issue / the barrier).
+// What a k-step costs besides its MFMAs, by s_memtime stamps (diagnostic build -DMDG_I8_STAMPS; five planes, Gaussian
+// columns, 18.8 MFMAs per wave and step = 1203 matrix-pipe cycles per SIMD): in the first versions (2-stage ring, every wave:
+// barrier -> its 5 stage loads -> fragment reads -> MFMAs) a step took ~2500 cycles -- ~700-800 of them spent by all eight
+// waves side by side on ~100 instructions of mask decoding (clz / med3 on the VALU), 64-bit address updates and LDS-DMA
+// issue while no wave multiplied, then ~1360 on the MFMAs (the younger wave of each SIMD loses the arbitration and finishes
+// last; the older one idles ~700 at the next barrier).  Two changes:
+//   * the stage loads are driven by per-wave piece descriptors held in SGPRs (base address, LDS offset, mask byte position,
+//     plane bits), ~9 scalar instructions per piece, the address an SGPR base + one VGPR offset shared by all pieces
+//     (issue_stage): ~420-540 cycles for the 5 loads -- what is left is the LDS-DMA instruction itself, which holds its wave
+//     ~85-100 cycles at issue;
+//   * the two waves of a SIMD take OPPOSITE orders inside a k-step (roles by wave number >= 4, MI355X_MICROARCH.md "Two waves
+//     per SIMD" item 9): waves 4-7 issue their share of the stage loads right after the barrier and multiply afterwards;
+//     waves 0-3 multiply first and issue their loads at the end of the step -- one wave's load issue runs under its partner's
+//     MFMAs.  A wave waits for its own loads (vmcnt(0)) right before it issues the next ones, a whole k-step after they went
+//     out, so the wait is free and needs no load count (the number of pieces a wave loads varies with the zero-plane skipping).
+// Five planes 26.7 -> 24.2 ms per sigma_mlp call (~1970 cycles per step), six planes 46.4 -> 37.9 ms.  Measured and dropped on
+// the way: a ping-pong with a second barrier per step (one wave of a SIMD only loads while the other only multiplies: 50.8 ms
+// -- an LDS-DMA issue beside a partner that issues MFMAs back to back takes 380 cycles instead of 85, s_setprio changes
+// nothing); the loads dealt out between a wave's own MFMAs (EXEC = 0 for skipped pieces, the accumulators as asm operands
+// to pin the order: 27.0 / 41.6 ms -- in lock-step both waves of a SIMD stall in their load issue together); fragment reads
+// ahead of the load issue; static s_setprio 1 for waves 4-7 (26.4 ms); four stages + fragment prefetch for five planes too
+// (24.7 ms); super-blocks of 1 / 4 x 4 tiles for six planes (39.4 / 39.0 ms).
 #ifndef MDG_I8_SKIP_ZERO
 #define MDG_I8_SKIP_ZERO 1    // skip the LDS-DMA load, the fragment read and the MFMAs of all-zero pieces
 #endif
@@ -317,7 +340,7 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 #define MDG_I8_ROLES 1  // 0: every wave loads first (the lock-step order of the first versions)
 #endif
 constexpr int NW = 8;     // waves per workgroup
-constexpr int RING = 3;   // LDS stages
+constexpr int ring_depth(int planes) { return planes == 6 ? 4 : 3; }
 
 template <int P>  // planes used: 5 or 6
 __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
@@ -329,6 +352,8 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
   constexpr int STAGE_BYTES = P * (PA + PB);       // 40 KB (P = 5, 128 x 128) / 36 KB (P = 6, 128 x 64)
   constexpr int PIECES = (GA + GB) * P;            // 1 KB pieces per stage
   constexpr bool SKIP = MDG_I8_SKIP_ZERO;
+  constexpr int RING = ring_depth(P);              // LDS stages
+  constexpr bool PREFETCH = P == 6;                // the next step's fragments are read before the barrier (needs RING = 4)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   // The route is chosen on the DEVICE: mdg_cov_accum_i8 enqueues the five-plane product, the six-plane product and the fp64
   // kernel back to back, and each exits at once unless the depth statistic of this call (i8_depth_kernel) selects it -- the
@@ -394,20 +419,44 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
     const unsigned byte = (m >> (8 * g)) & 0xFFu;
     return max(MIN_DEPTH, min(P, 32 - __builtin_clz(byte | 1u)));
   };
-  auto issue_stage = [&](int kt, int buf, unsigned mA, unsigned mB) {
+  // Per-wave piece descriptors, all wave-uniform (SGPRs), set up once: the k-step loop then spends ~8 scalar instructions per
+  // piece on the test "does this piece hold a nonzero" + M0 + one LDS-DMA load whose address is SGPR base + one VGPR offset
+  // (lane * 16 + k-step * 1024) shared by all pieces.  (First version: a running 64-bit address per piece, depth through
+  // clz / med3 on the VALU, exec-masked branches -- ~100 instructions per k-step and wave, 700-800 cycles by s_memtime stamps,
+  // during which no wave of the workgroup multiplied.)
+  constexpr int NQ = (PIECES + NW - 1) / NW;
+  unsigned long long pc_base[NQ];
+  unsigned pc_loff[NQ], pc_shift[NQ], pc_cmask[NQ], pc_force[NQ];
+  bool pc_valid[NQ];
 #pragma unroll
-    for (int q = 0; q < (PIECES + NW - 1) / NW; q++) {
-      const int p = wave + NW * q;
-      if (p < PIECES) {
-        const bool isA = p < GA * P;
-        const int pp = isA ? p : p - GA * P;
-        const int s = isA ? pp / GA : pp / GB, g = isA ? pp % GA : pp % GB;
-        if (SKIP && s >= group_depth(isA ? mA : mB, g)) continue;   // an all-zero piece: nothing will read it
-        const int64_t G = (isA ? bi * (TI / 32) : bj * (TJ / 32)) + g;
-        const signed char* src = a.planes + ((s * groups + G) * (int64_t)nk + kt) * 1024 + lane * 16;
-        unsigned char* dst = lds + buf * STAGE_BYTES + (isA ? s * PA : P * PA + s * PB) + g * 1024;
-        glds16(src, dst);
-      }
+  for (int q = 0; q < NQ; q++) {
+    const int p = wave + NW * q;
+    pc_valid[q] = (PIECES % NW == 0 && q < PIECES / NW) || p < PIECES;
+    const bool isA = p < GA * P;
+    const int pp = isA ? p : p - GA * P;
+    const int s = isA ? pp / GA : pp / GB, g = isA ? pp % GA : pp % GB;
+    const int64_t G = (isA ? bi * (TI / 32) : bj * (TJ / 32)) + g;
+    const unsigned long long base = (unsigned long long)(uintptr_t)a.planes + (unsigned long long)((s * groups + G) * (int64_t)nk) * 1024ull;
+    pc_base[q] = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(base >> 32)) << 32) |
+                 (unsigned)__builtin_amdgcn_readfirstlane((unsigned)base);
+    pc_loff[q] = (isA ? s * PA : P * PA + s * PB) + g * 1024;
+    pc_shift[q] = (isA ? 0 : 32) + 8 * g;
+    pc_cmask[q] = (0xFFu << s) & 0xFFu;          // bits s .. 7 of the group's mask byte: some plane >= s holds a nonzero
+    pc_force[q] = (!SKIP || s < MIN_DEPTH) ? 1u : 0u;   // planes below MIN_DEPTH are always staged (the unconditional MFMA block reads them)
+  }
+  const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)lds);
+  const unsigned lane16 = lane * 16;
+  auto issue_stage = [&](int kt, int buf, unsigned mA, unsigned mB) {
+    const unsigned long long m64 = ((unsigned long long)mB << 32) | mA;
+    const unsigned lbase = lds_base + buf * STAGE_BYTES;
+    const unsigned voff = lane16 + (unsigned)kt * 1024u;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      if (!pc_valid[q]) continue;
+      const unsigned present = ((unsigned)(m64 >> pc_shift[q]) & pc_cmask[q]) | pc_force[q];
+      if (present)   // (an all-zero piece is not loaded: nothing will read it)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lbase + pc_loff[q]), "v"(voff), "s"(pc_base[q])
+                     : "memory", "m0");
     }
   };
 
@@ -468,112 +517,159 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
   auto b_half = [&](unsigned m) { return TJ == 128 ? m : (m >> ((bj & 1) * 16)) & 0xFFFFu; };
   auto wait_loads = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
-  // masks of stage kt (being multiplied), kt + 1 (landed or landing) -- SGPRs; vA / vB: the loaded dwords of stage kt + 2
-  unsigned mA0 = ~0u, mB0 = ~0u, mA1 = ~0u, mB1 = ~0u, vA = ~0u, vB = ~0u;
+  // masks of the stages kt (being multiplied) .. kt + D (the one this step issues) -- SGPRs; vA / vB: the loaded dwords of the
+  // stage after those, in flight
+  constexpr int D = RING - 1;
+  unsigned mA[D + 1], mB[D + 1], vA = ~0u, vB = ~0u;
+#pragma unroll
+  for (int i = 0; i <= D; i++) mA[i] = mB[i] = ~0u;
   unsigned executed = 0;
   if (SKIP) {
-    unsigned t0, t1;
-    load_masks(0, t0, t1);
-    mA0 = __builtin_amdgcn_readfirstlane(t0);
-    mB0 = b_half(__builtin_amdgcn_readfirstlane(t1));
-    if (nk > 1) {
-      load_masks(1, t0, t1);
-      mA1 = __builtin_amdgcn_readfirstlane(t0);
-      mB1 = b_half(__builtin_amdgcn_readfirstlane(t1));
-    }
-    if (nk > 2) load_masks(2, vA, vB);
+#pragma unroll
+    for (int i = 0; i < D; i++)
+      if (i < nk) {
+        unsigned t0, t1;
+        load_masks(i, t0, t1);
+        mA[i] = __builtin_amdgcn_readfirstlane(t0);
+        mB[i] = b_half(__builtin_amdgcn_readfirstlane(t1));
+      }
+    if (nk > D) load_masks(D, vA, vB);
   }
-  issue_stage(0, 0, mA0, mB0);
-  if (nk > 1) issue_stage(1, 1, mA1, mB1);
+#pragma unroll
+  for (int i = 0; i < D; i++)
+    if (i < nk) issue_stage(i, i, mA[i], mB[i]);
   wait_loads();
   int buf = 0;                 // kt % RING
+#ifdef MDG_I8_STAMPS
+  unsigned long long ta = 0, tb = 0, tc = 0, td = 0, te = 0, s_wait = 0, s_issue = 0, s_comp = 0, s_tail = 0, t_begin;
+  MDG_STAMP(t_begin);
+#endif
+  const int r = lane & 31, h = lane >> 5;
+  // fragments of the planes below MIN_DEPTH (always staged, always multiplied): ONE set of reads feeds all their pairs
+  i32x4 fa[MIN_DEPTH][WB], fb[MIN_DEPTH];
+  auto load_frags = [&](int stage_buf) {
+    const unsigned char* base = lds + stage_buf * STAGE_BYTES;
+#pragma unroll
+    for (int s = 0; s < MIN_DEPTH; s++) {
+#pragma unroll
+      for (int b = 0; b < WB; b++) fa[s][b] = *(const i32x4*)(base + s * PA + (wr * WB + b) * 1024 + h * 512 + r * 16);
+      fb[s] = *(const i32x4*)(base + P * PA + s * PB + wc * 1024 + h * 512 + r * 16);
+    }
+  };
+  // the deeper planes of a step, each present one a block of its own (fragment read + its pairs).  A deep plane only pairs with
+  // planes 0 (and 1) of the other panel (s + t < P), so the blocks are independent and simply add:
+  //   P = 5: 9 pairs + 2 [dA > 3] + 2 [dB > 3] + [dA > 4] + [dB > 4];   P = 6: 15 + 2 [dA > 4] + 2 [dB > 4] + [dA > 5] + [dB > 5]
+  // (branching around single MFMAs / fragment reads instead makes hipcc put an lgkmcnt(0) in front of every LDS read; nine
+  // straight-line variants behind a switch make it spill the 160 accumulators at the merges)
+  auto deep_planes = [&](int stage_buf, unsigned mAk, unsigned mBk) {
+    const unsigned char* base = lds + stage_buf * STAGE_BYTES;
+    int dAb[WB];
+#pragma unroll
+    for (int b = 0; b < WB; b++) dAb[b] = SKIP ? group_depth(mAk, wr * WB + b) : P;
+    const int dBw = SKIP ? group_depth(mBk, wc) : P;
+    int deep_mfmas = 0;
+#pragma unroll
+    for (int d = MIN_DEPTH; d < P; d++) {
+#pragma unroll
+      for (int b = 0; b < WB; b++)
+        if (dAb[b] > d) {   // plane d of A block b with planes t < P - d of B (all below MIN_DEPTH: already in registers)
+          const i32x4 fd = *(const i32x4*)(base + d * PA + (wr * WB + b) * 1024 + h * 512 + r * 16);
+#pragma unroll
+          for (int t = 0; t < P - d; t++) acc[d + t][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fd, fb[t], acc[d + t][b], 0, 0, 0);
+          deep_mfmas += P - d;
+        }
+      if (dBw > d) {        // plane d of the B block with planes s < P - d of both A blocks
+        const i32x4 fd = *(const i32x4*)(base + P * PA + d * PB + wc * 1024 + h * 512 + r * 16);
+#pragma unroll
+        for (int s2 = 0; s2 < P - d; s2++)
+#pragma unroll
+          for (int b = 0; b < WB; b++)
+            acc[s2 + d][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s2][b], fd, acc[s2 + d][b], 0, 0, 0);
+        deep_mfmas += (P - d) * WB;
+      }
+    }
+    executed += deep_mfmas;
+  };
+  constexpr int UNCOND_PAIRS = P == 5 ? 9 : (MIN_DEPTH == 4 ? 15 : 21);   // pairs (s, t), s, t < MIN_DEPTH, s + t < P
+  auto rotate = [&]() {
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+      mA[i] = mA[i + 1];
+      mB[i] = mB[i + 1];
+    }
+    buf = buf == RING - 1 ? 0 : buf + 1;
+  };
+  const auto ahead = [&](int d) { int x = buf + d; return x >= RING ? x - RING : x; };   // (kt + d) % RING
+  if (PREFETCH) {
+    __builtin_amdgcn_s_barrier();   // stages 0 .. D - 1 complete (every wave waited for its share)
+    load_frags(0);
+  }
   // two loops: the int32 classes are folded into sigma between runs of FLUSH_STEPS k-steps, outside the MFMA loop (a
   // conditional flush inside it makes the compiler shuttle all 160 accumulators between AGPRs and VGPRs every step)
   for (int k0 = 0; k0 < nk; k0 += FLUSH_STEPS) {
     const int k1 = min(nk, k0 + FLUSH_STEPS);
+    // Roles: the two waves of a SIMD take opposite orders inside a k-step.  Waves 4-7 issue their share of stage kt + D right
+    // after the barrier and multiply afterwards; waves 0-3 multiply first and issue at the end of the step (after waiting for
+    // their previous loads, a whole k-step old by then) -- one wave's ~450 cycles of LDS-DMA issue run under its partner's MFMAs.
     for (int kt = k0; kt < k1; kt++) {
-      // A wave's share of stage kt + 1 went out a k-step ago (at this point of the previous step for the loads-first waves, at
-      // the end of the step before for the others); each wave has waited for its own before it arrives here.
-      if (loads_first) wait_loads();
-      __builtin_amdgcn_s_barrier();   // stage kt complete in LDS (every wave waited for its share), stage kt - 1 no longer read
-      unsigned mA2 = ~0u, mB2 = ~0u;
-      auto refill = [&]() {           // stage kt + 2 into the buffer stage kt - 1 just left; masks of kt + 3 behind it
+      MDG_STAMP(ta);
+      if (loads_first) wait_loads();  // this wave's loads of the previous step
+      __builtin_amdgcn_s_barrier();   // stage kt (PREFETCH: kt + 1 too) complete in LDS, stage kt - 1 no longer read
+      auto refill = [&]() {           // stage kt + D into the buffer stage kt - 1 just left; masks of the stage after it behind it
         if (SKIP) {
-          mA2 = __builtin_amdgcn_readfirstlane(vA);
-          mB2 = b_half(__builtin_amdgcn_readfirstlane(vB));
+          mA[D] = __builtin_amdgcn_readfirstlane(vA);
+          mB[D] = b_half(__builtin_amdgcn_readfirstlane(vB));
         }
-        const int nb = buf == 0 ? 2 : buf - 1;   // (kt + 2) % 3
-        if (kt + 2 < nk) issue_stage(kt + 2, nb, mA2, mB2);
-        if (SKIP && kt + 3 < nk) load_masks(kt + 3, vA, vB);
+        if (kt + D < nk) issue_stage(kt + D, ahead(D), mA[D], mB[D]);
+        if (SKIP && kt + D + 1 < nk) load_masks(kt + D + 1, vA, vB);
       };
+      MDG_STAMP(tb);
       if (loads_first) {
         refill();
         __builtin_amdgcn_sched_barrier(0);
       }
-      int dAb[WB];
-#pragma unroll
-      for (int b = 0; b < WB; b++) dAb[b] = SKIP ? group_depth(mA0, wr * WB + b) : P;
-      const int dBw = SKIP ? group_depth(mB0, wc) : P;
-      const unsigned char* base = lds + buf * STAGE_BYTES;
-      const int r = lane & 31, h = lane >> 5;
-      // The step: planes below MIN_DEPTH of both panels unconditionally -- ONE set of fragment reads, all their pairs -- then,
-      // for each deeper plane that is present, a block of its own (fragment read + its pairs).  A deep plane only pairs with
-      // planes 0 (and 1) of the other panel (s + t < P), so the blocks are independent and simply add:
-      //   P = 5: 9 pairs + 2 [dA > 3] + 2 [dB > 3] + [dA > 4] + [dB > 4];   P = 6: 15 + 2 [dA > 4] + 2 [dB > 4] + [dA > 5] + [dB > 5]
-      // (branching around single MFMAs / fragment reads instead makes hipcc put an lgkmcnt(0) in front of every LDS read; nine
-      // straight-line variants behind a switch make it spill the 160 accumulators at the merges)
-      i32x4 fa[MIN_DEPTH][WB], fb[MIN_DEPTH];
-#pragma unroll
-      for (int s = 0; s < MIN_DEPTH; s++) {
-#pragma unroll
-        for (int b = 0; b < WB; b++) fa[s][b] = *(const i32x4*)(base + s * PA + (wr * WB + b) * 1024 + h * 512 + r * 16);
-        fb[s] = *(const i32x4*)(base + P * PA + s * PB + wc * 1024 + h * 512 + r * 16);
-      }
-      int pairs = 0;
+      MDG_STAMP(tc);
+      if (!PREFETCH) load_frags(buf);
 #pragma unroll
       for (int s = 0; s < MIN_DEPTH; s++)
 #pragma unroll
         for (int t = 0; t < MIN_DEPTH; t++)
           if (s + t < P) {
-            pairs++;
 #pragma unroll
             for (int b = 0; b < WB; b++)
               acc[s + t][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s][b], fb[t], acc[s + t][b], 0, 0, 0);
           }
-      int deep_mfmas = 0;
-#pragma unroll
-      for (int d = MIN_DEPTH; d < P; d++) {
-#pragma unroll
-        for (int b = 0; b < WB; b++)
-          if (dAb[b] > d) {   // plane d of A block b with planes t < P - d of B (all below MIN_DEPTH: already in registers)
-            const i32x4 fd = *(const i32x4*)(base + d * PA + (wr * WB + b) * 1024 + h * 512 + r * 16);
-#pragma unroll
-            for (int t = 0; t < P - d; t++) acc[d + t][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fd, fb[t], acc[d + t][b], 0, 0, 0);
-            deep_mfmas += P - d;
-          }
-        if (dBw > d) {        // plane d of the B block with planes s < P - d of both A blocks
-          const i32x4 fd = *(const i32x4*)(base + P * PA + d * PB + wc * 1024 + h * 512 + r * 16);
-#pragma unroll
-          for (int s2 = 0; s2 < P - d; s2++)
-#pragma unroll
-            for (int b = 0; b < WB; b++)
-              acc[s2 + d][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s2][b], fd, acc[s2 + d][b], 0, 0, 0);
-          deep_mfmas += (P - d) * WB;
-        }
+      deep_planes(buf, mA[0], mB[0]);
+      executed += UNCOND_PAIRS * WB;
+      if (PREFETCH) {
+      // next step's fragments: stage kt + 1 has been complete since THIS step's barrier (its loads went out three steps ago
+      // and every wave waited for its share before the barrier), so the read latency hides behind the refill / the barrier
+      __builtin_amdgcn_sched_barrier(0);   // (not before the MFMAs above are issued: the fragment registers are theirs until then)
+      if (kt + 1 < nk) load_frags(ahead(1));
       }
-      executed += deep_mfmas;
-      executed += pairs * WB;
+      MDG_STAMP(td);
       if (!loads_first) {
         __builtin_amdgcn_sched_barrier(0);
-        wait_loads();       // this wave's share of stage kt + 1, issued at this point of the previous step
+        wait_loads();       // this wave's loads of the previous step
         refill();
       }
-      mA0 = mA1; mB0 = mB1; mA1 = mA2; mB1 = mB2;
-      buf = buf == RING - 1 ? 0 : buf + 1;
+      MDG_STAMP(te);
+#ifdef MDG_I8_STAMPS
+      s_wait += tb - ta; s_issue += tc - tb; s_comp += td - tc; s_tail += te - td;
+#endif
+      rotate();
     }
     flush();
   }
   if (a.mfma_count && lane == 0) atomicAdd(a.mfma_count, (unsigned long long)executed);
+#ifdef MDG_I8_STAMPS
+  if (a.stamps && lane == 0 && blockIdx.x < STAMP_WGS) {
+    unsigned long long t_end;
+    MDG_STAMP(t_end);
+    unsigned long long* o = a.stamps + ((size_t)blockIdx.x * NW + wave) * 8;
+    o[0] = s_wait; o[1] = s_issue; o[2] = s_comp; o[3] = s_tail; o[4] = t_end - t_begin; o[5] = executed; o[6] = nk;
+  }
+#endif
 }
 
 size_t planes_bytes(int64_t T, int64_t n) { return (size_t)NP * (size_t)n * (size_t)ceil_div(T, KS) * KS; }
@@ -641,6 +737,13 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
   SyrkArgs a;
   a.planes = planes; a.emax = emax; a.sigma = sigma; a.ld_sigma = ld_sigma; a.n = n; a.nk = nk; a.zmask = zmask; a.mfma_count = mfma_count;
   a.route_flag = flag; a.route_counts = route_counts;
+#ifdef MDG_I8_STAMPS
+  static unsigned long long* stamps_dev = nullptr;
+  const size_t stamps_n = (size_t)STAMP_WGS * NW * 8;
+  if (!stamps_dev) MDG_HIP(hipMalloc(&stamps_dev, stamps_n * 8));
+  MDG_HIP(hipMemsetAsync(stamps_dev, 0, stamps_n * 8, st));
+  a.stamps = stamps_dev;
+#endif
   const int rb = n / TI;
   if (ev_start) MDG_HIP(hipEventRecord((hipEvent_t)ev_start, st));
   for (int planes_used = 5; planes_used <= 6; planes_used++) {
@@ -650,7 +753,7 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
 #endif
     const bool wide = planes_used == 5;                                        // 128 x 128 tiles; six planes: 128 x 64
     const int tj = wide ? 128 : 64;
-    const size_t lds = (size_t)RING * planes_used * (PA + tj * KS);
+    const size_t lds = (size_t)ring_depth(planes_used) * planes_used * (PA + tj * KS);
     const int si = planes_used == 5 ? MDG_I8_SB5 : MDG_I8_SB6;                 // super-block rows (see the kernel); 0 = row-major
     const int sr = si ? (rb + si - 1) / si : 0, nsb = sr * (sr + 1) / 2;       // super-block rows, super-blocks
     const int tps = wide ? si * si : 2 * si * si;                              // tiles per super-block
@@ -669,6 +772,28 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
   const int fb = cov_accum_gated(x, MDG_BF16, n_tokens, n_feat, 1, ld, 0, sigma, ld_sigma, 0, fb_ws,
                                  ws_bytes - (size_t)((char*)fb_ws - (char*)ws), flag, 2, 2, stream);
   if (fb != MDG_OK) return fb;
+#ifdef MDG_I8_STAMPS
+  {
+    static unsigned long long host[STAMP_WGS * NW * 8];
+    MDG_HIP(hipMemcpyAsync(host, a.stamps, sizeof(host), hipMemcpyDeviceToHost, st));
+    MDG_HIP(hipStreamSynchronize(st));
+    double sum[2][6] = {};
+    long cnt[2] = {};
+    for (int w = 0; w < STAMP_WGS * NW; w++) {
+      const unsigned long long* o = host + (size_t)w * 8;
+      if (!o[6]) continue;
+      const int role = (w % NW) >= NW / 2;
+      for (int i = 0; i < 6; i++) sum[role][i] += (double)o[i] / (double)o[6];
+      cnt[role]++;
+    }
+    for (int role = 0; role < 2; role++)
+      if (cnt[role])
+        fprintf(stderr, "[stamps n=%d] waves %s: per k-step cycles (s_memtime): wait+barrier %.0f  refill-first %.0f  reads+mfma-issue %.0f  "
+                        "wait+refill-last %.0f  | whole tile / nk %.0f  mfma/step %.1f  (%ld waves)\n", n, role ? "4-7" : "0-3",
+                sum[role][0] / cnt[role], sum[role][1] / cnt[role], sum[role][2] / cnt[role], sum[role][3] / cnt[role],
+                sum[role][4] / cnt[role], sum[role][5] / cnt[role], cnt[role]);
+  }
+#endif
   if (used_i8) {   // measurement / test mode: report the route this call took (costs the host a round trip)
     int depth = 0;
     MDG_HIP(hipMemcpyAsync(&depth, flag, sizeof(int), hipMemcpyDeviceToHost, st));

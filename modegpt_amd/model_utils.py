@@ -127,7 +127,12 @@ def save_compressed_model(adapter, rotary_masks, save_dir: str, source_model_nam
         tokenizer.save_pretrained(save_dir)
     if mask_path is not None:
         torch.save(rotary_masks, mask_path)
+    # the modeling file config.auto_map names, and the module it imports relatively: together they depend on torch and
+    # transformers only, so the checkpoint loads on a machine without this engine (as the reference's single file does)
     shutil.copy(os.path.join(patchers_dir, rebuild_file_for(adapter.arch)), save_dir)
+    support = os.path.join(patchers_dir, "compressed_attention.py")
+    if os.path.exists(support):
+        shutil.copy(support, save_dir)
     with open(os.path.join(save_dir, "tokenizer_source.txt"), "w") as f:
         f.write(source_model_name.strip())
     logger.info(f"Model, tokenizer, and tokenizer_source.txt saved to {save_dir}")

@@ -5,7 +5,7 @@ the checkpoint loads) and are applied over the kept columns with the weight gath
 same HIP kernel as the rotation (reference semantics: src/patchers/DenseQwenRebuild.py:246-286)."""
 from transformers.models.qwen3.modeling_qwen3 import Qwen3ForCausalLM as _StockQwen3ForCausalLM
 
-from modegpt_amd.patchers.compressed_attention import shrink_to_config_ranks
+from .compressed_attention import shrink_to_config_ranks   # travels with the checkpoint (save_compressed_model copies both files)
 
 
 class Qwen3ForCausalLM(_StockQwen3ForCausalLM):

@@ -10,7 +10,7 @@ written by either engine loads.
 """
 from transformers.models.llama.modeling_llama import LlamaForCausalLM as _StockLlamaForCausalLM
 
-from modegpt_amd.patchers.compressed_attention import shrink_to_config_ranks
+from .compressed_attention import shrink_to_config_ranks   # travels with the checkpoint (save_compressed_model copies both files)
 
 
 class LlamaForCausalLM(_StockLlamaForCausalLM):

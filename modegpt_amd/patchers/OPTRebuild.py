@@ -4,7 +4,7 @@ ModelAdapter.convert_model builds them); attention views q/k and v with their ow
 the compressed width (reference semantics: src/patchers/OPTRebuild.py:120-163)."""
 from transformers.models.opt.modeling_opt import OPTForCausalLM as _StockOPTForCausalLM
 
-from modegpt_amd.patchers.compressed_attention import shrink_to_config_ranks
+from .compressed_attention import shrink_to_config_ranks   # travels with the checkpoint (save_compressed_model copies both files)
 
 
 class OPTForCausalLM(_StockOPTForCausalLM):

@@ -9,7 +9,7 @@ stock HF modules and gives their attention the compressed semantics, with the el
   * q/k/v are viewed with their own per-layer head widths                        (LlamaRebuild.py:320-326)
   * RoPE: cos/sin are gathered along the feature axis by the rotary mask, per kv head, query heads of a group share
     their kv head's mask; rotate_half pairs the two halves of the KEPT columns   (LlamaRebuild.py:153-176)
-    -> ops.rope_gather (csrc/rope.hip), which also writes the [B, heads, T, r] layout attention reads
+    -> modegpt_amd.ops.rope_gather (csrc/rope.hip), which also writes the [B, heads, T, r] layout attention reads
   * Qwen3: q_norm / k_norm normalise over the kept columns with the norm weight gathered by the same mask
     (DenseQwenRebuild.py:262-286) -> fused into the same kernel
   * softmax scale = (compressed q/k head width) ** -0.5                          (LlamaRebuild.py:266,282)
@@ -22,10 +22,18 @@ Two entry points share the forward functions:
   shrink_to_config_ranks(model, arch)                   called by the modeling files shipped with a checkpoint
                                                          (patchers/{LlamaRebuild,DenseQwenRebuild,OPTRebuild}.py)
 
-Inference only: the kernel has no backward.  Tensors must live on the GPU (ops raise otherwise).
+This file travels WITH a compressed checkpoint (model_utils.save_compressed_model copies it next to the *Rebuild.py that
+imports it relatively), the way the reference ships its self-contained modeling file (src/model_utils.py:103-124): it
+depends on torch and transformers only.  The fused HIP kernel is used when the modegpt_amd package is importable and the
+tensors live on a GPU; anywhere else (another machine, a CPU) the same chain runs as plain torch ops, the reference's own
+expression op for op -- the checkpoint loads and evaluates wherever the reference's would.  Which path ran is counted in
+PATH_CALLS; MODEGPT_REQUIRE_HIP=1 turns the torch path into an error.
+
+Inference only: the kernel has no backward.
 """
 from __future__ import annotations
 
+import logging
 import os
 import types
 from typing import List, Optional
@@ -33,7 +41,65 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
-from .. import ops
+logger = logging.getLogger("MoDeGPT")
+PATH_CALLS = {"hip": 0, "torch": 0}     # rope/norm chains served by mdg_rope_gather / by the torch expression
+_HIP_OPS = None
+
+
+def _hip_ops():
+    """modegpt_amd.ops when this process can import it (the checkpoint is being used on the machine that holds the engine),
+    else None -- decided once."""
+    global _HIP_OPS
+    if _HIP_OPS is None:
+        try:
+            from modegpt_amd import ops as _ops
+            _HIP_OPS = _ops
+        except Exception as exc:  # not installed here: the portable path
+            _HIP_OPS = False
+            logger.warning("compressed attention: modegpt_amd is not importable (%s); running the torch expression", exc)
+    return _HIP_OPS or None
+
+
+def _rotate_half(x):
+    h = x.shape[-1] // 2
+    return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
+
+
+def _rope_gather_torch(x, cos, sin, mask, n_heads, n_kv, norm_weight=None, eps=1e-6):
+    """The reference's chain in torch (LlamaRebuild.py:153-186, DenseQwenRebuild.py:262-286): x [B, T, n_heads * r] ->
+    optional masked RMSNorm over the r kept columns (fp32, weight gathered by the mask) -> [B, n_heads, T, r] ->
+    x * cos[mask] + rotate_half(x) * sin[mask], every op rounded to the tensor dtype as eager torch does."""
+    B, T, width = x.shape
+    r = width // n_heads
+    x = x.view(B, T, n_heads, r)
+    m = None
+    if mask is not None:
+        m = mask.to(x.device)
+        if n_heads != n_kv:
+            m = torch.repeat_interleave(m, n_heads // n_kv, dim=0)         # query heads share their kv head's row
+    if norm_weight is not None:
+        xf = x.to(torch.float32)
+        normed = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
+        x = (norm_weight[m][None, None] * normed).to(x.dtype)
+    x = x.transpose(1, 2)                                                  # [B, n_heads, T, r]
+    if m is None:
+        c, s = cos.unsqueeze(1), sin.unsqueeze(1)
+    else:                                                                  # [1, T, H, r] -> [1, H, T, r]
+        c, s = cos[:1, :, m].permute(0, 2, 1, 3), sin[:1, :, m].permute(0, 2, 1, 3)
+    return x * c + _rotate_half(x) * s
+
+
+def _rope_gather(x, cos, sin, mask, n_heads, n_kv, head_dim, norm_weight=None, eps=1e-6):
+    hip = _hip_ops() if x.is_cuda else None
+    if hip is not None:
+        PATH_CALLS["hip"] += 1
+        return hip.rope_gather(x, cos, sin, mask, n_heads, n_kv, head_dim, norm_weight=norm_weight, eps=eps)
+    if os.environ.get("MODEGPT_REQUIRE_HIP", "0") == "1":
+        raise RuntimeError("compressed attention: MODEGPT_REQUIRE_HIP=1 but the HIP kernel cannot serve this call "
+                           f"(tensor on {x.device}, modegpt_amd importable: {_hip_ops() is not None})")
+    PATH_CALLS["torch"] += 1
+    return _rope_gather_torch(x, cos.to(x.dtype), sin.to(x.dtype), mask, n_heads, n_kv,
+                              None if norm_weight is None else norm_weight.detach().to(x.dtype), eps)
 
 
 def _attention_interface(module):
@@ -75,8 +141,8 @@ def _rope_forward(self, hidden_states, position_embeddings=None, attention_mask=
     if mask is not None:
         # the reference's gather index has batch extent 1 (LlamaRebuild.py:167-175): batch 0's table serves every batch
         cos, sin = cos[:1], sin[:1]
-    q = ops.rope_gather(q, cos, sin, mask, n_h, n_kv, hd, norm_weight=qw, eps=eps)      # [B, n_h,  T, r_qk]
-    k = ops.rope_gather(k, cos, sin, mask, n_kv, n_kv, hd, norm_weight=kw, eps=eps)     # [B, n_kv, T, r_qk]
+    q = _rope_gather(q, cos, sin, mask, n_h, n_kv, hd, norm_weight=qw, eps=eps)         # [B, n_h,  T, r_qk]
+    k = _rope_gather(k, cos, sin, mask, n_kv, n_kv, hd, norm_weight=kw, eps=eps)        # [B, n_kv, T, r_qk]
     if past_key_values is not None:
         k, v = past_key_values.update(k, v, self.layer_idx)
     extra = {"sliding_window": self.sliding_window} if getattr(self, "sliding_window", None) is not None else {}

@@ -8,9 +8,11 @@ writes are committed so they travel instead.
 
 What is pinned by the reference's own code (imported, device constants patched
 "cuda:0" -> "cpu"):
-  G1 sigma_mlp via LlamaAdapter._llama_pre_gate_hook / ModelAdapter._make_fc_hook
-     (sigma_x / sigma_q / sigma_k hooks carry a literal "cuda" and cannot run on
-     CPU; those come from the oracle restatement and are marked `restated`)
+  G1 sigma_mlp via LlamaAdapter._llama_pre_gate_hook / ModelAdapter._make_fc_hook;
+     sigma_x / sigma_q / sigma_k via LlamaAdapter._input_hook / _make_proj_hook (Llama, Qwen3) and
+     ModelAdapter._make_proj_hook / OPTAdapter.on_batch_end_step (OPT).  Those hooks move their input with a literal
+     device="cuda" (LlamaAdapter.py:119,142, model_adapter.py:560): for the duration of each call torch.Tensor.to is wrapped so
+     that "cuda" means "cpu" -- the reference's own lines run unmodified (cuda_means_cpu below)
   G2 get_ridge_scores, compress_weights
   G3 sqrt_M incl. a rank-deficient input
   G4 compress_head_llama_grouped / compress_head_llama / compress_head_opt
@@ -25,6 +27,7 @@ the max deviation is printed.
 from __future__ import annotations
 
 import argparse
+import contextlib
 import os
 import signal
 import sys
@@ -56,6 +59,28 @@ def make_weight(gen, rows, cols):
     return (torch.randn(rows, cols, generator=gen, dtype=torch.float32) * 0.02).to(BF16)
 
 
+@contextlib.contextmanager
+def cuda_means_cpu():
+    """The reference's sigma_x / sigma_q / sigma_k hooks say `.to(dtype=..., device="cuda")` literally.  While this context is
+    open, Tensor.to treats a "cuda..." device argument as "cpu"; nothing else about the call changes."""
+    real = torch.Tensor.to
+
+    def is_cuda(x):
+        return (isinstance(x, str) and x.startswith("cuda")) or (isinstance(x, torch.device) and x.type == "cuda")
+
+    def to(self, *args, **kw):
+        args = tuple("cpu" if is_cuda(x) else x for x in args)
+        if is_cuda(kw.get("device")):
+            kw["device"] = "cpu"
+        return real(self, *args, **kw)
+
+    torch.Tensor.to = to
+    try:
+        yield
+    finally:
+        torch.Tensor.to = real
+
+
 def reference_on_path(ref_root):
     """Make `import src...` mean the reference checkout.  The repo root carries its own `src` package (the drop-in alias
     of the reference's command line); it must not be importable while vectors are generated, or the 'reference' outputs
@@ -79,6 +104,7 @@ def load_reference(ref_root):
     import src.compression.compress_qk as cq
     import src.compression.compress_vo as cv
     import src.adapters.LlamaAdapter as la
+    import src.adapters.OPTAdapter as oa
     import src.adapters.model_adapter as ma
     for mod in (cu, cm, cq, cv):
         for name in ("d1", "d2"):
@@ -86,7 +112,8 @@ def load_reference(ref_root):
                 setattr(mod, name, "cpu")
     la.calib_device = "cpu"
     ma.calib_device = "cpu"
-    return types.SimpleNamespace(cu=cu, cm=cm, cq=cq, cv=cv, la=la, ma=ma)
+    oa.calib_device = "cpu"
+    return types.SimpleNamespace(cu=cu, cm=cm, cq=cq, cv=cv, la=la, ma=ma, oa=oa)
 
 
 def maxrel(a, b):
@@ -140,19 +167,42 @@ def gen_case(R, name, arch, d, d_ff, n_h, n_kv, hd, tokens, n_texts, keep, seed,
         (O.cov_accum_tokens_relu if arch == "opt" else O.cov_accum_tokens)(o_mlp, part)
     O.cov_finalize(o_mlp, n_texts)
     print(f"[{name}] sigma_mlp oracle vs ref hook: {maxrel(o_mlp, sig_mlp):.2e}")
-    # restated (literal "cuda" in the reference hooks)
-    sig_x = torch.zeros(d, d, dtype=F64)
-    sig_q = torch.zeros(n_h, hd, hd, dtype=F64)
-    sig_k = torch.zeros(n_kv, hd, hd, dtype=F64)
+    # sigma_x / sigma_q / sigma_k through the reference's own hooks ("cuda" redirected to the CPU for the call), two batches
+    cov_x, cov_q, cov_k = [torch.zeros(d, d, dtype=F64)], [torch.zeros(n_h, hd, hd, dtype=F64)], [torch.zeros(n_kv, hd, hd, dtype=F64)]
+    if arch == "opt":
+        hq = R.ma.ModelAdapter._make_proj_hook(0, cov_q, n_h, hd, d)          # adds head by head (model_adapter.py:556-567)
+        hk = R.ma.ModelAdapter._make_proj_hook(0, cov_k, n_kv, hd, d)
+        # OPTAdapter.on_batch_end_step (OPTAdapter.py:44-45) is never invoked upstream and does no upcast of its own; fed the
+        # fp64 input every other hook builds, it is the statistic the adapter intends
+        hx = lambda m, i, out: R.oa.OPTAdapter.on_batch_end_step(None, 0, out.to(F64), cov_x)  # noqa: E731
+    else:
+        hq = R.la.LlamaAdapter._make_proj_hook(0, cov_q, n_h, hd, d)          # LlamaAdapter.py:115-125
+        hk = R.la.LlamaAdapter._make_proj_hook(0, cov_k, n_kv, hd, d)
+        hx = R.la.LlamaAdapter._input_hook(0, cov_x)                          # LlamaAdapter.py:138-147
+    with cuda_means_cpu():
+        for sl in (slice(0, half), slice(half, tokens)):
+            n_sl = len(range(*sl.indices(tokens)))
+            # [B, T, features] with B = 2: the input hook sums the per-sample products over B (`torch.sum(.., dim=0)`)
+            Bsz = 2 if n_sl % 2 == 0 else 1
+            hx(None, None, X[sl].view(Bsz, n_sl // Bsz, d))
+            hq(None, None, Qp[sl].view(Bsz, n_sl // Bsz, n_h * hd))
+            hk(None, None, Kp[sl].view(Bsz, n_sl // Bsz, n_kv * hd))
+    sig_x, sig_q, sig_k = cov_x[0] / (n_texts * 2048), cov_q[0] / (n_texts * 2048), cov_k[0] / (n_texts * 2048)
+    # the oracle's restatement of the same hooks, for the printed deviation
+    o_x = torch.zeros(d, d, dtype=F64)
+    o_q = torch.zeros(n_h, hd, hd, dtype=F64)
+    o_k = torch.zeros(n_kv, hd, hd, dtype=F64)
     for sl in (slice(0, half), slice(half, tokens)):
-        O.cov_accum_tokens(sig_x, X[sl])
-        O.cov_accum_heads(sig_q, Qp[sl], n_h, hd)
-        O.cov_accum_heads(sig_k, Kp[sl], n_kv, hd)
-    for s in (sig_x, sig_q, sig_k):
-        O.cov_finalize(s, n_texts)
+        O.cov_accum_tokens(o_x, X[sl])
+        O.cov_accum_heads(o_q, Qp[sl], n_h, hd)
+        O.cov_accum_heads(o_k, Kp[sl], n_kv, hd)
+    for t in (o_x, o_q, o_k):
+        O.cov_finalize(t, n_texts)
+    print(f"[{name}] sigma_x / sigma_q / sigma_k oracle vs ref hooks: {maxrel(o_x, sig_x):.2e} / {maxrel(o_q, sig_q):.2e} / "
+          f"{maxrel(o_k, sig_k):.2e}")
     out["sigma_mlp"], out["sigma_x"], out["sigma_q"], out["sigma_k"] = (
         sig_mlp.numpy(), sig_x.numpy(), sig_q.numpy(), sig_k.numpy())
-    out["meta_restated"] = np.array("sigma_x,sigma_q,sigma_k")
+    out["meta_restated"] = np.array("")   # every statistic of this fixture comes out of the reference's own hook code
 
     # ---- G2: MLP ----
     lin = lambda w: types.SimpleNamespace(weight=w)  # noqa: E731

@@ -1,10 +1,12 @@
 """CPU: the oracle replays every golden vector captured from the imported reference (oracle/gen_golden.py)."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 from oracle import modegpt_oracle as O
-from tests.golden_util import CASES, ROPE_CASES, Case, RopeCase, load_misc, vo_products
+from tests.golden_util import CASES, GOLDEN_DIR, ROPE_CASES, Case, RopeCase, load_misc, vo_products
 
 F64 = torch.float64
 
@@ -28,7 +30,10 @@ def test_sigma(name):
         O.cov_accum_heads(k, c.act["k"][sl], c.n_kv, c.hd)
     for s in (mlp, x, q, k):
         O.cov_finalize(s, c.n_texts)
-    assert rel(mlp, c.f64["sigma_mlp"]) < 1e-14   # pinned by the reference's own hook
+    # all four fixtures come out of the reference's own hook code (gen_golden.py runs _input_hook / _make_proj_hook with their
+    # literal "cuda" redirected to the CPU): nothing in them is restated
+    assert str(np.load(os.path.join(GOLDEN_DIR, name + ".npz"))["meta_restated"]) == ""
+    assert rel(mlp, c.f64["sigma_mlp"]) < 1e-14
     assert rel(x, c.f64["sigma_x"]) < 1e-14
     assert rel(q, c.f64["sigma_q"]) < 1e-14
     assert rel(k, c.f64["sigma_k"]) < 1e-14
