@@ -70,7 +70,10 @@ def compress_stand_in(ad, kind: str):
         return m
 
     for i in range(ad.n_layers):
-        r_qk, r_vo, r_mlp = 8 + 2 * i, 9 + i, 100 + 7 * i
+        r_qk, r_mlp = 8 + 2 * i, 100 + 7 * i
+        # Llama / Qwen3: the same (even) head width for q/k and v/o, as compress_qk.py:176-182 and compress_vo.py:36-41 produce
+        # for one keep ratio -- the reference's attention views q, k AND v with q_ranks // n_heads (LlamaRebuild.py:266,326)
+        r_vo = 9 + i if kind == "opt" else r_qk
         ad.replace_attn_layers(i, lin(n_h * r_qk, d), lin(n_kv * r_qk, d), lin(n_kv * r_vo, d), lin(d, n_h * r_vo))
         ad.replace_mlp_layers(i, lin(r_mlp, d), lin(d, r_mlp), None if kind == "opt" else lin(r_mlp, d))
         idx = torch.stack([torch.randperm(hd // 2, generator=g)[:r_qk // 2] for _ in range(n_kv)])
@@ -95,9 +98,46 @@ def cuda_means_cpu_for_load():
         torch.load = real
 
 
+@contextlib.contextmanager
+def transformers_4x_names():
+    """The reference's modeling files were written against transformers 4.5x; this image has 5.x, where two names they look up
+    moved.  For the duration of the load the LIBRARY'S OWN objects are registered under the old names -- nothing of the
+    reference is edited, nothing is re-implemented:
+      * ROPE_INIT_FUNCTIONS["default"] (LlamaRebuild.py:86) -> LlamaRotaryEmbedding.compute_default_rope_parameters, the
+        function 5.x calls for the default rope type instead of a registry entry."""
+    from transformers import modeling_rope_utils as mru
+    from transformers.models.llama.modeling_llama import LlamaRotaryEmbedding
+    added = "default" not in mru.ROPE_INIT_FUNCTIONS
+    if added:
+        mru.ROPE_INIT_FUNCTIONS["default"] = LlamaRotaryEmbedding.compute_default_rope_parameters
+    try:
+        yield ["ROPE_INIT_FUNCTIONS['default'] -> LlamaRotaryEmbedding.compute_default_rope_parameters"] if added else []
+    finally:
+        if added:
+            del mru.ROPE_INIT_FUNCTIONS["default"]
+
+
 def forward_logits(model, ids):
     with torch.no_grad():
         return model(input_ids=ids).logits.float()
+
+
+def forward_through_layers(model, ids):
+    """Logits of a Llama / Qwen3 style model by driving its OWN modules in order -- embedding, rotary table, every decoder layer
+    with an explicit additive causal mask, final norm, lm_head.  Used for the reference's classes, whose model-level forward
+    calls transformers' mask builder with a 4.x keyword (create_causal_mask(input_embeds=...)); everything specific to a
+    compressed checkpoint -- per-layer widths, the rotary-mask gather, the softmax scale -- lives in the layers driven here."""
+    core = model.model
+    with torch.no_grad():
+        h = core.embed_tokens(ids)
+        B, T = ids.shape
+        pos = torch.arange(T)[None].expand(B, T)
+        cos_sin = core.rotary_emb(h, pos)
+        mask = torch.full((T, T), torch.finfo(h.dtype).min, dtype=h.dtype).triu(1)[None, None]
+        for layer in core.layers:
+            out = layer(h, attention_mask=mask, position_ids=pos, position_embeddings=cos_sin)
+            h = out[0] if isinstance(out, tuple) else out
+        return model.lm_head(core.norm(h)).float()
 
 
 def main():
@@ -123,13 +163,14 @@ def main():
             # (A) this engine's shipped modeling file, torch path on the CPU
             mine = transformers.AutoModelForCausalLM.from_pretrained(out, trust_remote_code=True, dtype=torch.bfloat16).eval()
             logits_mine = forward_logits(mine, ids)
+            logits_mine_layers = None
             # (B) the reference's modeling file in its place
             ref_file = os.path.join(a.ref, "src", "patchers", KINDS[kind])
             shutil.copy(ref_file, os.path.join(out, KINDS[kind]))
             os.remove(os.path.join(out, "compressed_attention.py"))
             status = "loaded"
             try:
-                with cuda_means_cpu_for_load():
+                with cuda_means_cpu_for_load(), transformers_4x_names() as shims:
                     # a distinct module name per load: HF caches dynamic modules by directory name
                     refdir = os.path.join(tmp, "model_ref")
                     shutil.copytree(out, refdir)
@@ -137,16 +178,54 @@ def main():
                     if refcfg.get("mask_path"):
                         refcfg["mask_path"] = os.path.join(refdir, "rotary_masks.pt")
                         json.dump(refcfg, open(os.path.join(refdir, "config.json"), "w"))
-                    ref = transformers.AutoModelForCausalLM.from_pretrained(refdir, trust_remote_code=True,
-                                                                            dtype=torch.bfloat16).eval()
+                    # The class config.auto_map names, resolved the way from_pretrained resolves it; then constructed and
+                    # filled directly.  (from_pretrained itself goes on to re-initialise "missing" non-persistent buffers
+                    # through transformers-5 hooks -- module.compute_default_rope_parameters -- that a 4.x-era modeling file
+                    # does not have; constructing the class and loading the state dict is the same model without that step.)
+                    from transformers.dynamic_module_utils import get_class_from_dynamic_module
+                    rconf = transformers.AutoConfig.from_pretrained(refdir, trust_remote_code=True)
+                    cls = get_class_from_dynamic_module(rconf.auto_map["AutoModelForCausalLM"], refdir)
+                    # built on the meta device (transformers 5 runs no weight initialisers there -- its initialiser for
+                    # rotary modules calls a 5.x-only method), materialised empty, filled from the checkpoint; the rotary
+                    # module, whose inv_freq is a computed non-persistent buffer, is constructed again on the CPU
+                    with torch.device("meta"):
+                        ref = cls(rconf)
+                    ref = ref.to_empty(device="cpu").to(torch.bfloat16).eval()
+                    core = ref.model.decoder if kind == "opt" else ref.model
+                    if hasattr(core, "rotary_emb"):
+                        core.rotary_emb = type(core.rotary_emb)(rconf)
+                    from safetensors.torch import load_file
+                    wfile = [f for f in os.listdir(refdir) if f.endswith(".safetensors") or f.endswith(".bin")]
+                    sd = {}
+                    for f in wfile:
+                        sd.update(load_file(os.path.join(refdir, f)) if f.endswith(".safetensors")
+                                  else torch.load(os.path.join(refdir, f), map_location="cpu"))
+                    res = ref.load_state_dict(sd, strict=False)
+                    unexpected = list(res.unexpected_keys)
+                    missing_persistent = [k for k in res.missing_keys if "lm_head" not in k]   # lm_head is tied to the embedding
+                    assert not unexpected and not missing_persistent, (unexpected[:4], missing_persistent[:4])
+                    if hasattr(ref, "tie_weights"):
+                        ref.tie_weights()
                 assert type(ref).__module__.endswith(KINDS[kind][:-3])
                 rs = ref.state_dict()
                 missing = [k for k in state if k not in rs]
                 assert not missing, f"reference model lacks {missing[:4]}"
                 for k, v in state.items():
                     assert rs[k].shape == v.shape and torch.equal(rs[k], v), k
-                logits_ref = forward_logits(ref, ids)
+                ref.config._attn_implementation = "eager"
+                if kind == "opt":
+                    logits_ref = forward_logits(ref, ids)
+                else:
+                    logits_ref = forward_through_layers(ref, ids)
+                    mine.config._attn_implementation = "eager"
+                    logits_mine_layers = forward_through_layers(mine, ids)
+                    d2 = (logits_mine_layers - logits_mine).abs().max().item()
+                    d3 = (logits_mine_layers - logits_ref).abs().max().item()
+                    print(f"[{kind}] this engine's model: layer-by-layer drive (eager attention) vs its model-level forward (sdpa): "
+                          f"max |diff| = {d2:.3e};  layer-by-layer drive, this engine's modules vs the reference's: {d3:.3e}")
             except Exception as exc:  # recorded, not hidden: the fixture says what the reference's file did with the checkpoint
+                import traceback
+                traceback.print_exc()
                 status = f"reference modeling file failed: {type(exc).__name__}: {str(exc)[:300]}"
                 logits_ref = None
             print(f"[{kind}] reference {KINDS[kind]}: {status}")
@@ -154,7 +233,8 @@ def main():
                 d = (logits_mine - logits_ref).abs().max().item()
                 print(f"[{kind}] logits through this engine's modeling file vs the reference's: max |diff| = {d:.3e} "
                       f"(max |logit| = {logits_ref.abs().max().item():.3f})")
-        fx = {"meta_kind": np.array(kind), "meta_status": np.array(status), "config_json": np.array(json.dumps(cfg_json)),
+        fx = {"meta_kind": np.array(kind), "meta_status": np.array(status), "meta_shims": np.array("; ".join(shims)),
+              "meta_transformers": np.array(transformers.__version__), "config_json": np.array(json.dumps(cfg_json)),
               "input_ids": ids.numpy(), "n_masks": np.array(len(masks) if kind != "opt" else 0)}
         for i, m in enumerate(masks if kind != "opt" else []):
             fx[f"mask_{i}"] = m.numpy()
@@ -163,7 +243,9 @@ def main():
             fx["dtype:" + k] = np.array(str(v.dtype))
         if logits_ref is not None:
             fx["logits_reference"] = logits_ref.numpy()
-        fx["logits_engine_torch_path"] = logits_mine.numpy()
+        fx["logits_engine_torch_path"] = logits_mine.numpy()          # model-level forward (sdpa), this engine's modeling file, CPU
+        if kind != "opt":
+            fx["logits_engine_layers"] = logits_mine_layers.numpy()  # layer-by-layer drive (eager attention), same file
         np.savez_compressed(os.path.join(a.out, f"ckpt_{kind}.npz"), **fx)
 
 

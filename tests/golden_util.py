@@ -75,3 +75,55 @@ class RopeCase:
         self.has_norm = f"{name}_norm_w" in z.files
         if self.has_norm:
             self.norm_w, self.nq, self.nk = t("norm_w"), t("nq"), t("nk")
+
+
+# ---------------------------------------------------------------- compressed checkpoints (oracle/gen_checkpoint_golden.py)
+CKPT_KINDS = {"llama": "LlamaRebuild.py", "qwen3": "DenseQwenRebuild.py", "opt": "OPTRebuild.py"}
+
+
+def materialise_checkpoint(kind: str, dst: str):
+    """Rebuild the checkpoint directory of tests/golden/ckpt_<kind>.npz under `dst` exactly as save_compressed_model lays it
+    out (config.json with an absolute mask_path, weights, rotary_masks.pt, the architecture's *Rebuild.py and the
+    compressed_attention.py it imports).  Returns (directory, input_ids, fixture)."""
+    import json
+    import shutil
+    from safetensors.torch import save_file
+    z = np.load(os.path.join(GOLDEN_DIR, f"ckpt_{kind}.npz"))
+    os.makedirs(dst, exist_ok=True)
+    cfg = json.loads(str(z["config_json"]))
+    masks = [torch.from_numpy(z[f"mask_{i}"]) for i in range(int(z["n_masks"]))]
+    if masks:
+        cfg["mask_path"] = os.path.abspath(os.path.join(dst, "rotary_masks.pt"))
+        torch.save(masks, cfg["mask_path"])
+    with open(os.path.join(dst, "config.json"), "w") as f:
+        json.dump(cfg, f)
+    state = {}
+    for key in z.files:
+        if key.startswith("w:"):
+            a = z[key]
+            state[key[2:]] = bf16_from_bits(a).clone() if str(z["dtype:" + key[2:]]) == "torch.bfloat16" else torch.from_numpy(a).clone()
+    save_file(state, os.path.join(dst, "model.safetensors"), metadata={"format": "pt"})
+    patchers = os.path.join(os.path.dirname(GOLDEN_DIR), os.pardir, "modegpt_amd", "patchers")
+    for fname in (CKPT_KINDS[kind], "compressed_attention.py"):
+        shutil.copy(os.path.join(patchers, fname), dst)
+    return dst, torch.from_numpy(z["input_ids"]), z
+
+
+LAYER_DRIVE = '''
+def layer_drive(model, ids):
+    """Logits by driving the model's own modules in order with an explicit additive causal mask (what the fixture's
+    reference logits were produced with: oracle/gen_checkpoint_golden.py forward_through_layers)."""
+    import torch
+    core = model.model
+    with torch.no_grad():
+        h = core.embed_tokens(ids)
+        B, T = ids.shape
+        pos = torch.arange(T, device=ids.device)[None].expand(B, T)
+        cos_sin = core.rotary_emb(h, pos)
+        mask = torch.full((T, T), torch.finfo(h.dtype).min, dtype=h.dtype, device=ids.device).triu(1)[None, None]
+        for layer in core.layers:
+            out = layer(h, attention_mask=mask, position_ids=pos, position_embeddings=cos_sin)
+            h = out[0] if isinstance(out, tuple) else out
+        return model.lm_head(core.norm(h)).float()
+'''
+exec(LAYER_DRIVE)

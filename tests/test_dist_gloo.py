@@ -34,7 +34,7 @@ def _layer(i):
     return t, torch.arange(r).reshape(1, r) + i
 
 
-N_LAYERS = 5      # over 2 ranks: 3 + 2 (ragged)
+N_LAYERS = 15     # three chunks of 5 layers; each chunk over 2 ranks: 3 + 2 (ragged)
 
 
 def _worker(rank, world, port, tmp):
@@ -87,26 +87,29 @@ def _worker(rank, world, port, tmp):
     real_write = S._write_artifact
     S._write_artifact = lambda d, layer, suffix, w: (written.append((layer, suffix)), real_write(d, layer, suffix, w))[1]
 
-    chunk = list(range(N_LAYERS))
-    mine = S.my_layers(chunk, rank, world)
-    assert mine == ([0, 1, 2] if rank == 0 else [3, 4])
-    for rep in range(3):                              # several chunks back to back: ordering must hold every time
+    foreign = []
+    for first in range(0, N_LAYERS, 5):               # run_modegpt's loop over chunks (LAYERS_PER_STEP there), back to back
+        chunk = list(range(first, first + 5))
+        mine = S.my_layers(chunk, rank, world)
+        assert mine == (chunk[:3] if rank == 0 else chunk[3:])
         all_masks = R.compress_chunk(ad, ad.config, chunk, rank, world)
         assert calibrated[-1] == mine                 # hooks only for this rank's layers
-        assert len(all_masks) == N_LAYERS
-        for i in chunk:
-            assert torch.equal(all_masks[i], _layer(i)[1])
+        assert len(all_masks) == 5
+        for pos, i in enumerate(chunk):
+            assert torch.equal(all_masks[pos], _layer(i)[1])
+        foreign += [i for i in chunk if i not in mine]
         if rank == 0:
-            # what convert_model does next, with NO barrier in between: every layer's three files must be whole and right
+            # what convert_model does with the artefacts, with NO barrier in between (rank 1 is already in its next chunk):
+            # every layer's three files must be whole and right
             for i in chunk:
                 got = {}
                 for suffix in ("mlp", "qk", "vo"):
                     got.update(torch.load(os.path.join(shared, f"layer_{i}_{suffix}")))
                 for k, v in _layer(i)[0].items():
-                    assert torch.equal(got[k], v), (rep, i, k)
+                    assert torch.equal(got[k], v), (i, k)
     # only the consumer wrote artefacts it does not own; the others wrote nothing beyond their own layers
     if rank == 0:
-        assert sorted(set(written)) == sorted((i, s) for i in (3, 4) for s in ("mlp", "qk", "vo")) and len(written) == 3 * 6
+        assert sorted(written) == sorted((i, s) for i in foreign for s in ("mlp", "qk", "vo"))
     else:
         assert written == []
     assert not [f for f in os.listdir(shared) if ".tmp" in f]

@@ -690,3 +690,26 @@ def test_run_modegpt_main_on_a_local_fp16_opt_checkpoint(dev, tmp_path, monkeypa
     assert (out / "OPTRebuild.py").exists()
     art = torch.load(tmp_path / "out" / "layers" / "layer_0_mlp")
     assert set(art) == {"up", "down"} and art["up"].dtype == torch.bfloat16
+
+
+@pytest.mark.parametrize("kind", ["llama", "qwen3"])
+def test_fixture_checkpoint_through_the_hip_kernel_matches_the_reference_modeling(dev, kind, tmp_path, monkeypatch):
+    """The checkpoint of tests/golden/ckpt_<kind>.npz (written by this engine's writer; loaded and run through the REFERENCE's
+    LlamaRebuild.py / DenseQwenRebuild.py when the fixture was made) on the GPU: the shipped modeling file now takes the fused
+    HIP kernel for the rotary / masked-norm chain (PATH_CALLS proves it), and the logits must agree with the reference
+    modeling's.  Tolerance: the rotation is bit-identical to the reference's expression and the masked norm differs by <= 1 ulp
+    of bf16 on < 1 % of elements; the matmuls around it run on the GPU's bf16 GEMMs instead of the CPU's,
+    which is what the 3e-2 (of the largest logit) allows for."""
+    transformers = pytest.importorskip("transformers")
+    import sys
+    from tests.golden_util import layer_drive, materialise_checkpoint
+    monkeypatch.setenv("HF_MODULES_CACHE", str(tmp_path / "hf_modules"))
+    monkeypatch.setenv("MODEGPT_REQUIRE_HIP", "1")           # a silent torch fallback on the GPU box must fail, not pass
+    out, ids, z = materialise_checkpoint(kind, str(tmp_path / "model"))
+    m = transformers.AutoModelForCausalLM.from_pretrained(out, trust_remote_code=True, dtype=torch.bfloat16).to(dev).eval()
+    m.config._attn_implementation = "eager"
+    got = layer_drive(m, ids.to(dev)).cpu().numpy()
+    mod = sys.modules[type(m).__module__.rsplit(".", 1)[0] + ".compressed_attention"]
+    assert mod.PATH_CALLS["hip"] >= 2 * m.config.num_hidden_layers and mod.PATH_CALLS["torch"] == 0, mod.PATH_CALLS
+    want = z["logits_reference"]
+    assert np.abs(got - want).max() <= 3e-2 * np.abs(want).max(), float(np.abs(got - want).max())
