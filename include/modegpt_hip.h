@@ -27,7 +27,8 @@ extern "C" {
 #endif
 
 #define MDG_ABI_VERSION 4 /* 2: w_dtype on mdg_nystrom_down / mdg_vo_compress, mdg_rope_gather added; 3: mdg_cov_accum_i8_stats added;
-                             4: mdg_cov_accum_i8 chooses its route on the device (route_counts argument, no host synchronisation) */
+                             4: mdg_cov_accum_i8 chooses its route on the device (route_counts argument, no host synchronisation);
+                                mdg_comm_* / mdg_allgather_layers added */
 
 enum mdg_status {
   MDG_OK = 0,
@@ -229,6 +230,22 @@ int mdg_sqrt_psd_large(const double* M, int64_t n, int64_t ld, double ridge, int
 int mdg_rope_gather(const void* x, int dtype, int64_t ld_x, int64_t B, int64_t T, int n_heads, int n_kv, int r, int hd,
                     const void* cos, const void* sin, int64_t cs_batch_stride, const int64_t* mask,
                     const void* norm_w, double eps, void* out, void* stream);
+
+/* ------------------------------------------------------------------ multi-GPU (the reference is single-process,
+ * its unit of independent work is the layer loop of src/run_modegpt.py:107-156)
+ * Layers shard over the GPUs of a node, one process per GPU, no data-path exchange until the end: ONE all-gather of the
+ * ranks' packed per-layer records (modegpt_amd/sharding.py documents the record: header with shapes, rotary mask, bf16
+ * payload; every rank pads to the same bytes_per_rank).  This engine's driver runs that step through torch.distributed
+ * (backend "nccl" = RCCL over xGMI); the entry points below are the same step for a host without torch.  RCCL is resolved
+ * with dlopen("librccl.so.1") on first use -- no link-time dependency.
+ *   mdg_comm_unique_id   rank 0 fills id128 (128 bytes) and hands it to the other ranks by the host's own means (file, env, MPI)
+ *   mdg_comm_init        every rank, after hipSetDevice(its GPU): *comm receives the communicator
+ *   mdg_allgather_layers recv[r * bytes_per_rank ...] = rank r's send buffer, for every r; device pointers; enqueued on `stream`
+ *   mdg_comm_destroy     releases the communicator (NULL is accepted) */
+int mdg_comm_unique_id(void* id128);
+int mdg_comm_init(void** comm, int world, int rank, const void* id128);
+int mdg_allgather_layers(const void* send, void* recv, size_t bytes_per_rank, void* comm, void* stream);
+int mdg_comm_destroy(void* comm);
 
 /* ------------------------------------------------------------------ utilities
  * out_bf16[j, i] = bf16(in_f64[i, j])  (transpose + cast with torch's double->float->bf16 rounding) */

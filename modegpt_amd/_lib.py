@@ -69,6 +69,10 @@ SIGNATURES = {
     "mdg_sqrt_psd_large": (_i32, [_ptr, _i64, _i64, _f64, _i32, _ptr, _ptr, _ptr, _ptr, _sz, _ptr]),
     "mdg_rope_gather": (_i32, [_ptr, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _ptr, _ptr, _i64, _ptr, _ptr, _f64,
                                 _ptr, _ptr]),
+    "mdg_comm_unique_id": (_i32, [_ptr]),
+    "mdg_comm_init": (_i32, [C.POINTER(_ptr), _i32, _i32, _ptr]),
+    "mdg_allgather_layers": (_i32, [_ptr, _ptr, _sz, _ptr, _ptr]),
+    "mdg_comm_destroy": (_i32, [_ptr]),
     "mdg_cast_transpose_f64_bf16": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _i64, _ptr]),
     "mdg_probe_mfma_f64": (_i32, [_i32, C.POINTER(_f64), _ptr]),
 }

@@ -294,11 +294,6 @@ constexpr int STAMP_WGS = 1024;
 #define MDG_STAMP(x)
 #endif
 
-__device__ __forceinline__ void glds16(const void* g, void* l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16,
-                                   0, 0);
-}
-
 // Shape and LDS ring per route.  One workgroup of 8 waves per CU (two waves per SIMD, <= 256 registers each).
 //   P = 5: 128 x 128 tile, wave tile 64 x 32 (160 accumulators), stages of 40 KB -- 40 KB of L2 -> LDS traffic per k-step for
 //          16384 outputs where two 128 x 64 tiles move 60 KB.  Ring of 3 stages, filled two k-steps ahead.
@@ -456,7 +451,7 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
       const unsigned present = ((unsigned)(m64 >> pc_shift[q]) & pc_cmask[q]) | pc_force[q];
       if (present)   // (an all-zero piece is not loaded: nothing will read it)
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lbase + pc_loff[q]), "v"(voff), "s"(pc_base[q])
-                     : "memory", "m0");
+                     : "memory");   // (M0 is written; nothing the compiler emits in this kernel reads it)
     }
   };
 

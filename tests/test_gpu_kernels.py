@@ -750,3 +750,30 @@ def test_cov_i8_zero_plane_skipping_is_exact(ops, dev):
     d6 = torch.sqrt(torch.diag(R6))
     low6 = torch.tril(torch.ones(256, 256, dtype=torch.bool, device=dev))
     assert (((S6 - R6).abs() / (d6[:, None] * d6[None]))[low6]).max().item() < 1e-12
+
+
+# ---------------------------------------------------------------- the collective behind the C ABI
+def test_allgather_layers_through_the_c_abi(dev):
+    """mdg_comm_unique_id / mdg_comm_init / mdg_allgather_layers / mdg_comm_destroy (RCCL resolved with dlopen) on a
+    one-rank communicator: the gathered buffer equals the sent one, on the caller's stream; bad arguments are refused with a
+    status, not a crash.  (The N > 1 arithmetic of the same step -- padding, record layout, order -- is covered on CPU over gloo
+    in tests/test_dist_gloo.py; more than one GPU is the driver's to run.)"""
+    import ctypes as C
+    from modegpt_amd import _lib
+    lib = _lib.load()
+    uid = (C.c_char * 128)()
+    _lib.check(lib.mdg_comm_unique_id(uid), "mdg_comm_unique_id")
+    comm = C.c_void_p(None)
+    with torch.cuda.device(dev):
+        _lib.check(lib.mdg_comm_init(C.byref(comm), 1, 0, uid), "mdg_comm_init")
+        assert comm.value
+        send = torch.randint(0, 255, (3 * 1024 * 1024 + 5,), dtype=torch.uint8, device=dev)
+        recv = torch.zeros_like(send)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.mdg_allgather_layers(send.data_ptr(), recv.data_ptr(), send.numel(), comm, st), "mdg_allgather_layers")
+        torch.cuda.synchronize()
+        assert torch.equal(send, recv)
+        assert lib.mdg_allgather_layers(None, recv.data_ptr(), 16, comm, st) == _lib.MDG_ERR_BAD_ARG
+        assert lib.mdg_comm_init(C.byref(C.c_void_p(None)), 2, 5, uid) == _lib.MDG_ERR_BAD_ARG
+        _lib.check(lib.mdg_comm_destroy(comm), "mdg_comm_destroy")
+        assert lib.mdg_comm_destroy(None) == _lib.MDG_OK
