@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 R=$PWD
 OUT=$R/gpurun_out/benchprof
 rm -rf $OUT
-timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT -o p -- python3 bench.py > $R/gpurun_out/bench_under_rocprof.log 2>&1 || exit 1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT -o p -- python3 bench.py --no-cpu-baseline > $R/gpurun_out/bench_under_rocprof.log 2>&1 || exit 1
 DB=$(ls $OUT/*.db | head -1)
 python3 scripts/rocpd_summary.py $DB > $R/gpurun_out/bench_kernel_trace_stats.csv || exit 1
 python3 scripts/rocpd_summary.py $DB bygrid > $R/gpurun_out/bench_kernel_trace_bygrid.csv || exit 1

@@ -1,25 +1,32 @@
 """Summarise a rocprofv3 rocpd .db: per-kernel dispatch stats (and PMC counter sums if present) as CSV on stdout.
-With a second argument `bygrid`, kernels are additionally split by their grid size (one row per launch shape)."""
+With a second argument `bygrid`, kernels are additionally split by their grid size (one row per launch shape) and by whether
+the launch did work: mdg_cov_accum_i8 enqueues the five-plane product, the six-plane product and the fp64 kernel for every
+call and the device picks one -- the other launches exit on their first instruction (a few microseconds).  Dispatches shorter
+than GATE_MS are listed as `gated_out` rows so that the averages of the launches that ran are not diluted."""
 import sqlite3
 import sys
 
 db = sqlite3.connect(sys.argv[1])
 cur = db.cursor()
 BYGRID = len(sys.argv) > 2 and sys.argv[2] == "bygrid"
+GATE_MS = 0.03
+GATED = "(s.kernel_name like '%i8_syrk_kernel%' or s.kernel_name like '%cov_accum_kernel%') and (d.end-d.start) < %d" % int(GATE_MS * 1e6)
 if BYGRID:
-    print("kernel,grid_x,calls,avg_ms,min_ms,max_ms")
-    for r in cur.execute("""select s.kernel_name, d.grid_size_x, count(*), avg(d.end-d.start)/1e6, min(d.end-d.start)/1e6,
-            max(d.end-d.start)/1e6 from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id=s.id
-            group by 1, 2 order by 4 desc"""):
-        print('"%s",%d,%d,%.4f,%.4f,%.4f' % r)
+    print("kernel,grid_x,class,calls,avg_ms,min_ms,max_ms")
+    for r in cur.execute("""select s.kernel_name, d.grid_size_x, case when %s then 'gated_out' else 'ran' end, count(*),
+            avg(d.end-d.start)/1e6, min(d.end-d.start)/1e6, max(d.end-d.start)/1e6
+            from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id=s.id
+            group by 1, 2, 3 order by 5 desc""" % GATED):
+        print('"%s",%d,%s,%d,%.4f,%.4f,%.4f' % r)
     try:
-        rows = list(cur.execute("""select s.kernel_name, d.grid_size_x, p.name, count(distinct d.id), sum(e.value) / count(distinct d.id)
+        rows = list(cur.execute("""select s.kernel_name, d.grid_size_x, case when %s then 'gated_out' else 'ran' end, p.name,
+            count(distinct d.id), sum(e.value) / count(distinct d.id)
             from rocpd_pmc_event e join rocpd_info_pmc p on e.pmc_id=p.id join rocpd_kernel_dispatch d on e.event_id=d.event_id
-            join rocpd_info_kernel_symbol s on d.kernel_id=s.id group by 1, 2, 3 order by 1, 2, 3"""))
+            join rocpd_info_kernel_symbol s on d.kernel_id=s.id group by 1, 2, 3, 4 order by 1, 2, 3, 4""" % GATED))
         if rows:
-            print("\nkernel,grid_x,counter,dispatches,sum_per_dispatch")
+            print("\nkernel,grid_x,class,counter,dispatches,sum_per_dispatch")
             for r in rows:
-                print('"%s",%d,%s,%d,%.6g' % r)
+                print('"%s",%d,%s,%s,%d,%.6g' % r)
     except sqlite3.Error as e:
         print("# no pmc tables:", e)
     sys.exit(0)

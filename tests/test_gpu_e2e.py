@@ -447,10 +447,12 @@ def test_opt_compressed_forward_runs(dev, tmp_path):
     assert out.shape[:2] == (2, 32) and bool(torch.isfinite(out.float()).all())
 
 
-@pytest.mark.parametrize("name,keep", [("qwen3-14b", 0.7), ("llama-2-7b", 0.7)])
+@pytest.mark.parametrize("name,keep", [("qwen3-14b", 0.7), ("llama-2-7b", 0.7), ("llama-3-8b", 0.6)])
 def test_other_baseline_shapes_one_layer(dev, name, keep):
     """BASELINE configs #2 / #5 at their real layer shapes (d = 5120 / d_ff = 17408; the MHA two-SVD VO path with
-    32 kv heads), 16384 calibration tokens: the drop-in functions run and satisfy the size-independent invariants."""
+    32 kv heads) and config #4's keep ratio 0.6 at Llama-3-8B size (ranks 8601 / 76), 16384 calibration tokens: the drop-in
+    functions run and satisfy the size-independent invariants; for config #4 the MLP index set and the QK mask are also
+    compared with the oracle's (CPU Cholesky + cholesky_inverse of the 14336^2 statistic: seconds)."""
     from modegpt_amd import engine, ops
     shape = dict(engine.SHAPES[name])
     w = engine.make_layer_weights(shape, 7, dev)
@@ -462,7 +464,8 @@ def test_other_baseline_shapes_one_layer(dev, name, keep):
     assert torch.equal(covs["mlp"], covs["mlp"].T)
     out, mask = engine.compress_layer(ad, 0, covs, keep)
     f, d, nh, nkv, hd = shape["d_ff"], shape["d"], shape["n_heads"], shape["n_kv_heads"], shape["head_dim"]
-    r_mlp, r = int(f * keep), 88
+    r_mlp, r = int(f * keep), O.qk_rank(hd, keep, shape["arch"])
+    assert r == {0.7: 88, 0.6: 76}[keep] and r == O.vo_rank(hd, keep, shape["arch"])
     assert out["up"].shape == (r_mlp, d) and out["gate"].shape == (r_mlp, d) and out["down"].shape == (d, r_mlp)
     assert out["q_proj"].shape == (nh * r, d) and out["k_proj"].shape == (nkv * r, d)
     assert out["v_proj"].shape == (nkv * r, d) and out["o_proj"].shape == (d, nh * r)
@@ -481,6 +484,12 @@ def test_other_baseline_shapes_one_layer(dev, name, keep):
         assert (G - torch.eye(r, dtype=F64, device=dev)).abs().max().item() < 0.1
     for t in out.values():
         assert bool(torch.isfinite(t.float()).all())
+    if name == "llama-3-8b":   # config #4 against the oracle: selections must be identical at rank 8601 / 76
+        assert r_mlp == 8601
+        sc = O.ridge_scores(covs["mlp"].cpu(), 1e-4)
+        assert torch.equal(O.mlp_select(sc, r_mlp), idx.cpu())
+        _, omask = O.compress_qk_layer(w["q"].cpu(), w["k"].cpu(), covs["q"].cpu(), covs["k"].cpu(), nh, nkv, hd, r, shape["arch"], 1e-2)
+        assert torch.equal(omask, mask.cpu())
 
 
 def test_run_modegpt_main_on_local_checkpoint(dev, tmp_path, monkeypatch):
