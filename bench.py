@@ -546,6 +546,14 @@ def main():
         sc = ops.ridge_scores(covs["mlp"], _fl32(ridges["nystrom_ridge"]))
         gpu_out["mlp_idx"] = ops.select_smallest_sorted(sc, int(shape["d_ff"] * a.keep))
         out["roofline"]["measured_mfma_f64_issue_rate_tflops"] = ops.probe_mfma_f64(4096)
+        if i8:
+            zero, rnd = ops.probe_mfma_i8(random_operands=False), ops.probe_mfma_i8(random_operands=True)
+            out["roofline"]["measured_i8_mfma_rate_tops"] = {
+                "zero_operands": zero, "random_operands": rnd,
+                "frac_of_random_operand_rate": out["roofline"]["achieved"] / rnd,
+                "what": "mdg_probe_mfma_i8: v_mfma_i32_32x32x32_i8 back to back from registers (no LDS, no memory), two waves per "
+                        "SIMD on every CU, operands changing every MFMA.  With random bytes the board is at its power cap and the "
+                        "clock gives way: that rate, not the nominal `peak`, is the ceiling of any int8 kernel on random data"}
         h = batches[0]["h"]
         if i8:  # the same sigma_mlp batch through the v_mfma_f64 kernel, for the record, and the two routes against each other
             scratch = torch.zeros_like(covs["mlp"])

@@ -254,6 +254,12 @@ int mdg_cast_transpose_f64_bf16(const double* in, int64_t rows, int64_t cols, in
 /* Raw fp64 MFMA issue-rate probe used by bench.py to state the measured peak next to the spec:
  * returns TFLOP/s over `iters` back-to-back v_mfma_f64_16x16x4_f64 per wave on every CU.  SYNCHRONISES. */
 int mdg_probe_mfma_f64(int iters, double* tflops, void* stream);
+/* The same for the int8 pipe: TOP/s of back-to-back v_mfma_i32_32x32x32_i8 from registers, two waves per SIMD on every CU, the
+ * operands changing from one MFMA to the next -- all zero (random_operands = 0: nothing toggles, the pipe runs at full clock,
+ * ~0.97 of the 5 POP/s nominal peak) or random bytes (random_operands = 1: the board sits at its power cap and the clock
+ * gives way, ~0.68 of nominal on an MI355X -- the ceiling of ANY int8 kernel on random data, before a single byte is loaded).
+ * bench.py states both next to the kernel's achieved rate.  SYNCHRONISES. */
+int mdg_probe_mfma_i8(int iters, int random_operands, double* tops, void* stream);
 
 #ifdef __cplusplus
 }

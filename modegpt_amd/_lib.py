@@ -75,6 +75,7 @@ SIGNATURES = {
     "mdg_comm_destroy": (_i32, [_ptr]),
     "mdg_cast_transpose_f64_bf16": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _i64, _ptr]),
     "mdg_probe_mfma_f64": (_i32, [_i32, C.POINTER(_f64), _ptr]),
+    "mdg_probe_mfma_i8": (_i32, [_i32, _i32, C.POINTER(_f64), _ptr]),
 }
 
 _lib = None

@@ -30,6 +30,38 @@ __global__ __launch_bounds__(256, 2) void probe_mfma_f64_kernel(int iters, doubl
   if (s == 123.456) sink[0] = s;  // keep the chain alive without a store on the normal path
 }
 
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+// v_mfma_i32_32x32x32_i8 back to back from registers, the two operands CHANGING from one MFMA to the next (four A and four B
+// registers per lane in rotation; random bytes or all zero).  No LDS, no memory: what the matrix pipes and the register file
+// alone sustain -- with changing random operands well under the nominal rate, because the board is at its power cap.
+__global__ __launch_bounds__(256, 2) void probe_mfma_i8_kernel(int iters, int random, int* sink) {
+  i32x4 a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      unsigned s = (blockIdx.x * 256 + threadIdx.x) * 64 + i * 8 + j, t;
+      s ^= s >> 16; s *= 0x7feb352du; s ^= s >> 15; s *= 0x846ca68bu; s ^= s >> 16;
+      t = s * 0x9e3779b1u + 0x85ebca6bu; t ^= t >> 13;
+      a[i][j] = random ? (int)s : 0;
+      b[i][j] = random ? (int)t : 0;
+    }
+  i32x16 c[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) c[i] = (i32x16)0;
+  for (int it = 0; it < iters; it++)
+#pragma unroll
+    for (int i = 0; i < 8; i++) c[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i & 3], b[(i + (i >> 2)) & 3], c[i], 0, 0, 0);
+  int x = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) x ^= c[i][r];
+  if (x == 0x12345678) sink[0] = x;
+}
+
 }  // namespace mdg
 
 using namespace mdg;
@@ -81,6 +113,34 @@ extern "C" int mdg_probe_mfma_f64(int iters, double* tflops, void* stream) {
   }
   const double flop = (double)blocks * 4 /*waves*/ * (double)iters * 16 * (2.0 * 16 * 16 * 4);
   *tflops = flop / (ms * 1e-3) / 1e12;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(sink);
+  return MDG_OK;
+}
+
+extern "C" int mdg_probe_mfma_i8(int iters, int random_operands, double* tops, void* stream) {
+  MDG_CLEAR();
+  MDG_CHECK_ARG(iters > 0 && tops, "mdg_probe_mfma_i8: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  int dev = 0, n_cu = 0;
+  MDG_HIP(hipGetDevice(&dev));
+  MDG_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  int* sink = nullptr;
+  MDG_HIP(hipMalloc((void**)&sink, 64));
+  hipEvent_t e0, e1;
+  MDG_HIP(hipEventCreate(&e0));
+  MDG_HIP(hipEventCreate(&e1));
+  const int blocks = n_cu * 2;  // 8 waves per CU = 2 per SIMD
+  hipLaunchKernelGGL(probe_mfma_i8_kernel, dim3(blocks), dim3(256), 0, st, iters / 4 + 1, random_operands, sink);  // warm: lets the clock settle
+  MDG_HIP(hipEventRecord(e0, st));
+  hipLaunchKernelGGL(probe_mfma_i8_kernel, dim3(blocks), dim3(256), 0, st, iters, random_operands, sink);
+  MDG_HIP(hipEventRecord(e1, st));
+  MDG_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  MDG_HIP(hipEventElapsedTime(&ms, e0, e1));
+  const double op = (double)blocks * 4 /*waves*/ * (double)iters * 8 * (2.0 * 32 * 32 * 32);
+  *tops = op / (ms * 1e-3) / 1e12;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   (void)hipFree(sink);

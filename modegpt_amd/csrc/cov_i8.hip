@@ -33,6 +33,12 @@
 //                      31 - 37 % of the MFMAs on Gaussian / SiLU-gated data.  The 4-wave shapes of
 //                      the first versions (128 x 64 tile, 64 x 32 wave tiles, 4-stage ring with counted waits) stay available
 //                      behind -DMDG_I8_WIDE5=0 / -DMDG_I8_WIDE6=0.
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
 #include "common.hpp"
 
 namespace mdg {
@@ -283,6 +289,9 @@ struct SyrkArgs {
   unsigned long long* mfma_count;      // += v_mfma instructions this launch executed (the dense count is known on the host)
   const int* route_flag;               // written by i8_depth_kernel: 0 -> five planes, 1 -> six planes, bit 1 set -> the fp64 kernel
   int* route_counts;                   // optional device counters [five planes, six planes, fp64 fallback], += 1 by the launch that runs
+  const int* sched;                    // persistent launch: [ngroups][32] tile codes (bi << 16 | bj, -1 = none); nullptr = one tile per workgroup
+  int ngroups;
+  int* xcd_arrive;                     // [8] arrival counters of the round barrier (zeroed per call)
 #ifdef MDG_I8_STAMPS
   unsigned long long* stamps;          // diagnostic build only: per (workgroup, wave) cycle sums of the k-step phases
 #endif
@@ -331,14 +340,25 @@ constexpr int STAMP_WGS = 1024;
 #ifndef MDG_I8_SB6
 #define MDG_I8_SB6 2
 #endif
+#ifndef MDG_I8_LOCKSTEP
+#define MDG_I8_LOCKSTEP 1           // persistent launch (one workgroup per CU, static tile lists) for statistics of at least ...
+#endif
+#ifndef MDG_I8_LOCKSTEP_BARRIER
+#define MDG_I8_LOCKSTEP_BARRIER 0   // 1: barrier of an XCD's workgroups between rounds (halves the L2 misses, 2-6 % slower)
+#endif
+#ifndef MDG_I8_LOCKSTEP_MIN_ROWS
+#define MDG_I8_LOCKSTEP_MIN_ROWS 64   // ... this many 128-row blocks (n >= 8192); smaller ones keep one tile per workgroup
+#endif
 #ifndef MDG_I8_ROLES
 #define MDG_I8_ROLES 1  // 0: every wave loads first (the lock-step order of the first versions)
 #endif
 constexpr int NW = 8;     // waves per workgroup
 constexpr int ring_depth(int planes) { return planes == 6 ? 4 : 3; }
 
-template <int P>  // planes used: 5 or 6
-__global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
+// One output tile (bi, bj) of the lower region: bi = 128-row block, bj = TJ-row block (bj <= bi for 128 x 128 tiles, bj <= 2 bi + 1
+// for 128 x 64); all k-steps, then the fold into sigma.  `executed` += the MFMAs this wave issued.
+template <int P>
+__device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const int bi, const int bj, unsigned char* lds, unsigned& executed) {
   constexpr int WB = P == 6 ? 1 : 2;               // 32-row blocks of a wave tile: 64 x 32, or 32 x 32 (96 accumulators at P = 6)
   constexpr int TJ = WB == 2 ? 128 : 64;           // tile columns (rows of the J operand); waves are laid out (128 / 32 WB) x (TJ / 32)
   constexpr int PB = TJ * KS;
@@ -349,52 +369,6 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
   constexpr bool SKIP = MDG_I8_SKIP_ZERO;
   constexpr int RING = ring_depth(P);              // LDS stages
   constexpr bool PREFETCH = P == 6;                // the next step's fragments are read before the barrier (needs RING = 4)
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  // The route is chosen on the DEVICE: mdg_cov_accum_i8 enqueues the five-plane product, the six-plane product and the fp64
-  // kernel back to back, and each exits at once unless the depth statistic of this call (i8_depth_kernel) selects it -- the
-  // host never waits for the flag.  The six-plane launch also books the fp64 fallback in the route counters.
-  {
-    const int route = *a.route_flag;
-    if (route != (P == 5 ? 0 : 1)) {
-      if (P == 6 && (route & 2) && a.route_counts && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.route_counts + 2, 1);
-      return;
-    }
-    if (a.route_counts && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.route_counts + (P == 5 ? 0 : 1), 1);
-  }
-  // Tile (bi, bj): bi = 128-row block, bj = TJ-row block of the lower region (bj <= bi for 128 x 128 tiles, bj <= 2 bi + 1 for
-  // 128 x 64).  XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2, so workgroup w belongs
-  // to XCD w % 8 and is the (w / 8)-th one there.  The tiles are grouped into super-blocks that are square in features
-  // (SI x SI tiles of 128 x 128, SI x 2 SI tiles of 128 x 64); a super-block lives on ONE XCD, so per k-step its tiles pull
-  // each distinct panel row through that L2 once.  Super-blocks (R, C), C <= R, cover the lower region; tiles of a diagonal
-  // super-block that lie above it exit at once.
-  int bi, bj;
-  constexpr int SI = P == 5 ? MDG_I8_SB5 : MDG_I8_SB6;   // super-block: SI x SI (or SI x 2 SI) tiles; 0 = plain row-major order
-  if (SI > 0) {
-    constexpr int TPS = TJ == 128 ? SI * SI : SI * 2 * SI;   // tiles per super-block
-    constexpr int SJ = TJ == 128 ? SI : 2 * SI;              // tile columns of a super-block
-    const int w = blockIdx.x;
-    const int q = w >> 3;
-    const int sb = q / TPS * 8 + (w & 7), t_in = q % TPS;
-    int R = (int)((sqrtf(8.f * sb + 1.f) - 1.f) * 0.5f);
-    while ((R + 1) * (R + 2) / 2 <= sb) R++;
-    while (R * (R + 1) / 2 > sb) R--;
-    const int C = sb - R * (R + 1) / 2;
-    bi = SI * R + t_in / SJ;
-    bj = SJ * C + t_in % SJ;
-  } else if (TJ == 128) {
-    const int tile = blockIdx.x;  // bi (bi + 1) / 2 tiles precede row bi
-    bi = (int)((sqrtf(8.f * tile + 1.f) - 1.f) * 0.5f);
-    while ((bi + 1) * (bi + 2) / 2 <= tile) bi++;
-    while (bi * (bi + 1) / 2 > tile) bi--;
-    bj = tile - bi * (bi + 1) / 2;
-  } else {
-    const int tile = blockIdx.x;  // bi (bi + 1) tiles precede row bi
-    bi = (int)((sqrtf(4.f * tile + 1.f) - 1.f) * 0.5f);
-    while ((bi + 1) * (bi + 2) <= tile) bi++;
-    while (bi * (bi + 1) > tile) bi--;
-    bj = tile - bi * (bi + 1);
-  }
-  if (bi >= a.n / TI || bj * TJ > bi * TI + TI - 1) return;
   // the wave index through readfirstlane: hipcc then knows it is wave-uniform and the staging code becomes scalar (SGPR piece
   // addresses, s_cbranch on the piece tests, M0 from SGPRs) instead of exec-masked branches with a v_readfirstlane per piece
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -430,7 +404,11 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
     const bool isA = p < GA * P;
     const int pp = isA ? p : p - GA * P;
     const int s = isA ? pp / GA : pp / GB, g = isA ? pp % GA : pp % GB;
+#ifdef MDG_I8_EXPERIMENT_SAME_PANEL   // (timing experiment, wrong results: every tile streams panel 0 -- all loads hit in L2)
+    const int64_t G = g;
+#else
     const int64_t G = (isA ? bi * (TI / 32) : bj * (TJ / 32)) + g;
+#endif
     const unsigned long long base = (unsigned long long)(uintptr_t)a.planes + (unsigned long long)((s * groups + G) * (int64_t)nk) * 1024ull;
     pc_base[q] = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(base >> 32)) << 32) |
                  (unsigned)__builtin_amdgcn_readfirstlane((unsigned)base);
@@ -518,7 +496,6 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
   unsigned mA[D + 1], mB[D + 1], vA = ~0u, vB = ~0u;
 #pragma unroll
   for (int i = 0; i <= D; i++) mA[i] = mB[i] = ~0u;
-  unsigned executed = 0;
   if (SKIP) {
 #pragma unroll
     for (int i = 0; i < D; i++)
@@ -656,7 +633,6 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
     }
     flush();
   }
-  if (a.mfma_count && lane == 0) atomicAdd(a.mfma_count, (unsigned long long)executed);
 #ifdef MDG_I8_STAMPS
   if (a.stamps && lane == 0 && blockIdx.x < STAMP_WGS) {
     unsigned long long t_end;
@@ -667,9 +643,169 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
 #endif
 }
 
+// Persistent launch (large statistics): 8 x 32 workgroups, one per CU, each working through a host-built list of tiles
+// (SyrkArgs::sched) instead of one tile per workgroup.  Workgroup b belongs to logical XCD b % 8 (what the dispatcher's
+// round-robin gives -- if it ever does not, only locality is lost) and is its slot b / 8.  The tiles are dealt out in GROUPS
+// of up to 32 that form a compact block of the lower region (4 tile rows x 8 tile columns: 12 distinct panels for 32 tiles
+// instead of 64), one group per XCD and round.  Measured on one box, sigma_mlp 32768 x 14336, five / six planes per call:
+//   one tile per workgroup, 2 x 2 super-blocks (round 1's launch)      25.3-25.5 / 38.9-39.0 ms   58 / -- GB of L2 misses
+//   persistent, the workgroups run through their lists independently   24.5-24.6 / 38.2-38.3 ms   53 / 67 GB        <- default
+//   persistent + a barrier of the XCD's 32 workgroups between rounds   25.4-25.6 / 40.4-40.6 ms   32 / 54 GB
+// (-DMDG_I8_LOCKSTEP_BARRIER=1: the CUs of an XCD start every group together and, pulling the same panel slices through the
+// same L2, stay together).  The lock-step launch halves the L2-miss traffic and is SLOWER: the misses are not what bounds the
+// kernel (the power cap is: mdg_probe_mfma_i8), and 32 CUs folding into sigma and refilling their rings
+// at the same instant cost more than the hits return.  Without the barrier the static lists still save the per-tile
+// workgroup launch / drain: 3 %.
+template <int P>  // planes used: 5 or 6
+__global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
+  constexpr int WB = P == 6 ? 1 : 2;               // 32-row blocks of a wave tile: 64 x 32, or 32 x 32 (96 accumulators at P = 6)
+  constexpr int TJ = WB == 2 ? 128 : 64;           // tile columns (rows of the J operand); waves are laid out (128 / 32 WB) x (TJ / 32)
+  constexpr int PB = TJ * KS;
+  constexpr int GA = TI / 32, GB = TJ / 32;        // 32-row groups (1 KB pieces per plane and stage) of the two operands
+  constexpr int WCOLS = TJ / 32;
+  constexpr int STAGE_BYTES = P * (PA + PB);       // 40 KB (P = 5, 128 x 128) / 36 KB (P = 6, 128 x 64)
+  constexpr int PIECES = (GA + GB) * P;            // 1 KB pieces per stage
+  constexpr bool SKIP = MDG_I8_SKIP_ZERO;
+  constexpr int RING = ring_depth(P);              // LDS stages
+  constexpr bool PREFETCH = P == 6;                // the next step's fragments are read before the barrier (needs RING = 4)
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  // The route is chosen on the DEVICE: mdg_cov_accum_i8 enqueues the five-plane product, the six-plane product and the fp64
+  // kernel back to back, and each exits at once unless the depth statistic of this call (i8_depth_kernel) selects it -- the
+  // host never waits for the flag.  The six-plane launch also books the fp64 fallback in the route counters.
+  {
+    const int route = *a.route_flag;
+    if (route != (P == 5 ? 0 : 1)) {
+      if (P == 6 && (route & 2) && a.route_counts && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.route_counts + 2, 1);
+      return;
+    }
+    if (a.route_counts && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.route_counts + (P == 5 ? 0 : 1), 1);
+  }
+  unsigned executed = 0;
+  const int lane = threadIdx.x & 63;
+  if (a.sched) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    for (int round = 0;; round++) {
+      const int g = round * 8 + xcd;
+      if (g >= a.ngroups) break;
+      const int code = a.sched[g * 32 + slot];
+      if (code >= 0) i8_syrk_tile<P>(a, code >> 16, code & 0xFFFF, lds, executed);
+      if (g + 8 >= a.ngroups) break;          // this XCD's last round
+#if MDG_I8_LOCKSTEP_BARRIER
+      // round barrier of the XCD's workgroups: for speed only (nothing below depends on it), so the spin is bounded
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(a.xcd_arrive + xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int target = slots * (round + 1);
+        for (int spin = 0; spin < 4000 && __hip_atomic_load(a.xcd_arrive + xcd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; spin++)
+          __builtin_amdgcn_s_sleep(32);
+      }
+      __syncthreads();
+#endif
+    }
+  } else {
+    // Tile (bi, bj): bi = 128-row block, bj = TJ-row block of the lower region (bj <= bi for 128 x 128 tiles, bj <= 2 bi + 1 for
+    // 128 x 64).  XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2, so workgroup w belongs
+    // to XCD w % 8 and is the (w / 8)-th one there.  The tiles are grouped into super-blocks that are square in features
+    // (SI x SI tiles of 128 x 128, SI x 2 SI tiles of 128 x 64); a super-block lives on ONE XCD, so per k-step its tiles pull
+    // each distinct panel row through that L2 once.  Super-blocks (R, C), C <= R, cover the lower region; tiles of a diagonal
+    // super-block that lie above it exit at once.
+    int bi, bj;
+    constexpr int SI = P == 5 ? MDG_I8_SB5 : MDG_I8_SB6;   // super-block: SI x SI (or SI x 2 SI) tiles; 0 = plain row-major order
+    if (SI > 0) {
+      constexpr int TPS = TJ == 128 ? SI * SI : SI * 2 * SI;   // tiles per super-block
+      constexpr int SJ = TJ == 128 ? SI : 2 * SI;              // tile columns of a super-block
+      const int w = blockIdx.x;
+      const int q = w >> 3;
+      const int sb = q / TPS * 8 + (w & 7), t_in = q % TPS;
+      int R = (int)((sqrtf(8.f * sb + 1.f) - 1.f) * 0.5f);
+      while ((R + 1) * (R + 2) / 2 <= sb) R++;
+      while (R * (R + 1) / 2 > sb) R--;
+      const int C = sb - R * (R + 1) / 2;
+      bi = SI * R + t_in / SJ;
+      bj = SJ * C + t_in % SJ;
+    } else if (TJ == 128) {
+      const int tile = blockIdx.x;  // bi (bi + 1) / 2 tiles precede row bi
+      bi = (int)((sqrtf(8.f * tile + 1.f) - 1.f) * 0.5f);
+      while ((bi + 1) * (bi + 2) / 2 <= tile) bi++;
+      while (bi * (bi + 1) / 2 > tile) bi--;
+      bj = tile - bi * (bi + 1) / 2;
+    } else {
+      const int tile = blockIdx.x;  // bi (bi + 1) tiles precede row bi
+      bi = (int)((sqrtf(4.f * tile + 1.f) - 1.f) * 0.5f);
+      while ((bi + 1) * (bi + 2) <= tile) bi++;
+      while (bi * (bi + 1) > tile) bi--;
+      bj = tile - bi * (bi + 1);
+    }
+    if (bi >= a.n / TI || bj * TJ > bi * TI + TI - 1) return;
+    i8_syrk_tile<P>(a, bi, bj, lds, executed);
+  }
+  if (a.mfma_count && lane == 0) atomicAdd(a.mfma_count, (unsigned long long)executed);
+}
+
 size_t planes_bytes(int64_t T, int64_t n) { return (size_t)NP * (size_t)n * (size_t)ceil_div(T, KS) * KS; }
-size_t ints_bytes(int64_t n) { return align_up((size_t)(3 * n + 4) * sizeof(int), 256); }   // emax, deep, nz, flag[2] + mfma count
+constexpr int INTS_TAIL = 4 + 8;   // flag[2] + mfma count (8 bytes) + the 8 arrival counters of the persistent launch's round barrier
+size_t ints_bytes(int64_t n) { return align_up((size_t)(3 * n + INTS_TAIL) * sizeof(int), 256); }   // emax, deep, nz, then INTS_TAIL
 size_t zmask_bytes(int64_t T, int64_t n) { return align_up((size_t)ceil_div(T, KS) * (size_t)(n / 32), 256); }
+
+
+// ---- tile schedule of the persistent, XCD-lock-step launch (i8_syrk_kernel with SyrkArgs::sched)
+// Groups of up to 32 tiles = one XCD's 32 CUs for one round.  The lower region is cut into macro-rows of 4 tile rows and those
+// into chunks of 8 tile columns: a full group is a 4 x 8 block of tiles -- 4 A panels and 8 B panels shared by 32 tiles.  The
+// ragged groups along the diagonal are then packed (tiles of the smallest ones fill up the largest), so that ceil(tiles / 32)
+// groups -- and as few rounds as the tile count allows -- remain.  Built once per (device, tile-row count, tile shape) on the
+// host and kept on the device: a few KB of immutable lookup data, the one allocation the library keeps across calls.
+struct Schedule {
+  int* dev = nullptr;
+  int ngroups = 0;
+};
+
+const Schedule* schedule_for(int rb, int cw) {   // cw: tile columns per 128 features (1: 128 x 128 tiles, 2: 128 x 64)
+  static std::mutex mu;
+  static std::map<std::tuple<int, int, int>, Schedule> cache;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  auto key = std::make_tuple(dev, rb, cw);
+  auto it = cache.find(key);
+  if (it != cache.end()) return &it->second;
+  std::vector<std::vector<int>> full, ragged;
+  for (int R = 0; R * 4 < rb; R++) {
+    const int r1 = std::min(rb, R * 4 + 4);
+    const int ncols = r1 * cw;                       // columns of the macro-row's last tile row
+    for (int c0 = 0; c0 < ncols; c0 += 8) {
+      std::vector<int> g;
+      for (int bi = R * 4; bi < r1; bi++)
+        for (int bj = c0; bj < c0 + 8; bj++)
+          if (bj < (bi + 1) * cw) g.push_back((bi << 16) | bj);
+      if (g.size() == 32) full.push_back(g);
+      else if (!g.empty()) ragged.push_back(g);
+    }
+  }
+  std::sort(ragged.begin(), ragged.end(), [](const std::vector<int>& x, const std::vector<int>& y) { return x.size() > y.size(); });
+  size_t lo = 0, hi = ragged.size();
+  while (lo + 1 < hi) {                               // fill the largest ragged group from the smallest one
+    std::vector<int>& big = ragged[lo];
+    std::vector<int>& small = ragged[hi - 1];
+    while (big.size() < 32 && !small.empty()) {
+      big.push_back(small.back());
+      small.pop_back();
+    }
+    if (small.empty()) hi--;
+    if (big.size() == 32) lo++;
+  }
+  std::vector<int> table;
+  auto emit = [&](const std::vector<int>& g) {
+    for (int i = 0; i < 32; i++) table.push_back(i < (int)g.size() ? g[i] : -1);
+  };
+  for (auto& g : full) emit(g);
+  for (size_t i = 0; i < hi; i++)
+    if (!ragged[i].empty()) emit(ragged[i]);
+  Schedule sch;
+  sch.ngroups = (int)(table.size() / 32);
+  if (hipMalloc((void**)&sch.dev, table.size() * sizeof(int)) != hipSuccess) return nullptr;
+  if (hipMemcpy(sch.dev, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  return &cache.emplace(key, sch).first->second;
+}
 
 }  // namespace
 }  // namespace mdg
@@ -708,7 +844,7 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
   unsigned long long* mfma_count = (unsigned long long*)(flag + 2);   // 8-byte aligned (n is a multiple of 128); zeroed below
   unsigned char* zmask = (unsigned char*)emax + ints_bytes(n);
   void* fb_ws = zmask + zmask_bytes(n_tokens, n);
-  MDG_HIP(hipMemsetAsync(emax, 0, (size_t)(3 * n + 4) * sizeof(int), st));
+  MDG_HIP(hipMemsetAsync(emax, 0, (size_t)(3 * n + INTS_TAIL) * sizeof(int), st));
   const bool vec = ((uintptr_t)x % 16 == 0) && (ld % 8 == 0);
   {
     const int64_t rows_per_block = 2048;
@@ -732,6 +868,7 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
   SyrkArgs a;
   a.planes = planes; a.emax = emax; a.sigma = sigma; a.ld_sigma = ld_sigma; a.n = n; a.nk = nk; a.zmask = zmask; a.mfma_count = mfma_count;
   a.route_flag = flag; a.route_counts = route_counts;
+  a.xcd_arrive = flag + 4;
 #ifdef MDG_I8_STAMPS
   static unsigned long long* stamps_dev = nullptr;
   const size_t stamps_n = (size_t)STAMP_WGS * NW * 8;
@@ -752,7 +889,23 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
     const int si = planes_used == 5 ? MDG_I8_SB5 : MDG_I8_SB6;                 // super-block rows (see the kernel); 0 = row-major
     const int sr = si ? (rb + si - 1) / si : 0, nsb = sr * (sr + 1) / 2;       // super-block rows, super-blocks
     const int tps = wide ? si * si : 2 * si * si;                              // tiles per super-block
-    const dim3 grid(si ? (unsigned)((nsb + 7) / 8 * 8 * tps) : (unsigned)(wide ? rb * (rb + 1) / 2 : rb * (rb + 1)));
+    dim3 grid(si ? (unsigned)((nsb + 7) / 8 * 8 * tps) : (unsigned)(wide ? rb * (rb + 1) / 2 : rb * (rb + 1)));
+    // large statistics: the persistent launch, one workgroup per CU, tiles from the lock-step schedule
+    a.sched = nullptr;
+    a.ngroups = 0;
+#if MDG_I8_LOCKSTEP
+    if (rb >= MDG_I8_LOCKSTEP_MIN_ROWS) {
+      int dev = 0, n_cu = 0;
+      MDG_HIP(hipGetDevice(&dev));
+      MDG_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+      const Schedule* sch = n_cu == 256 ? schedule_for(rb, wide ? 1 : 2) : nullptr;   // 8 XCDs x 32 CUs is what the table is cut for
+      if (sch) {
+        a.sched = sch->dev;
+        a.ngroups = sch->ngroups;
+        grid = dim3(256);
+      }
+    }
+#endif
     if (planes_used == 6) {
       MDG_HIP(hipFuncSetAttribute((const void*)i8_syrk_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL((i8_syrk_kernel<6>), grid, dim3(64 * NW), lds, st, a);

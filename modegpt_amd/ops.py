@@ -521,6 +521,16 @@ def probe_mfma_f64(iters: int = 4096) -> float:
     return out.value
 
 
+def probe_mfma_i8(iters: int = 200000, random_operands: bool = True) -> float:
+    """Measured int8-MFMA rate of this device in TOP/s from register-resident operands that change every MFMA: all zero (full
+    clock) or random bytes (power-capped clock) -- the ceiling of any int8 kernel on such data."""
+    lib = _lib.load()
+    out = C.c_double(0.0)
+    check(lib.mdg_probe_mfma_i8(iters, int(random_operands), C.byref(out), torch.cuda.current_stream().cuda_stream),
+          "mdg_probe_mfma_i8")
+    return out.value
+
+
 def device_info(device: int = 0):
     lib = _lib.load()
     name = C.create_string_buffer(64)

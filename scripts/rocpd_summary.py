@@ -10,7 +10,8 @@ db = sqlite3.connect(sys.argv[1])
 cur = db.cursor()
 BYGRID = len(sys.argv) > 2 and sys.argv[2] == "bygrid"
 GATE_MS = 0.03
-GATED = "(s.kernel_name like '%i8_syrk_kernel%' or s.kernel_name like '%cov_accum_kernel%') and (d.end-d.start) < %d" % int(GATE_MS * 1e6)
+GATED = ("(s.kernel_name like '%%i8_syrk_kernel%%' or s.kernel_name like '%%cov_accum_kernel%%') and (d.end-d.start) < %d"
+         % int(GATE_MS * 1e6))
 if BYGRID:
     print("kernel,grid_x,class,calls,avg_ms,min_ms,max_ms")
     for r in cur.execute("""select s.kernel_name, d.grid_size_x, case when %s then 'gated_out' else 'ran' end, count(*),
