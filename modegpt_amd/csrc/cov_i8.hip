@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void i8_colmax_kernel(const bf16_t* x, int64_t
 // element is two full digits and a carry digit (see FLUSH_STEPS), so on real activations whole pieces of the lower planes are
 // zero -- Gaussian columns: plane 3 in 90 % of the pieces, planes 4 and 5 always; SiLU-gated: plane 4 in 98 % -- and the
 // product kernel neither loads nor multiplies those.  Called with the 32 rows of a piece in the 32 lanes of a half-wave.
-__device__ __forceinline__ void write_piece_mask(const unsigned (&any)[NP], unsigned char* zmask, int64_t index) {
+__device__ __forceinline__ unsigned write_piece_mask(const unsigned (&any)[NP], unsigned char* zmask, int64_t index) {
   unsigned byte = 0;
 #pragma unroll
   for (int s = 0; s < NP; s++) {
@@ -99,7 +99,14 @@ __device__ __forceinline__ void write_piece_mask(const unsigned (&any)[NP], unsi
     byte |= (half != 0) << s;
   }
   if ((threadIdx.x & 31) == 0) zmask[index] = (unsigned char)byte;
+  return byte;     // the mask of the caller's own piece (its half-wave)
 }
+
+// Planes the product kernels may read even where the piece mask says "all zero": both load every plane below their MIN_DEPTH
+// unconditionally (3 for five planes, 4 for six).  Pieces of the planes from here on are WRITTEN only when they hold a nonzero
+// there or in a deeper plane of the same piece (a product kernel that finds plane 5 present loads plane 4 as well) -- on
+// Gaussian / ReLU / SiLU-gated activations planes 4 and 5 practically never do: a third of the split pass's writes.
+constexpr int ALWAYS_WRITTEN_PLANES = 4;
 
 // One thread = one feature row of a 32-row group x one k-step (32 tokens) at a time: two 16-byte stores per plane and
 // k-step.  A workgroup walks SPLIT_STEPS k-steps of its row group, 8 at a time.
@@ -221,9 +228,9 @@ __global__ __launch_bounds__(256) void i8_split_vec_kernel(const bf16_t* x, int6
   int deep = 0, nz = 0;
   if (kt < nk) {   // (uniform per wave: a wave holds 64 features of ONE k-step)
     unsigned any[NP] = {};
+    unsigned dig[2][NP][4] = {};
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-      unsigned dig[NP][4] = {};
 #pragma unroll
       for (int q = 0; q < 16; q++) {
         int sig, ee;
@@ -242,19 +249,24 @@ __global__ __launch_bounds__(256) void i8_split_vec_kernel(const bf16_t* x, int6
 #pragma unroll
         for (int s2 = NP - 1; s2 >= 1; s2--) {
           const int b = (int)((N + 128) & 255) - 128;
-          dig[s2][q >> 2] |= (unsigned)(b & 255) << (8 * (q & 3));
+          dig[h][s2][q >> 2] |= (unsigned)(b & 255) << (8 * (q & 3));
           N = (N - b) >> 8;
         }
-        dig[0][q >> 2] |= (unsigned)((int)N & 255) << (8 * (q & 3));
+        dig[h][0][q >> 2] |= (unsigned)((int)N & 255) << (8 * (q & 3));
       }
 #pragma unroll
-      for (int s2 = 0; s2 < NP; s2++) {
-        signed char* piece = planes + ((s2 * groups + G) * (int64_t)nk + kt) * 1024;
-        *(i32x4*)(piece + h * 512 + r * 16) = (i32x4){(int)dig[s2][0], (int)dig[s2][1], (int)dig[s2][2], (int)dig[s2][3]};
-        any[s2] |= dig[s2][0] | dig[s2][1] | dig[s2][2] | dig[s2][3];
-      }
+      for (int s2 = 0; s2 < NP; s2++) any[s2] |= dig[h][s2][0] | dig[h][s2][1] | dig[h][s2][2] | dig[h][s2][3];
     }
-    write_piece_mask(any, zmask, (int64_t)kt * groups + G);
+    const unsigned present = write_piece_mask(any, zmask, (int64_t)kt * groups + G);
+#pragma unroll
+    for (int s2 = 0; s2 < NP; s2++)
+      if (s2 < ALWAYS_WRITTEN_PLANES || (present >> s2) != 0) {   // some plane >= s2 holds a nonzero here: the product kernels load
+                                                                  // every plane below a group's depth (uniform per half-wave = per piece)
+        signed char* piece = planes + ((s2 * groups + G) * (int64_t)nk + kt) * 1024;
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+          *(i32x4*)(piece + h * 512 + r * 16) = (i32x4){(int)dig[h][s2][0], (int)dig[h][s2][1], (int)dig[h][s2][2], (int)dig[h][s2][3]};
+      }
   }
   if (deep) atomicAdd(&deep_lds[f], deep);
   if (nz) atomicAdd(&nz_lds[f], nz);
@@ -384,6 +396,9 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const int bi, co
 #define MDG_I8_MIN_DEPTH6 4   // (experiments: 6 runs the six-plane kernel's mask machinery without skipping anything)
 #endif
   constexpr int MIN_DEPTH = P == 6 ? MDG_I8_MIN_DEPTH6 : P - 2;
+#ifndef MDG_EXPERIMENT
+  static_assert(MIN_DEPTH <= ALWAYS_WRITTEN_PLANES, "the split pass leaves all-zero pieces of the deeper planes unwritten");
+#endif
   auto group_depth = [&](unsigned m, int g) {   // 1 + deepest plane with a nonzero in group g, but at least MIN_DEPTH
     const unsigned byte = (m >> (8 * g)) & 0xFFu;
     return max(MIN_DEPTH, min(P, 32 - __builtin_clz(byte | 1u)));

@@ -706,11 +706,20 @@ def test_cov_accum_multi_side_stream_overlap_changes_nothing(ops, dev, monkeypat
     assert ((a[1].cpu() - ref)[:, low].abs().max() / ref.abs().max()).item() < 1e-12
 
 
-def test_cov_i8_zero_plane_skipping_is_exact(ops, dev):
+def test_cov_i8_zero_plane_skipping_is_exact(ops, dev, monkeypatch):
     """The product kernel skips digit planes that are all-zero over a tile panel in a k-step (piece masks written by the
-    split pass).  Data built so that the plane depth differs between row groups, between k-steps and between the two panels
+    split pass), and the split pass does not even WRITE all-zero pieces of planes 4 and 5: the workspace is handed over
+    poisoned (0x55 in every byte), so a piece that is read without having been written shows up in the result.  Data built so that the plane depth differs between row groups, between k-steps and between the two panels
     of a tile -- blocks of tiny values (deep planes only there), blocks of exact zeros, single deep elements -- must still
     match the fp64 kernel, and the executed-MFMA count must sit below the dense count yet above the three-plane floor."""
+    real_ws = ops._ws
+
+    def poisoned(nbytes, device):
+        t, p = real_ws(nbytes, device)
+        if t is not None:
+            t.fill_(0x55)
+        return t, p
+    monkeypatch.setattr(ops, "_ws", poisoned)
     gen = torch.Generator().manual_seed(31)
     T, n = 4096 + 17, 384
     X = torch.randn(T, n, generator=gen)
