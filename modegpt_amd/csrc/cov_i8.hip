@@ -22,17 +22,20 @@
 //                      counts the deep elements per column on the way, and writes one mask byte per (k-step, 32-row group)
 //                      saying which planes hold a nonzero there (an element is two full digits and a carry digit, so whole
 //                      pieces of the deeper planes are zero on real activations)
-//   i8_syrk_kernel<P, waves>  output tiles of the lower triangle, two waves per SIMD inside one workgroup of 8 waves:
+//   i8_depth_kernel    the route flag: 0 -> five planes, 1 -> six planes, bit 1 -> the fp64 kernel (read by the launches below)
+//   i8_syrk_kernel<P>  output tiles of the lower triangle, two waves per SIMD inside one workgroup of 8 waves:
 //                      P = 5: 128 x 128 tile, wave tile 64 x 32 (160 int32 accumulators; a 64 x 64 wave tile's 320 would not
 //                      fit); P = 6: 128 x 64 tile, wave tile 32 x 32 (96).  Per k-step of 32 tokens ONE set of fragment reads
 //                      feeds all P (P + 1) / 2 plane-pair products of the wave tile (3x less LDS traffic per MFMA than separate
-//                      GEMMs, which is what lets it pass the library's int8 rate); 2-stage LDS ring filled by LDS-DMA, one raw
-//                      barrier per stage; every 2047 k-steps (65504 tokens, the int32 bound) the classes are folded into sigma in fp64.  The P = 5
-//                      variant reads the top five of the six planes (a balanced-digit truncation).  Planes beyond a 32-row
-//                      group's depth in a k-step (piece masks) are neither loaded, nor read from LDS, nor multiplied: exact, and
-//                      31 - 37 % of the MFMAs on Gaussian / SiLU-gated data.  The 4-wave shapes of
-//                      the first versions (128 x 64 tile, 64 x 32 wave tiles, 4-stage ring with counted waits) stay available
-//                      behind -DMDG_I8_WIDE5=0 / -DMDG_I8_WIDE6=0.
+//                      GEMMs, which is what lets it pass the library's int8 rate); 3- / 4-stage LDS ring filled by LDS-DMA from
+//                      SGPR piece descriptors, the two waves of a SIMD in opposite load / multiply order, one raw barrier per
+//                      stage; every 2047 k-steps (65504 tokens, the int32 bound) the classes are folded into sigma in fp64.  The
+//                      P = 5 variant reads the top five of the six planes (a balanced-digit truncation).  Planes beyond a
+//                      32-row group's depth in a k-step (piece masks) are neither written, nor loaded, nor read from LDS, nor
+//                      multiplied: exact, and 28 - 37 % of the MFMAs on SiLU-gated / Gaussian data.  Both instantiations
+//                      and the fp64 kernel are enqueued for every call; the device picks one (each workgroup of the others
+//                      exits on its first instruction).  Statistics of 8192 features and more run as a persistent launch
+//                      (one workgroup per CU, static XCD-grouped tile lists).
 #include <algorithm>
 #include <map>
 #include <mutex>

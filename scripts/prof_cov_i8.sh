@@ -17,5 +17,5 @@ for pass in trace fetch write mfma; do
   python3 scripts/rocpd_summary.py $(ls $OUT/*.db | head -1) bygrid > $R/gpurun_out/covi8_$pass.csv || exit 1
   rm -rf $OUT
 done
-grep -h "i8_\|cov_accum_kernel" $R/gpurun_out/covi8_trace.csv | cut -c1-200
-grep -h "i8_syrk" $R/gpurun_out/covi8_fetch.csv $R/gpurun_out/covi8_write.csv $R/gpurun_out/covi8_mfma.csv | grep -v "^\"_ZN3mdg12_GLOBAL__N_114i8_syrk_kernelILi5EEEvNS0_8SyrkArgsE.kd\",[0-9]*,[0-9.]*,[0-9.]*,[0-9.]*,[0-9.]*,[0-9.]*$" | cut -c1-200
+grep -h "i8_\|cov_accum_kernel" $R/gpurun_out/covi8_trace.csv | grep -v gated_out | cut -c1-200
+grep -h "i8_syrk" $R/gpurun_out/covi8_fetch.csv $R/gpurun_out/covi8_write.csv $R/gpurun_out/covi8_mfma.csv | grep -v gated_out | grep "FETCH\|WRITE\|SQ_\|GRBM" | cut -c1-200

@@ -786,3 +786,25 @@ def test_allgather_layers_through_the_c_abi(dev):
         assert lib.mdg_comm_init(C.byref(C.c_void_p(None)), 2, 5, uid) == _lib.MDG_ERR_BAD_ARG
         _lib.check(lib.mdg_comm_destroy(comm), "mdg_comm_destroy")
         assert lib.mdg_comm_destroy(None) == _lib.MDG_OK
+
+
+def test_cov_i8_route_is_chosen_and_counted_on_the_device(ops, dev):
+    """The hooks' path (report=False) never asks the host which route a call took: the five-plane product, the six-plane
+    product and the fp64 kernel are all enqueued and the device runs one.  The tallies live on the device
+    (ops.i8_route_counts) and the results equal those of the reporting calls bit for bit."""
+    gen = torch.Generator().manual_seed(91)
+    n, T = 256, 3000
+    g, u = torch.randn(T, n, generator=gen), torch.randn(T, n, generator=gen)
+    data = {"i8_5": acts(gen, T, n), "i8_6": (torch.nn.functional.silu(g) * u).to(torch.bfloat16), "fallback_f64": (g ** 3).to(torch.bfloat16)}
+    ops.i8_route_counts(dev, reset=True)
+    for k, (route, X) in enumerate(data.items()):
+        X = X.to(dev)
+        S0 = torch.zeros(n, n, dtype=F64, device=dev)
+        S1 = torch.zeros_like(S0)
+        assert ops.cov_accum_i8(S0, X, report=False) is None          # enqueue only
+        planes = ops.cov_accum_i8(S1, X)                               # the same call, reporting
+        assert {5: "i8_5", 6: "i8_6", 0: "fallback_f64"}[planes] == route
+        assert torch.equal(S0, S1)
+        counts = ops.i8_route_counts(dev)
+        assert counts[route] == 2 and sum(counts.values()) == 2 * (k + 1), counts
+    assert ops.i8_route_counts(dev, reset=True)["fallback_f64"] == 2 and sum(ops.i8_route_counts(dev).values()) == 0
