@@ -200,7 +200,10 @@ static int read_flag(int* dflag, hipStream_t st, int* host) {
 // panel.  Outer level: one rank-512 lower-only update of everything behind the outer panel.  A rank-128 update of a
 // 128x128 fp64 tile moves 512 KB for 4.2 MFLOP (8 flop/B: HBM-bound at ~30 TF); rank-512 quadruples the intensity
 // and puts the bulk of the n^3/3 flops back under the MFMA roof.
-constexpr int NBO = 512;
+#ifndef MDG_CHOL_NBO
+#define MDG_CHOL_NBO 1024   // (512: 63.0 + 72.2 ms for the ridge scores + Nystrom solve of a Llama-3-8B layer; 1024: 62.5 + 69.7; 256: 66.4 + 76.3)
+#endif
+constexpr int NBO = MDG_CHOL_NBO;
 
 int potrf_lower(double* A, int64_t n, int64_t lda, double* inv_diag, hipStream_t st) {
   const int64_t nblk = ceil_div(n, NB);
