@@ -364,6 +364,9 @@ constexpr int STAMP_WGS = 1024;
 #ifndef MDG_I8_LOCKSTEP_MIN_ROWS
 #define MDG_I8_LOCKSTEP_MIN_ROWS 64   // ... this many 128-row blocks (n >= 8192); smaller ones keep one tile per workgroup
 #endif
+#ifndef MDG_I8_DEFER
+#define MDG_I8_DEFER 4      // MFMAs a loads-first wave holds back across the barrier (0: 25.3, 2: 26.0, 3: 24.9, 4: 24.6, 5: 25.0, 6: 27.8 ms per call)
+#endif
 #ifndef MDG_I8_ROLES
 #define MDG_I8_ROLES 1  // 0: every wave loads first (the lock-step order of the first versions)
 #endif
@@ -445,9 +448,15 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const int bi, co
     for (int q = 0; q < NQ; q++) {
       if (!pc_valid[q]) continue;
       const unsigned present = ((unsigned)(m64 >> pc_shift[q]) & pc_cmask[q]) | pc_force[q];
+#if defined(MDG_I8_EXPERIMENT_NO_LOADS)      // (timing experiments, wrong results) 1: no load instruction after the prologue;
+      if (present && (MDG_I8_EXPERIMENT_NO_LOADS == 2 || kt < RING - 1))   // 2: the instruction is issued under EXEC = 0 (no memory access)
+        asm volatile("s_mov_b64 exec, %3\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, -1"
+                     ::"s"(lbase + pc_loff[q]), "v"(voff), "s"(pc_base[q]), "s"(kt < RING - 1 ? ~0ull : 0ull) : "memory");
+#else
       if (present)   // (an all-zero piece is not loaded: nothing will read it)
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lbase + pc_loff[q]), "v"(voff), "s"(pc_base[q])
                      : "memory");   // (M0 is written; nothing the compiler emits in this kernel reads it)
+#endif
     }
   };
 
@@ -581,6 +590,12 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const int bi, co
     executed += deep_mfmas;
   };
   constexpr int UNCOND_PAIRS = P == 5 ? 9 : (MIN_DEPTH == 4 ? 15 : 21);   // pairs (s, t), s, t < MIN_DEPTH, s + t < P
+  constexpr int N_UNCOND = UNCOND_PAIRS * WB;                               // unconditional MFMAs per wave and k-step
+#ifndef MDG_I8_DEFER6
+#define MDG_I8_DEFER6 0     // six planes: 37.2 ms per call without, 55 ms with 3 - 5 deferred (the loads-first waves then lose their fragment prefetch)
+#endif
+  constexpr int DEFER = !MDG_I8_ROLES ? 0 : (PREFETCH ? MDG_I8_DEFER6 : MDG_I8_DEFER);   // of them, held back across the barrier by the loads-first waves
+  // (with PREFETCH and DEFER both on, only the multiply-first waves prefetch: a loads-first wave still needs its old fragments after the barrier)
   auto rotate = [&]() {
 #pragma unroll
     for (int i = 0; i < D; i++) {
@@ -592,7 +607,7 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const int bi, co
   const auto ahead = [&](int d) { int x = buf + d; return x >= RING ? x - RING : x; };   // (kt + d) % RING
   if (PREFETCH) {
     __builtin_amdgcn_s_barrier();   // stages 0 .. D - 1 complete (every wave waited for its share)
-    load_frags(0);
+    if (!(DEFER && loads_first)) load_frags(0);
   }
   // two loops: the int32 classes are folded into sigma between runs of FLUSH_STEPS k-steps, outside the MFMA loop (a
   // conditional flush inside it makes the compiler shuttle all 160 accumulators between AGPRs and VGPRs every step)
@@ -614,28 +629,44 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const int bi, co
         if (SKIP && kt + D + 1 < nk) load_masks(kt + D + 1, vA, vB);
       };
       MDG_STAMP(tb);
+      // the unconditional MFMAs of a step, in (s, t, block) order; [lo, hi) selects a run of them
+      auto mfma_run = [&](int lo, int hi) {
+        int idx = 0;
+#pragma unroll
+        for (int s = 0; s < MIN_DEPTH; s++)
+#pragma unroll
+          for (int t = 0; t < MIN_DEPTH; t++)
+            if (s + t < P) {
+#pragma unroll
+              for (int b = 0; b < WB; b++) {
+                if (idx >= lo && idx < hi) acc[s + t][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s][b], fb[t], acc[s + t][b], 0, 0, 0);
+                idx++;
+              }
+            }
+      };
       if (loads_first) {
+        // the loads-first waves keep the last DEFER MFMAs of the previous step back until here: they run while their SIMD
+        // partner, which multiplies first, is still waiting for its fragment reads -- the matrix pipe would idle ~150 cycles
+        // at every step boundary otherwise (fragments of the previous step are still in this wave's registers: it re-reads
+        // them only after its loads are out)
+        if (DEFER && kt > k0) {
+          mfma_run(N_UNCOND - DEFER, N_UNCOND);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         refill();
         __builtin_amdgcn_sched_barrier(0);
       }
       MDG_STAMP(tc);
-      if (!PREFETCH) load_frags(buf);
-#pragma unroll
-      for (int s = 0; s < MIN_DEPTH; s++)
-#pragma unroll
-        for (int t = 0; t < MIN_DEPTH; t++)
-          if (s + t < P) {
-#pragma unroll
-            for (int b = 0; b < WB; b++)
-              acc[s + t][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s][b], fb[t], acc[s + t][b], 0, 0, 0);
-          }
+      if (!PREFETCH || (DEFER && loads_first)) load_frags(buf);
+      mfma_run(0, N_UNCOND - DEFER);
+      if (DEFER == 0 || !loads_first) mfma_run(N_UNCOND - DEFER, N_UNCOND);
       deep_planes(buf, mA[0], mB[0]);
       executed += UNCOND_PAIRS * WB;
       if (PREFETCH) {
       // next step's fragments: stage kt + 1 has been complete since THIS step's barrier (its loads went out three steps ago
       // and every wave waited for its share before the barrier), so the read latency hides behind the refill / the barrier
       __builtin_amdgcn_sched_barrier(0);   // (not before the MFMAs above are issued: the fragment registers are theirs until then)
-      if (kt + 1 < nk) load_frags(ahead(1));
+      if (kt + 1 < nk && !(DEFER && loads_first)) load_frags(ahead(1));
       }
       MDG_STAMP(td);
       if (!loads_first) {
@@ -648,6 +679,19 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const int bi, co
       s_wait += tb - ta; s_issue += tc - tb; s_comp += td - tc; s_tail += te - td;
 #endif
       rotate();
+    }
+    if (DEFER && loads_first) {   // the deferred MFMAs of the segment's last step (its fragments are still in registers)
+#pragma unroll
+      for (int s = 0, idx = 0; s < MIN_DEPTH; s++)
+#pragma unroll
+        for (int t = 0; t < MIN_DEPTH; t++)
+          if (s + t < P) {
+#pragma unroll
+            for (int b = 0; b < WB; b++) {
+              if (idx >= N_UNCOND - DEFER) acc[s + t][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s][b], fb[t], acc[s + t][b], 0, 0, 0);
+              idx++;
+            }
+          }
     }
     flush();
   }
