@@ -16,6 +16,14 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 typedef unsigned short bf16_t;  // raw bits
 typedef unsigned short f16_t;   // raw bits
 
+// Experiment / debug knobs read from the environment exist only in builds with -DMDG_EXPERIMENT (scripts/probes/*.sh,
+// scripts/bench_kernels.py); the product library never lets an environment variable change what it computes or prints.
+#ifdef MDG_EXPERIMENT
+#define MDG_KNOB(name) (getenv(name) != nullptr)
+#else
+#define MDG_KNOB(name) false
+#endif
+
 // ---------------------------------------------------------------- errors
 void set_error(const char* fmt, ...);
 

@@ -372,7 +372,7 @@ int sqrt_psd_newton(const double* M, int64_t n, int64_t ld, double ridge, double
     MDG_HIP(hipMemcpyAsync(&r2, red + 1 + k, sizeof(double), hipMemcpyDeviceToHost, st));
     MDG_HIP(hipStreamSynchronize(st));
     const double res = sqrt(r2);
-    if (getenv("MDG_DEBUG_NEWTON")) fprintf(stderr, "newton-schulz step %d: ||I - ZY||_F = %.3e\n", k, res);
+    if (MDG_KNOB("MDG_DEBUG_NEWTON")) fprintf(stderr, "newton-schulz step %d: ||I - ZY||_F = %.3e\n", k, res);
     if (!(res == res) || res > 1e6) return MDG_OK;                       // diverging: not positive definite
     // round-off floor: the residual has stopped contracting (it squares per step once below ~0.5)
     if (res < 1e-7 && res > 0.25 * prev) { *ok = 1; break; }
@@ -409,7 +409,7 @@ extern "C" int mdg_sqrt_psd_large(const double* M, int64_t n, int64_t ld, double
   MDG_CHECK_ARG(M && root && n > 0 && ld >= n, "mdg_sqrt_psd_large: bad arguments");
   MDG_CHECK_ARG(ws && ws_bytes >= mdg_sqrt_psd_large_ws_bytes(n), "mdg_sqrt_psd_large: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  if (!scaled && !evals_out && ridge >= 1e-12 && !getenv("MDG_SQRT_JACOBI")) {
+  if (!scaled && !evals_out && ridge >= 1e-12 && !MDG_KNOB("MDG_SQRT_JACOBI")) {
     int ok = 0;
     MDG_TRY(sqrt_psd_newton(M, n, ld, ridge, root, inv_root, (double*)ws, st, &ok));
     if (ok) return MDG_OK;  // otherwise: the eigen route below, which implements the reference's clamps
@@ -471,7 +471,7 @@ extern "C" int mdg_sqrt_psd_large(const double* M, int64_t n, int64_t ld, double
     double h[2];
     MDG_HIP(hipMemcpyAsync(h, red, sizeof(h), hipMemcpyDeviceToHost, st));
     MDG_HIP(hipStreamSynchronize(st));
-    if (getenv("MDG_DEBUG_JACOBI")) fprintf(stderr, "block-jacobi sweep %d: off^2 %.3e tot^2 %.3e\n", sweep, h[0], h[1]);
+    if (MDG_KNOB("MDG_DEBUG_JACOBI")) fprintf(stderr, "block-jacobi sweep %d: off^2 %.3e tot^2 %.3e\n", sweep, h[0], h[1]);
     done = h[0] <= 1e-26 * h[1] || h[1] == 0.;  // ||off||_F <= 1e-13 ||A||_F
   }
   if (!done) {

@@ -617,7 +617,7 @@ extern "C" int mdg_rope_gather(const void* x, int dtype, int64_t ld_x, int64_t B
   // Packs of the rotate_half partners straight from / to memory when they are at least 4 bytes.  Measured on
   // [16, 2048, 32 x r] bf16, direct vs LDS route: r = 88 (8-byte packs) 84 vs 113 us; r = 76 (4-byte) 105 vs 99 us, a tie;
   // r = 102 (2-byte) 199 vs 132 us.  MDG_ROPE_TILE=1 forces the LDS route (experiment knob of scripts/bench_kernels.py).
-  if (vec > 1 && !getenv("MDG_ROPE_TILE")) {
+  if (vec > 1 && !MDG_KNOB("MDG_ROPE_TILE")) {
     const dim3 grid((unsigned)(N_XCD * n_kv), (unsigned)tiles8, (unsigned)a.chunks);
     if (dtype == MDG_BF16) MDG_HIP(launch_rope_vec<MDG_BF16>(a, vec, hpt, grid, st));
     else if (dtype == MDG_F16) MDG_HIP(launch_rope_vec<MDG_F16>(a, vec, hpt, grid, st));
