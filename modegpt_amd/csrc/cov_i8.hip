@@ -371,7 +371,10 @@ constexpr int STAMP_WGS = 1024;
 #define MDG_I8_ROLES 1  // 0: every wave loads first (the lock-step order of the first versions)
 #endif
 constexpr int NW = 8;     // waves per workgroup
-constexpr int ring_depth(int planes) { return planes == 6 ? 4 : 3; }
+#ifndef MDG_I8_RING5
+#define MDG_I8_RING5 3
+#endif
+constexpr int ring_depth(int planes) { return planes == 6 ? 4 : MDG_I8_RING5; }
 
 // One output tile (bi, bj) of the lower region: bi = 128-row block, bj = TJ-row block (bj <= bi for 128 x 128 tiles, bj <= 2 bi + 1
 // for 128 x 64); all k-steps, then the fold into sigma.  `executed` += the MFMAs this wave issued.
