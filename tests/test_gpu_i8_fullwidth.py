@@ -153,3 +153,22 @@ def test_mlp_rank_selection_is_identical_on_both_routes(ops, dev, kind):
     for keep in (0.7, 0.6):
         r = int(n * keep)
         assert torch.equal(ops.select_smallest_sorted(sc8, r), ops.select_smallest_sorted(sc64, r)), (kind, keep)
+
+
+@pytest.mark.parametrize("n,T,kind", [(8192, 65504 + 2000, "gaussian"), (8192, 65504 + 2000, "silu_gated"), (8320, 3000, "gaussian"),
+                                      (12416, 2100, "silu_gated"), (8192, 33, "gaussian")])
+def test_persistent_launch_shapes(ops, dev, n, T, kind):
+    """Statistics of 8192 features and more run as the persistent launch (one workgroup per CU working through static tile
+    lists): the int32 fold boundary inside a tile list (65504 tokens), row-block counts that leave ragged groups along the
+    diagonal (65 and 97 blocks), and a call shorter than the LDS ring is deep."""
+    X = (gaussian if kind == "gaussian" else silu_gated)(dev, T, n, 31 + n)
+    S8 = torch.zeros(n, n, dtype=F64, device=dev)
+    S64 = torch.zeros_like(S8)
+    assert ops.cov_accum_i8(S8, X) in (5, 6)
+    ops.cov_accum(S64, X)
+    assert entrywise_err(S8, S64) < 1e-12
+    # every tile of the lower triangle was visited exactly once: a second call doubles the result exactly
+    ops.cov_accum_i8(S8, X)
+    low = torch.tril(torch.ones(n, n, dtype=torch.bool, device=dev))
+    ref = S64 * 2
+    assert entrywise_err(S8, ref) < 1e-12 and bool(torch.isfinite(S8[low]).all())
