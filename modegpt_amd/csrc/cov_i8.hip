@@ -302,6 +302,9 @@ struct SyrkArgs {
   int n, nk;
   const unsigned char* zmask;          // [nk][n / 32] piece masks written by the split pass (write_piece_mask)
   unsigned long long* mfma_count;      // += v_mfma instructions this launch executed (the dense count is known on the host)
+#ifdef MDG_EXPERIMENT
+  int force_route = -1;                // MDG_I8_PLANES=5|6 of scripts/bench_kernels.py: run that product kernel whatever the data say
+#endif
   const int* route_flag;               // written by i8_depth_kernel: 0 -> five planes, 1 -> six planes, bit 1 set -> the fp64 kernel
   int* route_counts;                   // optional device counters [five planes, six planes, fp64 fallback], += 1 by the launch that runs
   const int* sched;                    // persistent launch: [ngroups][32] tile codes (bi << 16 | bj, -1 = none); nullptr = one tile per workgroup
@@ -738,7 +741,11 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
   // kernel back to back, and each exits at once unless the depth statistic of this call (i8_depth_kernel) selects it -- the
   // host never waits for the flag.  The six-plane launch also books the fp64 fallback in the route counters.
   {
+#ifdef MDG_EXPERIMENT
+    const int route = a.force_route >= 0 ? a.force_route : *a.route_flag;
+#else
     const int route = *a.route_flag;
+#endif
     if (route != (P == 5 ? 0 : 1)) {
       if (P == 6 && (route & 2) && a.route_counts && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.route_counts + 2, 1);
       return;
@@ -945,8 +952,10 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
   if (ev_start) MDG_HIP(hipEventRecord((hipEvent_t)ev_start, st));
   for (int planes_used = 5; planes_used <= 6; planes_used++) {
 #ifdef MDG_EXPERIMENT   // knob of scripts/bench_kernels.py (force one product kernel); compiled out of the product library
-    if (const char* ev = getenv("MDG_I8_PLANES"))
+    if (const char* ev = getenv("MDG_I8_PLANES")) {
       if (atoi(ev) != planes_used) continue;
+      a.force_route = planes_used == 5 ? 0 : 1;
+    }
 #endif
     const bool wide = planes_used == 5;                                        // 128 x 128 tiles; six planes: 128 x 64
     const int tj = wide ? 128 : 64;
