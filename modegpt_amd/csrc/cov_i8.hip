@@ -307,11 +307,18 @@ struct SyrkArgs {
 #endif
   const int* route_flag;               // written by i8_depth_kernel: 0 -> five planes, 1 -> six planes, bit 1 set -> the fp64 kernel
   int* route_counts;                   // optional device counters [five planes, six planes, fp64 fallback], += 1 by the launch that runs
-  const int* sched;                    // persistent launch: [ngroups][32] tile codes (bi << 16 | bj, -1 = none); nullptr = one tile per workgroup
+  const int2* sched;                   // persistent launch: [ngroups][32] entries {tile code bi << 16 | bj (-1 = none), k-chunk code
+                                       // (0 = all k-steps; else slot << 10 | Q << 5 | q: chunk q of Q, folded into partial tile `slot`)};
+                                       // nullptr = one tile per workgroup
   int ngroups;
+  double* partial;                     // [slot][128][TJ] fp64 partial tiles of the k-split last round (zeroed per call; i8_tail_combine_kernel)
+  const int4* tail;                    // [n_tail] {tile code, Q, first slot, 0}: the tiles of the split round
   int* xcd_arrive;                     // [8] arrival counters of the round barrier (zeroed per call)
 #ifdef MDG_I8_STAMPS
   unsigned long long* stamps;          // diagnostic build only: per (workgroup, wave) cycle sums of the k-step phases
+#endif
+#ifdef MDG_I8_WGTIMES
+  unsigned long long* wgtimes;         // diagnostic build only: [256][2 + 32] wall clock (100 MHz) at workgroup start / end / after each tile
 #endif
 };
 #ifdef MDG_I8_STAMPS
@@ -365,7 +372,7 @@ constexpr int STAMP_WGS = 1024;
 #define MDG_I8_LOCKSTEP_BARRIER 0   // 1: barrier of an XCD's workgroups between rounds (halves the L2 misses, 2-6 % slower)
 #endif
 #ifndef MDG_I8_LOCKSTEP_MIN_ROWS
-#define MDG_I8_LOCKSTEP_MIN_ROWS 64   // ... this many 128-row blocks (n >= 8192); smaller ones keep one tile per workgroup
+#define MDG_I8_LOCKSTEP_MIN_ROWS 16   // ... this many 128-row blocks (n >= 2048: everything ops.py routes here); below, one tile per workgroup
 #endif
 #ifndef MDG_I8_DEFER
 #define MDG_I8_DEFER 4      // MFMAs a loads-first wave holds back across the barrier (0: 25.3, 2: 26.0, 3: 24.9, 4: 24.6, 5: 25.0, 6: 27.8 ms per call)
@@ -380,9 +387,13 @@ constexpr int NW = 8;     // waves per workgroup
 constexpr int ring_depth(int planes) { return planes == 6 ? 4 : MDG_I8_RING5; }
 
 // One output tile (bi, bj) of the lower region: bi = 128-row block, bj = TJ-row block (bj <= bi for 128 x 128 tiles, bj <= 2 bi + 1
-// for 128 x 64); all k-steps, then the fold into sigma.  `executed` += the MFMAs this wave issued.
+// for 128 x 64); the k-steps [kb, ke), then the fold: element (row, col) of the statistic goes to
+// fold[(row - fold_row0) * fold_ld + col - fold_col0] (sigma itself, or a partial tile of the k-split last round).
+// `executed` += the MFMAs this wave issued.
 template <int P>
-__device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const int bi, const int bj, unsigned char* lds, unsigned& executed) {
+__device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const int bi, const int bj, const int kb, const int ke, double* const fold,
+                                             const int64_t fold_ld, const int fold_row0, const int fold_col0, unsigned char* lds,
+                                             unsigned& executed) {
   constexpr int WB = P == 6 ? 1 : 2;               // 32-row blocks of a wave tile: 64 x 32, or 32 x 32 (96 accumulators at P = 6)
   constexpr int TJ = WB == 2 ? 128 : 64;           // tile columns (rows of the J operand); waves are laid out (128 / 32 WB) x (TJ / 32)
   constexpr int PB = TJ * KS;
@@ -485,14 +496,14 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const int bi, co
     // written as `*p += v` one by one the compiler must keep them in order and every element pays a full memory round trip
 #pragma unroll
     for (int b = 0; b < WB; b++) {  // one 32-row block at a time: 16 loads in flight per lane
-      double* const p = a.sigma + (int64_t)(row0 + b * 32) * a.ld_sigma + col;
+      double* const p = fold + (int64_t)(row0 + b * 32 - fold_row0) * fold_ld + (col - fold_col0);
       const int* const e = a.emax + row0 + b * 32;
       double old[16];
       int er[16];
 #pragma unroll
       for (int reg = 0; reg < 16; reg++) {
         const int off = (reg & 3) + 8 * (reg >> 2);
-        old[reg] = p[(int64_t)off * a.ld_sigma];
+        old[reg] = p[(int64_t)off * fold_ld];
         er[reg] = e[off];
       }
 #pragma unroll
@@ -501,7 +512,7 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const int bi, co
         double v = 0.;
 #pragma unroll
         for (int k = P - 1; k >= 0; k--) v += ldexp((double)acc[k][b][reg], 80 - 8 * k);
-        if (col <= row0 + b * 32 + off) p[(int64_t)off * a.ld_sigma] = old[reg] + v * sc_j * ldexp(1.0, er[reg] - 172);
+        if (col <= row0 + b * 32 + off) p[(int64_t)off * fold_ld] = old[reg] + v * sc_j * ldexp(1.0, er[reg] - 172);
       }
     }
 #pragma unroll
@@ -532,19 +543,19 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const int bi, co
   if (SKIP) {
 #pragma unroll
     for (int i = 0; i < D; i++)
-      if (i < nk) {
+      if (kb + i < ke) {
         unsigned t0, t1;
-        load_masks(i, t0, t1);
+        load_masks(kb + i, t0, t1);
         mA[i] = __builtin_amdgcn_readfirstlane(t0);
         mB[i] = b_half(__builtin_amdgcn_readfirstlane(t1));
       }
-    if (nk > D) load_masks(D, vA, vB);
+    if (ke - kb > D) load_masks(kb + D, vA, vB);
   }
 #pragma unroll
   for (int i = 0; i < D; i++)
-    if (i < nk) issue_stage(i, i, mA[i], mB[i]);
+    if (kb + i < ke) issue_stage(kb + i, i, mA[i], mB[i]);
   wait_loads();
-  int buf = 0;                 // kt % RING
+  int buf = 0;                 // (kt - kb) % RING
 #ifdef MDG_I8_STAMPS
   unsigned long long ta = 0, tb = 0, tc = 0, td = 0, te = 0, s_wait = 0, s_issue = 0, s_comp = 0, s_tail = 0, t_begin;
   MDG_STAMP(t_begin);
@@ -617,8 +628,8 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const int bi, co
   }
   // two loops: the int32 classes are folded into sigma between runs of FLUSH_STEPS k-steps, outside the MFMA loop (a
   // conditional flush inside it makes the compiler shuttle all 160 accumulators between AGPRs and VGPRs every step)
-  for (int k0 = 0; k0 < nk; k0 += FLUSH_STEPS) {
-    const int k1 = min(nk, k0 + FLUSH_STEPS);
+  for (int k0 = kb; k0 < ke; k0 += FLUSH_STEPS) {
+    const int k1 = min(ke, k0 + FLUSH_STEPS);
     // Roles: the two waves of a SIMD take opposite orders inside a k-step.  Waves 4-7 issue their share of stage kt + D right
     // after the barrier and multiply afterwards; waves 0-3 multiply first and issue at the end of the step (after waiting for
     // their previous loads, a whole k-step old by then) -- one wave's ~450 cycles of LDS-DMA issue run under its partner's MFMAs.
@@ -631,8 +642,8 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const int bi, co
           mA[D] = __builtin_amdgcn_readfirstlane(vA);
           mB[D] = b_half(__builtin_amdgcn_readfirstlane(vB));
         }
-        if (kt + D < nk) issue_stage(kt + D, ahead(D), mA[D], mB[D]);
-        if (SKIP && kt + D + 1 < nk) load_masks(kt + D + 1, vA, vB);
+        if (kt + D < ke) issue_stage(kt + D, ahead(D), mA[D], mB[D]);
+        if (SKIP && kt + D + 1 < ke) load_masks(kt + D + 1, vA, vB);
       };
       MDG_STAMP(tb);
       // the unconditional MFMAs of a step, in (s, t, block) order; [lo, hi) selects a run of them
@@ -672,7 +683,7 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const int bi, co
       // next step's fragments: stage kt + 1 has been complete since THIS step's barrier (its loads went out three steps ago
       // and every wave waited for its share before the barrier), so the read latency hides behind the refill / the barrier
       __builtin_amdgcn_sched_barrier(0);   // (not before the MFMAs above are issued: the fragment registers are theirs until then)
-      if (kt + 1 < nk && !(DEFER && loads_first)) load_frags(ahead(1));
+      if (kt + 1 < ke && !(DEFER && loads_first)) load_frags(ahead(1));
       }
       MDG_STAMP(td);
       if (!loads_first) {
@@ -754,13 +765,29 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
   }
   unsigned executed = 0;
   const int lane = threadIdx.x & 63;
+#ifdef MDG_I8_WGTIMES
+  if (a.sched && threadIdx.x == 0) a.wgtimes[blockIdx.x * 64] = wall_clock64();
+#endif
   if (a.sched) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
     for (int round = 0;; round++) {
       const int g = round * 8 + xcd;
       if (g >= a.ngroups) break;
-      const int code = a.sched[g * 32 + slot];
-      if (code >= 0) i8_syrk_tile<P>(a, code >> 16, code & 0xFFFF, lds, executed);
+      const int2 entry = a.sched[g * 32 + slot];
+      const int code = entry.x, chunk = entry.y;
+      if (code >= 0) {
+        const int bi = code >> 16, bj = code & 0xFFFF;
+        if (chunk == 0) {
+          i8_syrk_tile<P>(a, bi, bj, 0, a.nk, a.sigma, a.ld_sigma, 0, 0, lds, executed);
+        } else {   // the last round: k-chunk q of Q of this tile, folded into its own (zeroed) partial tile
+          const int q = chunk & 31, Q = (chunk >> 5) & 31, pslot = chunk >> 10;
+          const int kb = (int)((int64_t)a.nk * q / Q), ke = (int)((int64_t)a.nk * (q + 1) / Q);
+          if (kb < ke) i8_syrk_tile<P>(a, bi, bj, kb, ke, a.partial + (int64_t)pslot * TI * TJ, TJ, bi * TI, bj * TJ, lds, executed);
+        }
+      }
+#ifdef MDG_I8_WGTIMES
+      if (threadIdx.x == 0 && round < 60) a.wgtimes[blockIdx.x * 64 + 2 + round] = wall_clock64();
+#endif
       if (g + 8 >= a.ngroups) break;          // this XCD's last round
 #if MDG_I8_LOCKSTEP_BARRIER
       // round barrier of the XCD's workgroups: for speed only (nothing below depends on it), so the spin is bounded
@@ -809,9 +836,34 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
       bj = tile - bi * (bi + 1);
     }
     if (bi >= a.n / TI || bj * TJ > bi * TI + TI - 1) return;
-    i8_syrk_tile<P>(a, bi, bj, lds, executed);
+    i8_syrk_tile<P>(a, bi, bj, 0, a.nk, a.sigma, a.ld_sigma, 0, 0, lds, executed);
   }
   if (a.mfma_count && lane == 0) atomicAdd(a.mfma_count, (unsigned long long)executed);
+#ifdef MDG_I8_WGTIMES
+  if (a.sched && threadIdx.x == 0) a.wgtimes[blockIdx.x * 64 + 1] = wall_clock64();
+#endif
+}
+
+// The persistent launch's LAST round would keep R = (tiles mod 256) CUs busy for a whole tile while the others idle -- 16 of
+// 256 at sigma_x's shape (528 tiles), 184 at sigma_mlp's (6328).  The schedule (schedule_for) therefore cuts each tile of that
+// round into Q k-chunks -- R Q pieces worked by all CUs in ceil(R Q / 256) short rounds, 16 x 16 in one round resp. 184 x 4 in
+// three -- each folding into its own fp64 partial tile; this kernel then adds a tile's partials to sigma in chunk order (a
+// fixed order: the result stays run-to-run bit-identical).  One workgroup per split tile.
+template <int P>
+__global__ __launch_bounds__(256) void i8_tail_combine_kernel(SyrkArgs a, int n_tail) {
+  constexpr int TJ = P == 6 ? 64 : 128;
+  if (*a.route_flag != (P == 5 ? 0 : 1)) return;     // the product launch of the other route produced the partials, or none did
+  const int4 t = a.tail[blockIdx.x];
+  const int bi = t.x >> 16, bj = t.x & 0xFFFF, Q = t.y;
+  const double* part = a.partial + (int64_t)t.z * TI * TJ;
+  for (int e = threadIdx.x; e < TI * TJ; e += 256) {
+    const int row = bi * TI + e / TJ, col = bj * TJ + e % TJ;
+    if (col > row) continue;
+    double* p = a.sigma + (int64_t)row * a.ld_sigma + col;
+    double v = *p;
+    for (int q = 0; q < Q; q++) v += part[(int64_t)q * TI * TJ + e];
+    *p = v;
+  }
 }
 
 size_t planes_bytes(int64_t T, int64_t n) { return (size_t)NP * (size_t)n * (size_t)ceil_div(T, KS) * KS; }
@@ -827,9 +879,16 @@ size_t zmask_bytes(int64_t T, int64_t n) { return align_up((size_t)ceil_div(T, K
 // groups -- and as few rounds as the tile count allows -- remain.  Built once per (device, tile-row count, tile shape) on the
 // host and kept on the device: a few KB of immutable lookup data, the one allocation the library keeps across calls.
 struct Schedule {
-  int* dev = nullptr;
-  int ngroups = 0;
+  int2* dev = nullptr;     // [ngroups][32] {tile code, k-chunk code}
+  int4* tail = nullptr;    // [n_tail] {tile code, Q, first partial slot, 0}
+  int ngroups = 0, n_tail = 0, pieces = 0;
 };
+#ifndef MDG_I8_TAIL_SPLIT
+#define MDG_I8_TAIL_SPLIT 1     // 0: the last round runs whole tiles on (tiles mod 256) CUs
+#endif
+constexpr int TAIL_MAX_Q = 16;         // k-chunks per tile of the split round(s) (a chunk should stay much longer than the 2-3 k-steps of ring fill)
+constexpr int TAIL_MAX_PIECES = 1024;  // partial tiles (chunks of all split tiles together)
+constexpr size_t PARTIAL_BYTES = (size_t)TAIL_MAX_PIECES * TI * 128 * sizeof(double);   // partial tiles of at most 128 x 128
 
 const Schedule* schedule_for(int rb, int cw) {   // cw: tile columns per 128 features (1: 128 x 128 tiles, 2: 128 x 64)
   static std::mutex mu;
@@ -865,17 +924,55 @@ const Schedule* schedule_for(int rb, int cw) {   // cw: tile columns per 128 fea
     if (small.empty()) hi--;
     if (big.size() == 32) lo++;
   }
-  std::vector<int> table;
-  auto emit = [&](const std::vector<int>& g) {
-    for (int i = 0; i < 32; i++) table.push_back(i < (int)g.size() ? g[i] : -1);
-  };
-  for (auto& g : full) emit(g);
+  std::vector<std::vector<int>> groups(full);        // all groups hold 32 tiles, except possibly the last one
   for (size_t i = 0; i < hi; i++)
-    if (!ragged[i].empty()) emit(ragged[i]);
+    if (!ragged[i].empty()) groups.push_back(ragged[i]);
+  size_t tiles = 0;
+  for (auto& g : groups) tiles += g.size();
+  std::vector<int2> table;
+  std::vector<int4> tail;
+  auto emit = [&](const std::vector<int>& g) {
+    for (int i = 0; i < 32; i++) table.push_back(make_int2(i < (int)g.size() ? g[i] : -1, 0));
+  };
+  const size_t whole_groups = tiles / 256 * 8;        // the full rounds: 8 groups of 32 whole tiles each
+  std::vector<int> rest;                              // tiles of the last, partly filled round
+  for (size_t i = whole_groups; i < groups.size(); i++) rest.insert(rest.end(), groups[i].begin(), groups[i].end());
+  // Q chunks per tile turn the R left-over tiles into R Q pieces worked in ceil(R Q / 256) short rounds of 1 / Q tile each
+  // (+ ~4 % of a tile per round for the ring fill and the fold of a chunk): take the cheapest Q
+  const int R = (int)rest.size();
+  int Q = 1;
+  double best = 1.0;
+  for (int q = 2; q <= TAIL_MAX_Q && R > 0; q++) {
+    if (R * q > TAIL_MAX_PIECES) break;
+    const double cost = (double)((R * q + 255) / 256) * (1.0 / q + 0.04);
+    if (cost < best - 0.02) { best = cost; Q = q; }
+  }
   Schedule sch;
+  if (MDG_I8_TAIL_SPLIT && Q >= 2) {
+    for (size_t i = 0; i < whole_groups; i++) emit(groups[i]);
+    // piece t Q + q = chunk q of tile t; piece p runs in tail round p / 256 on XCD p % 8; its partial tile is slot p
+    const int pieces = R * Q, tail_rounds = (pieces + 255) / 256;
+    std::vector<int2> last((size_t)tail_rounds * 256, make_int2(-1, 0));
+    for (int t = 0; t < R; t++) {
+      tail.push_back(make_int4(rest[t], Q, t * Q, 0));
+      for (int q = 0; q < Q; q++) {
+        const int piece = t * Q + q, idx = piece % 256;
+        last[(size_t)(piece / 256) * 256 + (idx % 8) * 32 + idx / 8] = make_int2(rest[t], (piece << 10) | (Q << 5) | q);
+      }
+    }
+    table.insert(table.end(), last.begin(), last.end());
+    sch.n_tail = (int)tail.size();
+    sch.pieces = pieces;
+  } else {
+    for (auto& g : groups) emit(g);
+  }
   sch.ngroups = (int)(table.size() / 32);
-  if (hipMalloc((void**)&sch.dev, table.size() * sizeof(int)) != hipSuccess) return nullptr;
-  if (hipMemcpy(sch.dev, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  if (hipMalloc((void**)&sch.dev, table.size() * sizeof(int2)) != hipSuccess) return nullptr;
+  if (hipMemcpy(sch.dev, table.data(), table.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  if (!tail.empty()) {
+    if (hipMalloc((void**)&sch.tail, tail.size() * sizeof(int4)) != hipSuccess) return nullptr;
+    if (hipMemcpy(sch.tail, tail.data(), tail.size() * sizeof(int4), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  }
   return &cache.emplace(key, sch).first->second;
 }
 
@@ -887,7 +984,7 @@ using namespace mdg;
 extern "C" size_t mdg_cov_accum_i8_ws_bytes(int64_t n_tokens, int64_t n_feat) {
   if (n_tokens <= 0 || n_feat <= 0) return 0;
   const size_t fallback = mdg_cov_accum_ws_bytes(n_tokens, n_feat, 1);
-  return align_up(planes_bytes(n_tokens, n_feat), 256) + ints_bytes(n_feat) + zmask_bytes(n_tokens, n_feat) + fallback + 256;
+  return align_up(planes_bytes(n_tokens, n_feat), 256) + ints_bytes(n_feat) + zmask_bytes(n_tokens, n_feat) + PARTIAL_BYTES + fallback + 256;
 }
 
 extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat, int64_t ld, double* sigma, int64_t ld_sigma,
@@ -915,7 +1012,8 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
   int* flag = nz_cnt + n;
   unsigned long long* mfma_count = (unsigned long long*)(flag + 2);   // 8-byte aligned (n is a multiple of 128); zeroed below
   unsigned char* zmask = (unsigned char*)emax + ints_bytes(n);
-  void* fb_ws = zmask + zmask_bytes(n_tokens, n);
+  double* partial = (double*)(zmask + zmask_bytes(n_tokens, n));   // (256-byte aligned: every region before it is)
+  void* fb_ws = (char*)partial + PARTIAL_BYTES;
   MDG_HIP(hipMemsetAsync(emax, 0, (size_t)(3 * n + INTS_TAIL) * sizeof(int), st));
   const bool vec = ((uintptr_t)x % 16 == 0) && (ld % 8 == 0);
   {
@@ -948,7 +1046,31 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
   MDG_HIP(hipMemsetAsync(stamps_dev, 0, stamps_n * 8, st));
   a.stamps = stamps_dev;
 #endif
+#ifdef MDG_I8_WGTIMES
+  static unsigned long long* wg_dev = nullptr;
+  if (!wg_dev) MDG_HIP(hipMalloc(&wg_dev, 256 * 64 * 8));
+  MDG_HIP(hipMemsetAsync(wg_dev, 0, 256 * 64 * 8, st));
+  a.wgtimes = wg_dev;
+#endif
   const int rb = n / TI;
+  // large statistics: the persistent launch, one workgroup per CU, tiles from the static schedule
+  const Schedule* sched_of[2] = {nullptr, nullptr};
+#if MDG_I8_LOCKSTEP
+  if (rb >= MDG_I8_LOCKSTEP_MIN_ROWS) {
+    int dev = 0, n_cu = 0;
+    MDG_HIP(hipGetDevice(&dev));
+    MDG_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    if (n_cu == 256)   // 8 XCDs x 32 CUs is what the tables are cut for
+      for (int i = 0; i < 2; i++) sched_of[i] = schedule_for(rb, i + 1);
+  }
+#endif
+  {  // partial tiles of the k-split last round (only one of the two product launches runs: they share the region)
+    size_t zero_bytes = 0;
+    for (int i = 0; i < 2; i++)
+      if (sched_of[i]) zero_bytes = std::max(zero_bytes, (size_t)sched_of[i]->pieces * TI * (i == 0 ? 128 : 64) * sizeof(double));
+    if (zero_bytes) MDG_HIP(hipMemsetAsync(partial, 0, zero_bytes, st));
+  }
+  a.partial = partial;
   if (ev_start) MDG_HIP(hipEventRecord((hipEvent_t)ev_start, st));
   for (int planes_used = 5; planes_used <= 6; planes_used++) {
 #ifdef MDG_EXPERIMENT   // knob of scripts/bench_kernels.py (force one product kernel); compiled out of the product library
@@ -964,28 +1086,24 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
     const int sr = si ? (rb + si - 1) / si : 0, nsb = sr * (sr + 1) / 2;       // super-block rows, super-blocks
     const int tps = wide ? si * si : 2 * si * si;                              // tiles per super-block
     dim3 grid(si ? (unsigned)((nsb + 7) / 8 * 8 * tps) : (unsigned)(wide ? rb * (rb + 1) / 2 : rb * (rb + 1)));
-    // large statistics: the persistent launch, one workgroup per CU, tiles from the lock-step schedule
+    const Schedule* sch = sched_of[wide ? 0 : 1];
     a.sched = nullptr;
+    a.tail = nullptr;
     a.ngroups = 0;
-#if MDG_I8_LOCKSTEP
-    if (rb >= MDG_I8_LOCKSTEP_MIN_ROWS) {
-      int dev = 0, n_cu = 0;
-      MDG_HIP(hipGetDevice(&dev));
-      MDG_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-      const Schedule* sch = n_cu == 256 ? schedule_for(rb, wide ? 1 : 2) : nullptr;   // 8 XCDs x 32 CUs is what the table is cut for
-      if (sch) {
-        a.sched = sch->dev;
-        a.ngroups = sch->ngroups;
-        grid = dim3(256);
-      }
+    if (sch) {
+      a.sched = sch->dev;
+      a.tail = sch->tail;
+      a.ngroups = sch->ngroups;
+      grid = dim3(256);
     }
-#endif
     if (planes_used == 6) {
       MDG_HIP(hipFuncSetAttribute((const void*)i8_syrk_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL((i8_syrk_kernel<6>), grid, dim3(64 * NW), lds, st, a);
+      if (sch && sch->n_tail) hipLaunchKernelGGL((i8_tail_combine_kernel<6>), dim3(sch->n_tail), dim3(256), 0, st, a, sch->n_tail);
     } else {
       MDG_HIP(hipFuncSetAttribute((const void*)i8_syrk_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL((i8_syrk_kernel<5>), grid, dim3(64 * NW), lds, st, a);
+      if (sch && sch->n_tail) hipLaunchKernelGGL((i8_tail_combine_kernel<5>), dim3(sch->n_tail), dim3(256), 0, st, a, sch->n_tail);
     }
     MDG_LAUNCH_CHECK();
   }
@@ -1014,6 +1132,34 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
                         "wait+refill-last %.0f  | whole tile / nk %.0f  mfma/step %.1f  (%ld waves)\n", n, role ? "4-7" : "0-3",
                 sum[role][0] / cnt[role], sum[role][1] / cnt[role], sum[role][2] / cnt[role], sum[role][3] / cnt[role],
                 sum[role][4] / cnt[role], sum[role][5] / cnt[role], cnt[role]);
+  }
+#endif
+#ifdef MDG_I8_WGTIMES
+  {
+    static unsigned long long host[256 * 64];
+    MDG_HIP(hipMemcpyAsync(host, a.wgtimes, sizeof(host), hipMemcpyDeviceToHost, st));
+    MDG_HIP(hipStreamSynchronize(st));
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (int w = 0; w < 256; w++) if (host[w * 64]) { t0 = std::min(t0, host[w * 64]); t1 = std::max(t1, host[w * 64 + 1]); }
+    if (t1) {
+      std::vector<double> ends;
+      double xcd_end[8] = {};
+      for (int w = 0; w < 256; w++) { const double e = (host[w * 64 + 1] - t0) * 1e-5; ends.push_back(e); xcd_end[w & 7] = std::max(xcd_end[w & 7], e); }
+      std::sort(ends.begin(), ends.end());
+      fprintf(stderr, "[wgtimes n=%d] kernel %.3f ms; workgroup end times (ms): min %.3f  p10 %.3f  median %.3f  p90 %.3f  max %.3f; last end per XCD:", n,
+              (t1 - t0) * 1e-5, ends[0], ends[25], ends[128], ends[230], ends[255]);
+      for (int x = 0; x < 8; x++) fprintf(stderr, " %.3f", xcd_end[x]);
+      // time of the last whole round's end and per-round durations of workgroup 0 and of the slowest workgroup
+      int slow = 0;
+      for (int w = 0; w < 256; w++) if (host[w * 64 + 1] > host[slow * 64 + 1]) slow = w;
+      fprintf(stderr, "\n   slowest workgroup %d, its rounds end at (ms):", slow);
+      for (int r = 0; r < 60 && host[slow * 64 + 2 + r]; r++) fprintf(stderr, " %.2f", (host[slow * 64 + 2 + r] - t0) * 1e-5);
+      int fast = 0;
+      for (int w = 0; w < 256; w++) if (host[w * 64 + 1] < host[fast * 64 + 1]) fast = w;
+      fprintf(stderr, "\n   fastest workgroup %d, its rounds end at (ms):", fast);
+      for (int r = 0; r < 60 && host[fast * 64 + 2 + r]; r++) fprintf(stderr, " %.2f", (host[fast * 64 + 2 + r] - t0) * 1e-5);
+      fprintf(stderr, "\n");
+    }
   }
 #endif
   if (used_i8) {   // measurement / test mode: report the route this call took (costs the host a round trip)

@@ -7,5 +7,5 @@ for cfg in "$@"; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -w -DMDG_EXPERIMENT $cfg -c cov_i8.hip -o build/cov_i8.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libmodegpt_hip.so build/*.o
   echo "== $cfg"
-  (cd ../.. && timeout -k 10 200 python3 scripts/bench_kernels.py ${I8_MODE:-covi8 covi8p6} 2>&1 | grep "cov mlp\|cov x\|route\|stamps")
+  (cd ../.. && timeout -k 10 200 python3 scripts/bench_kernels.py ${I8_MODE:-covi8 covi8p6} 2>&1 | grep "cov mlp\|cov x\|route\|stamps\|wgtimes\|slowest\|fastest")
 done

@@ -156,11 +156,17 @@ def test_mlp_rank_selection_is_identical_on_both_routes(ops, dev, kind):
 
 
 @pytest.mark.parametrize("n,T,kind", [(8192, 65504 + 2000, "gaussian"), (8192, 65504 + 2000, "silu_gated"), (8320, 3000, "gaussian"),
-                                      (12416, 2100, "silu_gated"), (8192, 33, "gaussian")])
+                                      (12416, 2100, "silu_gated"), (8192, 33, "gaussian"),
+                                      (4096, 100, "gaussian"), (4096, 33, "silu_gated"), (2944, 5000, "gaussian"),
+                                      (3328, 5 * 65504 + 3000, "gaussian"), (3712, 5 * 65504 + 3000, "silu_gated")])
 def test_persistent_launch_shapes(ops, dev, n, T, kind):
-    """Statistics of 8192 features and more run as the persistent launch (one workgroup per CU working through static tile
+    """Statistics of 2048 features and more run as the persistent launch (one workgroup per CU working through static tile
     lists): the int32 fold boundary inside a tile list (65504 tokens), row-block counts that leave ragged groups along the
-    diagonal (65 and 97 blocks), and a call shorter than the LDS ring is deep."""
+    diagonal (65 and 97 blocks), and a call shorter than the LDS ring is deep.  The tiles of the last, partly filled round are
+    cut into k-chunks that fold into partial tiles (i8_tail_combine_kernel adds them to sigma): 4096 features -> 16 tiles in
+    15 chunks (five planes) / 32 tiles in 7 chunks (six), with 4 or 2 k-steps in the whole call most chunks are EMPTY;
+    2944 features -> 20 tiles in 11 chunks; 3328 / 3712 features -> 95 / 102 tiles in five chunks each, worked in two short
+    rounds, each chunk longer than the int32 fold interval (a partial tile is folded into more than once)."""
     X = (gaussian if kind == "gaussian" else silu_gated)(dev, T, n, 31 + n)
     S8 = torch.zeros(n, n, dtype=F64, device=dev)
     S64 = torch.zeros_like(S8)
