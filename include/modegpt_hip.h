@@ -26,9 +26,10 @@
 extern "C" {
 #endif
 
-#define MDG_ABI_VERSION 4 /* 2: w_dtype on mdg_nystrom_down / mdg_vo_compress, mdg_rope_gather added; 3: mdg_cov_accum_i8_stats added;
+#define MDG_ABI_VERSION 5 /* 2: w_dtype on mdg_nystrom_down / mdg_vo_compress, mdg_rope_gather added; 3: mdg_cov_accum_i8_stats added;
                              4: mdg_cov_accum_i8 chooses its route on the device (route_counts argument, no host synchronisation);
-                                mdg_comm_* / mdg_allgather_layers added */
+                                mdg_comm_* / mdg_allgather_layers added;
+                             5: mdg_potrs_lower takes a workspace (mdg_potrs_lower_ws_bytes) */
 
 enum mdg_status {
   MDG_OK = 0,
@@ -134,10 +135,13 @@ int mdg_gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const void* A, i
  * Replaces torch.linalg.cholesky at compress_mlp.py:20,56. */
 size_t mdg_potrf_inv_diag_elems(int64_t n);
 int mdg_potrf_lower(double* A, int64_t n, int64_t lda, double* inv_diag, void* stream);
-/* X (n x nrhs, ldx, in place) <- (L L^T)^-1 X, by blocked substitution with the inverted diagonal blocks.
+/* X (n x nrhs, ldx, in place) <- (L L^T)^-1 X by blocks of 1024 rows: the diagonal blocks of L are inverted explicitly
+ * (recursive doubling from inv_diag), a block's substitution is one triangular-aware GEMM with that inverse, one rank-1024
+ * GEMM carries its solution on.  ws: mdg_potrs_lower_ws_bytes(n, nrhs) (the block inverses + a second right-hand-side buffer).
  * Replaces torch.cholesky_solve at compress_mlp.py:57. */
+size_t mdg_potrs_lower_ws_bytes(int64_t n, int64_t nrhs);
 int mdg_potrs_lower(const double* L, int64_t n, int64_t ldl, const double* inv_diag, double* X, int64_t nrhs,
-                    int64_t ldx, void* stream);
+                    int64_t ldx, void* ws, size_t ws_bytes, void* stream);
 /* out[j] = ((L L^T)^-1)_jj = || L^-1 e_j ||^2.  ws: mdg_inv_diag_of_spd_ws_bytes(n).
  * Replaces torch.cholesky_inverse + torch.diag at compress_mlp.py:21-23. */
 size_t mdg_chol_inverse_diag_ws_bytes(int64_t n);

@@ -27,7 +27,7 @@ class CovProblem(C.Structure):
                 ("ld_sigma", _i64), ("sigma_batch_stride", _i64)]
 
 
-ABI_VERSION = 4   # include/modegpt_hip.h MDG_ABI_VERSION this binding table was written against
+ABI_VERSION = 5   # include/modegpt_hip.h MDG_ABI_VERSION this binding table was written against
 
 # name -> (restype, argtypes); must list every symbol the header declares (tests/test_abi.py checks it)
 SIGNATURES = {
@@ -48,7 +48,8 @@ SIGNATURES = {
                              _ptr, _i32, _i64, _i64, _i64, _i64, _i64, _i32, _ptr]),
     "mdg_potrf_inv_diag_elems": (_sz, [_i64]),
     "mdg_potrf_lower": (_i32, [_ptr, _i64, _i64, _ptr, _ptr]),
-    "mdg_potrs_lower": (_i32, [_ptr, _i64, _i64, _ptr, _ptr, _i64, _i64, _ptr]),
+    "mdg_potrs_lower_ws_bytes": (_sz, [_i64, _i64]),
+    "mdg_potrs_lower": (_i32, [_ptr, _i64, _i64, _ptr, _ptr, _i64, _i64, _ptr, _sz, _ptr]),
     "mdg_chol_inverse_diag_ws_bytes": (_sz, [_i64]),
     "mdg_chol_inverse_diag": (_i32, [_ptr, _i64, _i64, _ptr, _ptr, _ptr, _sz, _ptr]),
     "mdg_syevj_batched": (_i32, [_ptr, _i64, _i64, _ptr, _ptr, _ptr]),

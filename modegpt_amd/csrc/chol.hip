@@ -27,9 +27,11 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // per column for the inverse (384 barriers, ~200 us: the factorisation was barrier-bound).  Instead the 128 columns go
 // in 8 steps of 16: the 16x16 diagonal sub-block is factorised AND inverted by one wave entirely in registers (lane i
 // owns row i; pivots and multipliers are broadcast with v_readlane, no LDS round trips, no barriers), the 16-wide panel
-// below is solved by multiplying with that inverse (one thread per row), and the rank-16 update of the trailing part
-// is spread over all 16 waves: 3 barriers per step.  inv(L) is then assembled from the 16x16 inverses by three
-// levels of block doubling, X21 = -X22 (L21 X11), with T = L21 X11 parked in the (not yet written) global output.
+// below is solved by multiplying with that inverse, and the rank-16 update of the trailing part is spread over all 16
+// waves: 3 barriers per step.  inv(L) is then assembled from the 16x16 inverses by three levels of block doubling,
+// X21 = -X22 (L21 X11), T = L21 X11 written over L21.  Panel solve, trailing update and both doubling products run as
+// 16 x 16 tiles on v_mfma_f64_16x16x4_f64 straight out of the LDS block (round 1 did them on the VALU, two LDS reads per
+// FMA, T through global memory: 157 us per block, of which the 8 serial 16 x 16 factorisations are ~36).
 __global__ __launch_bounds__(1024) void potrf_diag_kernel(double* A, int64_t lda, int nb, int64_t k0, double* inv,
                                                           int* info) {
   constexpr int PT = 1024, SB = 16;
@@ -38,6 +40,7 @@ __global__ __launch_bounds__(1024) void potrf_diag_kernel(double* A, int64_t lda
   __shared__ double dinv[SB * (SB + 1)];  // inverse of the current 16x16 diagonal sub-block
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mi = lane & 15, kq = lane >> 4;   // v_mfma_f64_16x16x4_f64: A[mi][kq], B[kq][mi], D[kq + 4 reg][mi]
   for (int e = tid; e < NB * NB; e += PT) {
     const int i = e / NB, j = e % NB;
     double v = 0.;
@@ -84,33 +87,39 @@ __global__ __launch_bounds__(1024) void potrf_diag_kernel(double* A, int64_t lda
       }
     }
     __syncthreads();
-    const int o = kb + SB, n2 = NB - o;
-    if (tid < n2) {  // ---- panel: L21 = A21 inv(L11)^T, one thread per row
-      const int i = o + tid;
-      double ar[SB], out[SB];
+    // ---- panel: L21 = A21 inv(L11)^T on the matrix cores, one 16-row tile per wave (the B operand is the zero-padded 16 x 16
+    // inverse: B[k][j] = X[j][k]); in place -- a wave has read its tile before it writes it
+    const int o = kb + SB, nt = (NB - o) / SB;
+    if (wave < nt) {
+      const int r0 = o + wave * SB;
+      d4 acc = (d4){0., 0., 0., 0.};
 #pragma unroll
-      for (int t = 0; t < SB; t++) ar[t] = a[i * DP + kb + t];
-#pragma unroll
-      for (int c = 0; c < SB; c++) {
-        double sacc = 0.;
-#pragma unroll
-        for (int t = 0; t <= c; t++) sacc += ar[t] * dinv[c * (SB + 1) + t];
-        out[c] = sacc;
+      for (int k4 = 0; k4 < SB / 4; k4++) {
+        const int kk = k4 * 4 + kq;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[(r0 + mi) * DP + kb + kk], dinv[mi * (SB + 1) + kk], acc, 0, 0, 0);
       }
 #pragma unroll
-      for (int c = 0; c < SB; c++) a[i * DP + kb + c] = out[c];
+      for (int reg = 0; reg < 4; reg++) a[(r0 + kq + 4 * reg) * DP + kb + mi] = acc[reg];
     }
     __syncthreads();
-    // ---- rank-16 update of the trailing lower triangle: 32 x 32 thread grid striding rows and columns
-    for (int i = tid >> 5; i < n2; i += 32) {
-      const double* ri = a + (o + i) * DP + kb;
-      for (int j = tid & 31; j <= i; j += 32) {
-        const double* rj = a + (o + j) * DP + kb;
-        double sacc = 0.;
+    // ---- rank-16 update of the trailing lower triangle: 16 x 16 tiles dealt to the 16 waves, C -= L21_i L21_j^T
+    const int ntile = nt * (nt + 1) / 2;
+    for (int t = wave; t < ntile; t += PT / 64) {
+      int ti = 0;
+      while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
+      const int tj = t - ti * (ti + 1) / 2;
+      const int ri = o + ti * SB, rj = o + tj * SB;
+      d4 acc;
 #pragma unroll
-        for (int t = 0; t < SB; t++) sacc += ri[t] * rj[t];
-        a[(o + i) * DP + o + j] -= sacc;
+      for (int reg = 0; reg < 4; reg++) acc[reg] = a[(ri + kq + 4 * reg) * DP + rj + mi];
+#pragma unroll
+      for (int k4 = 0; k4 < SB / 4; k4++) {
+        const int kk = k4 * 4 + kq;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[(ri + mi) * DP + kb + kk], a[(rj + mi) * DP + kb + kk], acc, 0, 0, 0);
       }
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++)
+        if (ti != tj || mi <= kq + 4 * reg) a[(ri + kq + 4 * reg) * DP + rj + mi] = acc[reg];   // (the strict upper part holds inv(L))
     }
     __syncthreads();
   }
@@ -118,23 +127,38 @@ __global__ __launch_bounds__(1024) void potrf_diag_kernel(double* A, int64_t lda
     const int i = e / nb, j = e % nb;
     if (j <= i) A[(int64_t)i * lda + j] = a[i * DP + j];
   }
-  // ---- inv(L) by block doubling: diagonal 16x16 inverses are in place (transposed, upper part + xd)
+  // ---- inv(L) by block doubling: diagonal 16x16 inverses are in place (transposed, upper part + xd).  Per level and pair
+  // T = L21 X11 (written over L21: L itself is in global memory by now) and X21 = -X22 T, 16 x 16 tiles on the matrix cores,
+  // one tile per wave (4 / 8 / 16 tiles per level); the triangular operands are read with their zero halves filled in.
   for (int s2 = SB; s2 < NB; s2 *= 2) {
-    const int outs = (NB / (2 * s2)) * s2 * s2;
-    for (int e = tid; e < outs; e += PT) {  // T = L21 X11 -> global scratch (the slot X21 will occupy)
-      const int pr = e / (s2 * s2), r = (e % (s2 * s2)) / s2, c = e % s2;
-      const int C0 = pr * 2 * s2, R0 = C0 + s2;
-      double sacc = a[(R0 + r) * DP + C0 + c] * xd[C0 + c];
-      for (int t = c + 1; t < s2; t++) sacc += a[(R0 + r) * DP + C0 + t] * a[(C0 + c) * DP + C0 + t];
-      inv[(R0 + r) * NB + C0 + c] = sacc;
+    const int tps = s2 / SB, ntile = (NB / (2 * s2)) * tps * tps;
+    const int pr = wave / (tps * tps), rt = (wave % (tps * tps)) / tps, ct = wave % tps;
+    const int C0 = pr * 2 * s2, R0 = C0 + s2;
+    d4 acc = (d4){0., 0., 0., 0.};
+    if (wave < ntile) {
+      const int cj = ct * SB + mi;
+      for (int k4 = ct * (SB / 4); k4 < s2 / 4; k4++) {   // X11 is lower triangular: rows k >= column
+        const int kk = k4 * 4 + kq;
+        const double bv = kk > cj ? a[(C0 + cj) * DP + C0 + kk] : (kk == cj ? xd[C0 + cj] : 0.);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[(R0 + rt * SB + mi) * DP + C0 + kk], bv, acc, 0, 0, 0);
+      }
+    }
+    __syncthreads();   // every tile of T is computed before any of them overwrites L21
+    if (wave < ntile) {
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) a[(R0 + rt * SB + kq + 4 * reg) * DP + C0 + ct * SB + mi] = acc[reg];
     }
     __syncthreads();
-    for (int e = tid; e < outs; e += PT) {  // X21 = -X22 T, stored transposed in the upper part
-      const int pr = e / (s2 * s2), r = (e % (s2 * s2)) / s2, c = e % s2;
-      const int C0 = pr * 2 * s2, R0 = C0 + s2;
-      double sacc = xd[R0 + r] * inv[(R0 + r) * NB + C0 + c];
-      for (int t = 0; t < r; t++) sacc += a[(R0 + t) * DP + R0 + r] * inv[(R0 + t) * NB + C0 + c];
-      a[(C0 + c) * DP + R0 + r] = -sacc;
+    if (wave < ntile) {
+      const int ri = rt * SB + mi;
+      acc = (d4){0., 0., 0., 0.};
+      for (int k4 = 0; k4 < (rt + 1) * (SB / 4); k4++) {   // X22 is lower triangular: columns k <= row
+        const int kk = k4 * 4 + kq;
+        const double av = ri > kk ? a[(R0 + kk) * DP + R0 + ri] : (ri == kk ? xd[R0 + ri] : 0.);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, a[(R0 + kk) * DP + C0 + ct * SB + mi], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) a[(C0 + ct * SB + mi) * DP + R0 + rt * SB + kq + 4 * reg] = -acc[reg];   // X21, transposed
     }
     __syncthreads();
   }
@@ -245,55 +269,17 @@ int potrf_lower(double* A, int64_t n, int64_t lda, double* inv_diag, hipStream_t
   return MDG_OK;
 }
 
-// Blocked substitution with the inverted diagonal blocks, same two levels: rank-128 updates stay inside the current
-// 512-row outer block, one rank-512 update carries the block's solution to everything behind (forward) / before
-// (backward) it.
-int potrs_lower(const double* L, int64_t n, int64_t ldl, const double* inv_diag, double* X, int64_t nrhs,
-                int64_t ldx, hipStream_t st) {
-  for (int64_t J0 = 0; J0 < n; J0 += NBO) {  // L Y = B
-    const int64_t Jend = J0 + NBO < n ? J0 + NBO : n;
-    for (int64_t k0 = J0; k0 < Jend; k0 += NB) {
-      const int64_t nb = n - k0 < NB ? n - k0 : NB;
-      double* Xb = X + k0 * ldx;
-      MDG_TRY(gemm_f64(nb, nrhs, nb, 1.0, inv_diag + (k0 / NB) * NB * NB, MDG_F64, NB, 1, nullptr, Xb, MDG_F64, ldx, 1, 0.0,
-                       Xb, MDG_F64, ldx, 1, 0, 0, 0, 0, st));
-      const int64_t w = Jend - (k0 + nb);
-      if (w > 0)
-        MDG_TRY(gemm_f64(w, nrhs, nb, -1.0, L + (k0 + nb) * ldl + k0, MDG_F64, ldl, 1, nullptr, Xb, MDG_F64, ldx, 1, 1.0,
-                         X + (k0 + nb) * ldx, MDG_F64, ldx, 1, 0, 0, 0, 0, st));
-    }
-    if (n - Jend > 0)
-      MDG_TRY(gemm_f64(n - Jend, nrhs, Jend - J0, -1.0, L + Jend * ldl + J0, MDG_F64, ldl, 1, nullptr, X + J0 * ldx,
-                       MDG_F64, ldx, 1, 1.0, X + Jend * ldx, MDG_F64, ldx, 1, 0, 0, 0, 0, st));
-  }
-  const int64_t last_J0 = ((n - 1) / NBO) * NBO;
-  for (int64_t J0 = last_J0; J0 >= 0; J0 -= NBO) {  // L^T X = Y
-    const int64_t Jend = J0 + NBO < n ? J0 + NBO : n;
-    const int64_t last_k0 = J0 + ((Jend - J0 - 1) / NB) * NB;
-    for (int64_t k0 = last_k0; k0 >= J0; k0 -= NB) {
-      const int64_t nb = n - k0 < NB ? n - k0 : NB;
-      double* Xb = X + k0 * ldx;
-      MDG_TRY(gemm_f64(nb, nrhs, nb, 1.0, inv_diag + (k0 / NB) * NB * NB, MDG_F64, 1, NB, nullptr, Xb, MDG_F64, ldx, 1, 0.0,
-                       Xb, MDG_F64, ldx, 1, 0, 0, 0, 0, st));
-      if (k0 > J0)  // rows of this outer block above the inner block: X[J0:k0] -= L[k0:k0+nb, J0:k0]^T Xb
-        MDG_TRY(gemm_f64(k0 - J0, nrhs, nb, -1.0, L + k0 * ldl + J0, MDG_F64, 1, ldl, nullptr, Xb, MDG_F64, ldx, 1, 1.0,
-                         X + J0 * ldx, MDG_F64, ldx, 1, 0, 0, 0, 0, st));
-    }
-    if (J0 > 0)  // X[0:J0] -= L[J0:Jend, 0:J0]^T X[J0:Jend]
-      MDG_TRY(gemm_f64(J0, nrhs, Jend - J0, -1.0, L + J0 * ldl, MDG_F64, 1, ldl, nullptr, X + J0 * ldx, MDG_F64, ldx, 1,
-                       1.0, X, MDG_F64, ldx, 1, 0, 0, 0, 0, st));
-  }
-  return MDG_OK;
-}
-
-// X = inv(L) by recursive doubling on the block size, then column norms.
-int chol_inverse_diag(const double* L, int64_t n, int64_t ldl, const double* inv_diag, double* out, double* X,
-                      double* T, hipStream_t st) {
+// Triangular inverse by recursive doubling on the block size, starting from the inverted 128-wide diagonal blocks the
+// factorisation left behind: after the level of pair size s, X holds inv of every aligned 2s-wide diagonal block of L.
+// Levels run while s < s_limit: s_limit = n gives X = inv(L); s_limit = NBO the inverses of the NBO-wide diagonal blocks only
+// (potrs_lower).  X is addressed as X[i * ldx + j] for (i, j) inside one diagonal block; with ldx < n the blocks are simply
+// skewed in memory (row i starts at i * ldx, its block's columns at + j): n * ldx + n elements hold them all.
+int tri_inverse_doubling(const double* L, int64_t n, int64_t ldl, const double* inv_diag, double* X, int64_t ldx, double* T,
+                         int64_t s_limit, hipStream_t st) {
   const int64_t nblk = ceil_div(n, NB);
-  const int64_t ldx = n;
   hipLaunchKernelGGL(place_inv_diag_kernel, dim3((unsigned)nblk), dim3(256), 0, st, inv_diag, X, ldx, n);
   MDG_LAUNCH_CHECK();
-  for (int64_t s = NB; s < n; s *= 2) {
+  for (int64_t s = NB; s < n && s < s_limit; s *= 2) {
     // pair p: Cb = [2ps, 2ps+s), R = [2ps+s, min(2ps+2s, n))
     const int64_t full = n / (2 * s);                 // pairs with a complete R
     const int64_t r0_last = full * 2 * s + s;         // a trailing ragged pair exists if r0_last < n
@@ -313,8 +299,52 @@ int chol_inverse_diag(const double* L, int64_t n, int64_t ldl, const double* inv
                        MDG_GEMM_A_LOWER_TRI, st));
     }
   }
+  return MDG_OK;
+}
+
+// X = inv(L), then column norms.
+int chol_inverse_diag(const double* L, int64_t n, int64_t ldl, const double* inv_diag, double* out, double* X,
+                      double* T, hipStream_t st) {
+  const int64_t ldx = n;
+  MDG_TRY(tri_inverse_doubling(L, n, ldl, inv_diag, X, ldx, T, n, st));
   hipLaunchKernelGGL(lower_colnorm2_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, st, X, ldx, n, out);
   MDG_LAUNCH_CHECK();
+  return MDG_OK;
+}
+
+// (L L^T) X = B by blocks of NBO rows.  The substitution inside a block is ONE triangular-aware GEMM with the block's explicit
+// inverse (tri_inverse_doubling up to NBO: ~n NBO^2 / 3 flops, three batched levels), and one rank-NBO GEMM carries the
+// block's solution to everything behind (forward) / before (backward) it.  Round 1 walked the 128-wide diagonal blocks
+// inside every outer block -- 2 x n / 128 steps of a 128-row multiply (32 workgroups) and a thin update, ~85 us a step
+// whatever the flops: 24.5 ms for n = 10035, nrhs = 4096, of which the carries are 12.  Out of place between X and a
+// second right-hand-side buffer: forward X -> W, backward W -> X.
+size_t potrs_ws_elems(int64_t n, int64_t nrhs) {
+  return (size_t)n * NBO + (size_t)n + ((size_t)n * NBO / 4 + NB * NB) + (size_t)n * nrhs;
+}
+
+int potrs_lower(const double* L, int64_t n, int64_t ldl, const double* inv_diag, double* X, int64_t nrhs, int64_t ldx,
+                double* ws, hipStream_t st) {
+  double* Linv = ws;                                   // skewed [n][NBO]: inv of every NBO-wide diagonal block
+  double* T = Linv + (size_t)n * NBO + n;
+  double* W = T + ((size_t)n * NBO / 4 + NB * NB);     // [n][nrhs]
+  MDG_TRY(tri_inverse_doubling(L, n, ldl, inv_diag, Linv, NBO, T, NBO, st));
+  for (int64_t J0 = 0; J0 < n; J0 += NBO) {  // L Y = B:  W_J = inv(L_JJ) X_J;  X[Jend:] -= L[Jend:, J] W_J
+    const int64_t Jend = J0 + NBO < n ? J0 + NBO : n, nbj = Jend - J0;
+    MDG_TRY(gemm_f64(nbj, nrhs, nbj, 1.0, Linv + J0 * NBO + J0, MDG_F64, NBO, 1, nullptr, X + J0 * ldx, MDG_F64, ldx, 1, 0.0,
+                     W + J0 * nrhs, MDG_F64, nrhs, 1, 0, 0, 0, MDG_GEMM_A_LOWER_TRI, st));
+    if (n - Jend > 0)
+      MDG_TRY(gemm_f64(n - Jend, nrhs, nbj, -1.0, L + Jend * ldl + J0, MDG_F64, ldl, 1, nullptr, W + J0 * nrhs, MDG_F64, nrhs,
+                       1, 1.0, X + Jend * ldx, MDG_F64, ldx, 1, 0, 0, 0, 0, st));
+  }
+  const int64_t last_J0 = ((n - 1) / NBO) * NBO;
+  for (int64_t J0 = last_J0; J0 >= 0; J0 -= NBO) {  // L^T X = Y:  X_J = inv(L_JJ)^T W_J;  W[0:J0] -= L[J, 0:J0]^T X_J
+    const int64_t Jend = J0 + NBO < n ? J0 + NBO : n, nbj = Jend - J0;
+    MDG_TRY(gemm_f64(nbj, nrhs, nbj, 1.0, Linv + J0 * NBO + J0, MDG_F64, 1, NBO, nullptr, W + J0 * nrhs, MDG_F64, nrhs, 1, 0.0,
+                     X + J0 * ldx, MDG_F64, ldx, 1, 0, 0, 0, MDG_GEMM_A_UPPER_TRI, st));
+    if (J0 > 0)
+      MDG_TRY(gemm_f64(J0, nrhs, nbj, -1.0, L + J0 * ldl, MDG_F64, 1, ldl, nullptr, X + J0 * ldx, MDG_F64, ldx, 1, 1.0, W,
+                       MDG_F64, nrhs, 1, 0, 0, 0, 0, st));
+  }
   return MDG_OK;
 }
 
@@ -339,11 +369,18 @@ extern "C" int mdg_potrf_lower(double* A, int64_t n, int64_t lda, double* inv_di
   return potrf_lower(A, n, lda, inv_diag, (hipStream_t)stream);
 }
 
+extern "C" size_t mdg_potrs_lower_ws_bytes(int64_t n, int64_t nrhs) {
+  if (n <= 0 || nrhs <= 0) return 0;
+  return potrs_ws_elems(n, nrhs) * sizeof(double);
+}
+
 extern "C" int mdg_potrs_lower(const double* L, int64_t n, int64_t ldl, const double* inv_diag, double* X,
-                               int64_t nrhs, int64_t ldx, void* stream) {
+                               int64_t nrhs, int64_t ldx, void* ws, size_t ws_bytes, void* stream) {
   MDG_CLEAR();
   MDG_CHECK_ARG(L && inv_diag && X && n > 0 && nrhs > 0 && ldl >= n && ldx >= nrhs, "mdg_potrs_lower: bad arguments");
-  return potrs_lower(L, n, ldl, inv_diag, X, nrhs, ldx, (hipStream_t)stream);
+  MDG_CHECK_ARG(ws && ws_bytes >= mdg_potrs_lower_ws_bytes(n, nrhs), "mdg_potrs_lower: workspace %zu < required %zu", ws_bytes,
+                mdg_potrs_lower_ws_bytes(n, nrhs));
+  return potrs_lower(L, n, ldl, inv_diag, X, nrhs, ldx, (double*)ws, (hipStream_t)stream);
 }
 
 extern "C" size_t mdg_chol_inverse_diag_ws_bytes(int64_t n) {

@@ -9,8 +9,9 @@ int gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const void* A, int a
              int c_dtype, int64_t ldc, int64_t batch, int64_t a_bs, int64_t b_bs, int64_t c_bs, int flags,
              hipStream_t st);
 int potrf_lower(double* A, int64_t n, int64_t lda, double* inv_diag, hipStream_t st);
-int potrs_lower(const double* L, int64_t n, int64_t ldl, const double* inv_diag, double* X, int64_t nrhs,
-                int64_t ldx, hipStream_t st);
+int potrs_lower(const double* L, int64_t n, int64_t ldl, const double* inv_diag, double* X, int64_t nrhs, int64_t ldx,
+                double* ws, hipStream_t st);
+size_t potrs_ws_elems(int64_t n, int64_t nrhs);
 int copy_lower(const double* src, int64_t ld_src, const int64_t* idx, double* dst, int64_t ldd, int64_t n,
                double ridge, hipStream_t st);
 }  // namespace mdg
@@ -18,7 +19,7 @@ int copy_lower(const double* src, int64_t ld_src, const int64_t* idx, double* ds
 using namespace mdg;
 
 extern "C" size_t mdg_nystrom_down_ws_bytes(int64_t n, int64_t r, int64_t d) {
-  return ((size_t)r * r + mdg_potrf_inv_diag_elems(r) + (size_t)r * d) * sizeof(double);
+  return ((size_t)r * r + mdg_potrf_inv_diag_elems(r) + (size_t)r * d + potrs_ws_elems(r, d)) * sizeof(double);
 }
 
 extern "C" int mdg_nystrom_down(const double* C, int64_t n, int64_t ldc, const int64_t* idx, int64_t r, const void* Wd,
@@ -35,12 +36,13 @@ extern "C" int mdg_nystrom_down(const double* C, int64_t n, int64_t ldc, const i
   double* Ckk = (double*)ws;
   double* inv = Ckk + (size_t)r * r;
   double* X = inv + mdg_potrf_inv_diag_elems(r);
+  double* solve_ws = X + (size_t)r * d;
   // C_kk + eps I  (lower)                                           compress_mlp.py:52,56
   MDG_TRY(copy_lower(C, ldc, idx, Ckk, r, r, eps, st));
   // cross = C[idx,:] @ W_d^T  -> [r, d]                             compress_mlp.py:54
   MDG_TRY(gemm_f64(r, d, n, 1.0, C, MDG_F64, ldc, 1, idx, Wd, w_dtype, 1, ld_wd, 0.0, X, MDG_F64, d, 1, 0, 0, 0, 0, st));
   MDG_TRY(potrf_lower(Ckk, r, r, inv, st));                       // compress_mlp.py:56
-  MDG_TRY(potrs_lower(Ckk, r, r, inv, X, d, d, st));              // compress_mlp.py:57
+  MDG_TRY(potrs_lower(Ckk, r, r, inv, X, d, d, solve_ws, st));    // compress_mlp.py:57
   if (down_f64) MDG_HIP(hipMemcpyAsync(down_f64, X, (size_t)r * d * sizeof(double), hipMemcpyDeviceToDevice, st));
   // [r, d] fp64 -> [d, r] bf16                                      compress_mlp.py:61,97
   return mdg_cast_transpose_f64_bf16(X, r, d, d, down_out, ld_out, stream);

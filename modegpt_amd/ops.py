@@ -305,9 +305,11 @@ def potrs_lower(L: torch.Tensor, inv: torch.Tensor, X: torch.Tensor) -> None:
     """X <- (L L^T)^-1 X in place."""
     _need_gpu(L, inv, X)
     lib = _lib.load()
+    nbytes = lib.mdg_potrs_lower_ws_bytes(L.shape[0], X.shape[1])
+    ws, wsp = _ws(nbytes, L.device)
     with torch.cuda.device(L.device):
         check(lib.mdg_potrs_lower(L.data_ptr(), L.shape[0], L.stride(0), inv.data_ptr(), X.data_ptr(), X.shape[1],
-                                  X.stride(0), _stream(L)), "mdg_potrs_lower")
+                                  X.stride(0), wsp, nbytes, _stream(L)), "mdg_potrs_lower")
 
 
 def syevj(A: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
