@@ -392,6 +392,12 @@ constexpr int STAMP_WGS = 1024;
 #ifndef MDG_I8_DEFER
 #define MDG_I8_DEFER 4      // MFMAs a loads-first wave holds back across the barrier (0: 25.3, 2: 26.0, 3: 24.9, 4: 24.6, 5: 25.0, 6: 27.8 ms per call)
 #endif
+#ifndef MDG_I8_FOLD_ATOMIC
+#define MDG_I8_FOLD_ATOMIC 0   // 1: fold into sigma with returnless global_atomic_add_f64 instead of load / add / store -- bit-identical
+                               // (scripts/probes/i8_fold_bits.py) and no register spill left, but 0.9 % SLOWER per launch on two boxes
+                               // (21.72 / 22.27 -> 21.91 / 22.46 ms): the folds of different CUs are not synchronised, so their
+                               // latency already hides behind the other CUs' MFMAs, and the kernel is bound by power, not by stalls
+#endif
 #ifndef MDG_I8_ROLES
 #define MDG_I8_ROLES 1  // 0: every wave loads first (the lock-step order of the first versions)
 #endif
@@ -474,7 +480,7 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const int bi, co
   const unsigned lane16 = lane * 16;
   auto issue_stage = [&](int kt, int buf, unsigned mA, unsigned mB) {
     const unsigned long long m64 = ((unsigned long long)mB << 32) | mA;
-    const unsigned lbase = lds_base + buf * STAGE_BYTES;
+    const unsigned lbase = __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_BYTES);   // (wave-uniform; says so to the compiler)
     const unsigned voff = lane16 + (unsigned)kt * 1024u;
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
@@ -513,8 +519,23 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const int bi, co
     for (int b = 0; b < WB; b++) {  // one 32-row block at a time: 16 loads in flight per lane
       double* const p = fold + (int64_t)(row0 + b * 32 - fold_row0) * fold_ld + (col - fold_col0);
       const int* const e = a.emax + row0 + b * 32;
-      double old[16];
       int er[16];
+#if MDG_I8_FOLD_ATOMIC
+      // `+=` as a returnless global_atomic_add_f64: the addition happens at the L2, the workgroup neither waits for the old
+      // values nor holds them in registers.  One tile = one workgroup per launch touches an element, so there is no ordering
+      // to lose: the same correctly rounded fp64 addition, bit for bit.
+#pragma unroll
+      for (int reg = 0; reg < 16; reg++) er[reg] = e[(reg & 3) + 8 * (reg >> 2)];
+#pragma unroll
+      for (int reg = 0; reg < 16; reg++) {
+        const int off = (reg & 3) + 8 * (reg >> 2);
+        double v = 0.;
+#pragma unroll
+        for (int k = P - 1; k >= 0; k--) v += ldexp((double)acc[k][b][reg], 80 - 8 * k);
+        if (col <= row0 + b * 32 + off) unsafeAtomicAdd(p + (int64_t)off * fold_ld, v * sc_j * ldexp(1.0, er[reg] - 172));
+      }
+#else
+      double old[16];
 #pragma unroll
       for (int reg = 0; reg < 16; reg++) {
         const int off = (reg & 3) + 8 * (reg >> 2);
@@ -529,6 +550,7 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const int bi, co
         for (int k = P - 1; k >= 0; k--) v += ldexp((double)acc[k][b][reg], 80 - 8 * k);
         if (col <= row0 + b * 32 + off) p[(int64_t)off * fold_ld] = old[reg] + v * sc_j * ldexp(1.0, er[reg] - 172);
       }
+#endif
     }
 #pragma unroll
     for (int k = 0; k < P; k++)
