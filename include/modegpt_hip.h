@@ -135,8 +135,8 @@ int mdg_gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const void* A, i
  * Replaces torch.linalg.cholesky at compress_mlp.py:20,56. */
 size_t mdg_potrf_inv_diag_elems(int64_t n);
 int mdg_potrf_lower(double* A, int64_t n, int64_t lda, double* inv_diag, void* stream);
-/* X (n x nrhs, ldx, in place) <- (L L^T)^-1 X by blocks of 1024 rows: the diagonal blocks of L are inverted explicitly
- * (recursive doubling from inv_diag), a block's substitution is one triangular-aware GEMM with that inverse, one rank-1024
+/* X (n x nrhs, ldx, in place) <- (L L^T)^-1 X by blocks of 2048 rows: the diagonal blocks of L are inverted explicitly
+ * (recursive doubling from inv_diag), a block's substitution is one triangular-aware GEMM with that inverse, one rank-2048
  * GEMM carries its solution on.  ws: mdg_potrs_lower_ws_bytes(n, nrhs) (the block inverses + a second right-hand-side buffer).
  * Replaces torch.cholesky_solve at compress_mlp.py:57. */
 size_t mdg_potrs_lower_ws_bytes(int64_t n, int64_t nrhs);

@@ -312,34 +312,39 @@ int chol_inverse_diag(const double* L, int64_t n, int64_t ldl, const double* inv
   return MDG_OK;
 }
 
-// (L L^T) X = B by blocks of NBO rows.  The substitution inside a block is ONE triangular-aware GEMM with the block's explicit
-// inverse (tri_inverse_doubling up to NBO: ~n NBO^2 / 3 flops, three batched levels), and one rank-NBO GEMM carries the
+#ifndef MDG_CHOL_NBS
+#define MDG_CHOL_NBS 2048   // (n = 10035, nrhs = 4096: 512 -> 21.9 ms, 1024 -> 18.7, 2048 -> 17.9)
+#endif
+constexpr int NBS = MDG_CHOL_NBS;
+
+// (L L^T) X = B by blocks of NBS rows.  The substitution inside a block is ONE triangular-aware GEMM with the block's explicit
+// inverse (tri_inverse_doubling up to NBS: ~n NBS^2 / 3 flops, log2(NBS / 128) batched levels), and one rank-NBS GEMM carries the
 // block's solution to everything behind (forward) / before (backward) it.  Round 1 walked the 128-wide diagonal blocks
 // inside every outer block -- 2 x n / 128 steps of a 128-row multiply (32 workgroups) and a thin update, ~85 us a step
 // whatever the flops: 24.5 ms for n = 10035, nrhs = 4096, of which the carries are 12.  Out of place between X and a
 // second right-hand-side buffer: forward X -> W, backward W -> X.
 size_t potrs_ws_elems(int64_t n, int64_t nrhs) {
-  return (size_t)n * NBO + (size_t)n + ((size_t)n * NBO / 4 + NB * NB) + (size_t)n * nrhs;
+  return (size_t)n * NBS + (size_t)n + ((size_t)n * NBS / 4 + NB * NB) + (size_t)n * nrhs;
 }
 
 int potrs_lower(const double* L, int64_t n, int64_t ldl, const double* inv_diag, double* X, int64_t nrhs, int64_t ldx,
                 double* ws, hipStream_t st) {
-  double* Linv = ws;                                   // skewed [n][NBO]: inv of every NBO-wide diagonal block
-  double* T = Linv + (size_t)n * NBO + n;
-  double* W = T + ((size_t)n * NBO / 4 + NB * NB);     // [n][nrhs]
-  MDG_TRY(tri_inverse_doubling(L, n, ldl, inv_diag, Linv, NBO, T, NBO, st));
-  for (int64_t J0 = 0; J0 < n; J0 += NBO) {  // L Y = B:  W_J = inv(L_JJ) X_J;  X[Jend:] -= L[Jend:, J] W_J
-    const int64_t Jend = J0 + NBO < n ? J0 + NBO : n, nbj = Jend - J0;
-    MDG_TRY(gemm_f64(nbj, nrhs, nbj, 1.0, Linv + J0 * NBO + J0, MDG_F64, NBO, 1, nullptr, X + J0 * ldx, MDG_F64, ldx, 1, 0.0,
+  double* Linv = ws;                                   // skewed [n][NBS]: inv of every NBS-wide diagonal block
+  double* T = Linv + (size_t)n * NBS + n;
+  double* W = T + ((size_t)n * NBS / 4 + NB * NB);     // [n][nrhs]
+  MDG_TRY(tri_inverse_doubling(L, n, ldl, inv_diag, Linv, NBS, T, NBS, st));
+  for (int64_t J0 = 0; J0 < n; J0 += NBS) {  // L Y = B:  W_J = inv(L_JJ) X_J;  X[Jend:] -= L[Jend:, J] W_J
+    const int64_t Jend = J0 + NBS < n ? J0 + NBS : n, nbj = Jend - J0;
+    MDG_TRY(gemm_f64(nbj, nrhs, nbj, 1.0, Linv + J0 * NBS + J0, MDG_F64, NBS, 1, nullptr, X + J0 * ldx, MDG_F64, ldx, 1, 0.0,
                      W + J0 * nrhs, MDG_F64, nrhs, 1, 0, 0, 0, MDG_GEMM_A_LOWER_TRI, st));
     if (n - Jend > 0)
       MDG_TRY(gemm_f64(n - Jend, nrhs, nbj, -1.0, L + Jend * ldl + J0, MDG_F64, ldl, 1, nullptr, W + J0 * nrhs, MDG_F64, nrhs,
                        1, 1.0, X + Jend * ldx, MDG_F64, ldx, 1, 0, 0, 0, 0, st));
   }
-  const int64_t last_J0 = ((n - 1) / NBO) * NBO;
-  for (int64_t J0 = last_J0; J0 >= 0; J0 -= NBO) {  // L^T X = Y:  X_J = inv(L_JJ)^T W_J;  W[0:J0] -= L[J, 0:J0]^T X_J
-    const int64_t Jend = J0 + NBO < n ? J0 + NBO : n, nbj = Jend - J0;
-    MDG_TRY(gemm_f64(nbj, nrhs, nbj, 1.0, Linv + J0 * NBO + J0, MDG_F64, 1, NBO, nullptr, W + J0 * nrhs, MDG_F64, nrhs, 1, 0.0,
+  const int64_t last_J0 = ((n - 1) / NBS) * NBS;
+  for (int64_t J0 = last_J0; J0 >= 0; J0 -= NBS) {  // L^T X = Y:  X_J = inv(L_JJ)^T W_J;  W[0:J0] -= L[J, 0:J0]^T X_J
+    const int64_t Jend = J0 + NBS < n ? J0 + NBS : n, nbj = Jend - J0;
+    MDG_TRY(gemm_f64(nbj, nrhs, nbj, 1.0, Linv + J0 * NBS + J0, MDG_F64, 1, NBS, nullptr, W + J0 * nrhs, MDG_F64, nrhs, 1, 0.0,
                      X + J0 * ldx, MDG_F64, ldx, 1, 0, 0, 0, MDG_GEMM_A_UPPER_TRI, st));
     if (J0 > 0)
       MDG_TRY(gemm_f64(J0, nrhs, nbj, -1.0, L + J0 * ldl, MDG_F64, 1, ldl, nullptr, X + J0 * ldx, MDG_F64, ldx, 1, 1.0, W,

@@ -6,5 +6,5 @@ for cfg in "$@"; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -w $cfg -c chol.hip -o build/chol.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libmodegpt_hip.so build/*.o
   echo "== $cfg"
-  (cd ../.. && timeout -k 10 200 python3 scripts/bench_kernels.py cov mlp 2>&1 | grep "ridge_scores 1\|nystrom_down")
+  (cd ../.. && timeout -k 10 200 python3 scripts/probes/decomp_phases.py phases 2>&1 | grep "potrf_lower\|potrs")
 done

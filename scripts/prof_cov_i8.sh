@@ -18,4 +18,4 @@ for pass in trace fetch write mfma; do
   rm -rf $OUT
 done
 grep -h "i8_\|cov_accum_kernel" $R/gpurun_out/covi8_trace.csv | grep -v gated_out | cut -c1-200
-grep -h "i8_syrk" $R/gpurun_out/covi8_fetch.csv $R/gpurun_out/covi8_write.csv $R/gpurun_out/covi8_mfma.csv | grep -v gated_out | grep "FETCH\|WRITE\|SQ_\|GRBM" | cut -c1-200
+grep -h "i8_syrk" $R/gpurun_out/covi8_fetch.csv $R/gpurun_out/covi8_write.csv $R/gpurun_out/covi8_mfma.csv | grep ran_long | grep "FETCH\|WRITE\|SQ_\|GRBM" | cut -c1-200

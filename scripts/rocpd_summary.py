@@ -2,7 +2,9 @@
 With a second argument `bygrid`, kernels are additionally split by their grid size (one row per launch shape) and by whether
 the launch did work: mdg_cov_accum_i8 enqueues the five-plane product, the six-plane product and the fp64 kernel for every
 call and the device picks one -- the other launches exit on their first instruction (a few microseconds).  Dispatches shorter
-than GATE_MS are listed as `gated_out` rows so that the averages of the launches that ran are not diluted."""
+than GATE_MS are listed as `gated_out` rows so that the averages of the launches that ran are not diluted.  Since the persistent
+launch gives every product launch the same grid (256 workgroups), the i8_syrk launches that ran are further split by duration:
+`ran_long` (>= LONG_MS: the sigma_mlp-sized statistics) and `ran` (sigma_x-sized)."""
 import sqlite3
 import sys
 
@@ -10,20 +12,23 @@ db = sqlite3.connect(sys.argv[1])
 cur = db.cursor()
 BYGRID = len(sys.argv) > 2 and sys.argv[2] == "bygrid"
 GATE_MS = 0.03
+LONG_MS = 10.0
 GATED = ("(s.kernel_name like '%%i8_syrk_kernel%%' or s.kernel_name like '%%cov_accum_kernel%%') and (d.end-d.start) < %d"
          % int(GATE_MS * 1e6))
+LONG = "s.kernel_name like '%%i8_syrk_kernel%%' and (d.end-d.start) >= %d" % int(LONG_MS * 1e6)
+CLASS = "case when %s then 'gated_out' when %s then 'ran_long' else 'ran' end" % (GATED, LONG)
 if BYGRID:
     print("kernel,grid_x,class,calls,avg_ms,min_ms,max_ms")
-    for r in cur.execute("""select s.kernel_name, d.grid_size_x, case when %s then 'gated_out' else 'ran' end, count(*),
+    for r in cur.execute("""select s.kernel_name, d.grid_size_x, %s, count(*),
             avg(d.end-d.start)/1e6, min(d.end-d.start)/1e6, max(d.end-d.start)/1e6
             from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id=s.id
-            group by 1, 2, 3 order by 5 desc""" % GATED):
+            group by 1, 2, 3 order by 5 desc""" % CLASS):
         print('"%s",%d,%s,%d,%.4f,%.4f,%.4f' % r)
     try:
-        rows = list(cur.execute("""select s.kernel_name, d.grid_size_x, case when %s then 'gated_out' else 'ran' end, p.name,
+        rows = list(cur.execute("""select s.kernel_name, d.grid_size_x, %s, p.name,
             count(distinct d.id), sum(e.value) / count(distinct d.id)
             from rocpd_pmc_event e join rocpd_info_pmc p on e.pmc_id=p.id join rocpd_kernel_dispatch d on e.event_id=d.event_id
-            join rocpd_info_kernel_symbol s on d.kernel_id=s.id group by 1, 2, 3, 4 order by 1, 2, 3, 4""" % GATED))
+            join rocpd_info_kernel_symbol s on d.kernel_id=s.id group by 1, 2, 3, 4 order by 1, 2, 3, 4""" % CLASS))
         if rows:
             print("\nkernel,grid_x,class,counter,dispatches,sum_per_dispatch")
             for r in rows:

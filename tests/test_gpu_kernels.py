@@ -168,7 +168,7 @@ def spd(gen, n, cond_pow=3.0):
     return (Q * lam) @ Q.T
 
 
-@pytest.mark.parametrize("n", [16, 128, 129, 300, 640, 1000, 1024, 1025, 2500])   # (1024: the outer block of the two-level scheme)
+@pytest.mark.parametrize("n", [16, 128, 129, 300, 640, 1000, 1024, 1025, 2048, 2500, 4300])   # (1024 / 2048: the outer blocks of potrf / potrs)
 def test_potrf_potrs(ops, dev, n):
     gen = torch.Generator().manual_seed(n)
     A = spd(gen, n)
