@@ -34,8 +34,10 @@
 //                      32-row group's depth in a k-step (piece masks) are neither written, nor loaded, nor read from LDS, nor
 //                      multiplied: exact, and 28 - 37 % of the MFMAs on SiLU-gated / Gaussian data.  Both instantiations
 //                      and the fp64 kernel are enqueued for every call; the device picks one (each workgroup of the others
-//                      exits on its first instruction).  Statistics of 8192 features and more run as a persistent launch
-//                      (one workgroup per CU, static XCD-grouped tile lists).
+//                      exits on its first instruction).  Statistics of 2048 features and more (everything ops.py sends
+//                      here) run as a persistent launch: one workgroup per CU, static XCD-grouped tile lists, the last, partly
+//                      filled round cut into k-chunks that fold into fp64 partial tiles
+//   i8_tail_combine_kernel<P>  adds the partial tiles of that last round to sigma, in chunk order
 #include <algorithm>
 #include <map>
 #include <mutex>
