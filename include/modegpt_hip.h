@@ -26,10 +26,11 @@
 extern "C" {
 #endif
 
-#define MDG_ABI_VERSION 5 /* 2: w_dtype on mdg_nystrom_down / mdg_vo_compress, mdg_rope_gather added; 3: mdg_cov_accum_i8_stats added;
+#define MDG_ABI_VERSION 6 /* 2: w_dtype on mdg_nystrom_down / mdg_vo_compress, mdg_rope_gather added; 3: mdg_cov_accum_i8_stats added;
                              4: mdg_cov_accum_i8 chooses its route on the device (route_counts argument, no host synchronisation);
                                 mdg_comm_* / mdg_allgather_layers added;
-                             5: mdg_potrs_lower takes a workspace (mdg_potrs_lower_ws_bytes) */
+                             5: mdg_potrs_lower takes a workspace (mdg_potrs_lower_ws_bytes);
+                             6: mdg_cov_accum_i8_multi added (several statistics in one int8 launch); the int8 workspace layout changed */
 
 enum mdg_status {
   MDG_OK = 0,
@@ -104,6 +105,20 @@ int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat, int64_t ld
  * most -- and on real activations well below -- the dense (tiles) x (k-steps) x (waves) x (MFMAs per step).  Copies 8 bytes
  * device -> host on `stream` and synchronises it.  bench.py prices the kernel with this count. */
 int mdg_cov_accum_i8_stats(const void* ws, int64_t n_tokens, int64_t n_feat, unsigned long long* executed_mfma, void* stream);
+/* Up to 4 statistics of ONE calibration batch (the four hooks of a layer) through the int8 digit-plane kernels with ONE
+ * persistent product launch: the tiles of all statistics share one static tile schedule, so the small ones fill what the large
+ * one's last round leaves idle instead of ending launches of their own, and one route -- the deepest any column of any
+ * statistic asks for (more planes are never less exact; if one needs the fp64 kernel, all take it).  `problems` is a HOST array,
+ * largest statistic first, all with the same n_tokens, bf16.  batch == 1: sigma [n_feat][ld_sigma], n_feat a multiple of 128.
+ * batch > 1: per-head Grams of an activation [n_tokens][batch * 128] -- n_feat must be 128, sigma contiguous
+ * [batch][128][128] (ld_sigma 128, sigma_batch_stride 16384); only the diagonal tiles are computed.  Several statistics need a
+ * 256-CU device (the schedule is cut for 8 XCDs x 32 CUs); otherwise call mdg_cov_accum_i8 per statistic.
+ * used_i8 / route_counts / ev_start / ev_stop as in mdg_cov_accum_i8 (route_counts += the number of statistics);
+ * mdg_cov_accum_i8_stats(ws, 0, 0, ...) reads the executed-MFMA count of the whole launch.  mdg_cov_accum_i8 is this call with
+ * one statistic. */
+size_t mdg_cov_accum_i8_multi_ws_bytes(int count, const mdg_cov_problem* problems);
+int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems, void* ws, size_t ws_bytes, int* used_i8, int* route_counts,
+                           void* ev_start, void* ev_stop, void* stream);
 /* sigma[b] <- scale * sigma[b] on the lower triangle, mirrored into the upper.  scale = 1/(n_texts*2048)
  * reproduces calibration.py:141-146. */
 int mdg_cov_finalize(double* sigma, int64_t n, int64_t batch, int64_t ld_sigma, int64_t sigma_batch_stride,

@@ -27,7 +27,7 @@ class CovProblem(C.Structure):
                 ("ld_sigma", _i64), ("sigma_batch_stride", _i64)]
 
 
-ABI_VERSION = 5   # include/modegpt_hip.h MDG_ABI_VERSION this binding table was written against
+ABI_VERSION = 6   # include/modegpt_hip.h MDG_ABI_VERSION this binding table was written against
 
 # name -> (restype, argtypes); must list every symbol the header declares (tests/test_abi.py checks it)
 SIGNATURES = {
@@ -39,6 +39,8 @@ SIGNATURES = {
     "mdg_cov_accum_i8_ws_bytes": (_sz, [_i64, _i64]),
     "mdg_cov_accum_i8": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _i64, _ptr, _sz, C.POINTER(_i32), _ptr, _ptr, _ptr, _ptr]),
     "mdg_cov_accum_i8_stats": (_i32, [_ptr, _i64, _i64, C.POINTER(C.c_ulonglong), _ptr]),
+    "mdg_cov_accum_i8_multi_ws_bytes": (_sz, [_i32, C.POINTER(CovProblem)]),
+    "mdg_cov_accum_i8_multi": (_i32, [_i32, C.POINTER(CovProblem), _ptr, _sz, C.POINTER(_i32), _ptr, _ptr, _ptr, _ptr]),
     "mdg_cov_accum_multi_ws_bytes": (_sz, [_i32, C.POINTER(CovProblem), _i32]),
     "mdg_cov_accum_multi": (_i32, [_i32, C.POINTER(CovProblem), _i32, _ptr, _sz, _ptr]),
     "mdg_cov_finalize": (_i32, [_ptr, _i64, _i64, _i64, _i64, _f64, _ptr]),

@@ -311,20 +311,30 @@ __global__ __launch_bounds__(256) void i8_depth_kernel(const int* deep_cnt, cons
 
 template <int V> struct ic { static constexpr int value = V; };
 
-struct SyrkArgs {
+// One statistic of a launch.  block == 0: sigma is n x n, lower triangle; block == 128: sigma is [n / 128][128][128] (per-head
+// Grams of a [tokens][heads x 128] activation): only the diagonal 128 x 128 tiles exist, element (row, col) of head row / 128
+// lives at sigma[row * ld_sigma + col - 128 (row / 128)] with ld_sigma = 128.
+struct SyrkProblem {
   const signed char* planes;
   const int* emax;
+  const unsigned char* zmask;          // [nk][n / 32] piece masks written by the split pass (write_piece_mask)
   double* sigma;
   int64_t ld_sigma;
-  int n, nk;
-  const unsigned char* zmask;          // [nk][n / 32] piece masks written by the split pass (write_piece_mask)
+  int n, block;
+};
+constexpr int MAX_PROBLEMS = 4;        // the four hooks of a layer: sigma_mlp, sigma_x, sigma_q, sigma_k
+constexpr int CODE_PROB = 28, CODE_BI = 14;   // tile code = problem << 28 | bi << 14 | bj
+
+struct SyrkArgs {
+  SyrkProblem prob[MAX_PROBLEMS];
+  int nprob, nk;
   unsigned long long* mfma_count;      // += v_mfma instructions this launch executed (the dense count is known on the host)
 #ifdef MDG_EXPERIMENT
   int force_route = -1;                // MDG_I8_PLANES=5|6 of scripts/bench_kernels.py: run that product kernel whatever the data say
 #endif
   const int* route_flag;               // written by i8_depth_kernel: 0 -> five planes, 1 -> six planes, bit 1 set -> the fp64 kernel
   int* route_counts;                   // optional device counters [five planes, six planes, fp64 fallback], += 1 by the launch that runs
-  const int2* sched;                   // persistent launch: [ngroups][32] entries {tile code bi << 16 | bj (-1 = none), k-chunk code
+  const int2* sched;                   // persistent launch: [ngroups][32] entries {tile code (-1 = none), k-chunk code
                                        // (0 = all k-steps; else slot << 10 | Q << 5 | q: chunk q of Q, folded into partial tile `slot`)};
                                        // nullptr = one tile per workgroup
   int ngroups;
@@ -414,7 +424,7 @@ constexpr int ring_depth(int planes) { return planes == 6 ? 4 : MDG_I8_RING5; }
 // fold[(row - fold_row0) * fold_ld + col - fold_col0] (sigma itself, or a partial tile of the k-split last round).
 // `executed` += the MFMAs this wave issued.
 template <int P>
-__device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const int bi, const int bj, const int kb, const int ke, double* const fold,
+__device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProblem& pr, const int bi, const int bj, const int kb, const int ke, double* const fold,
                                              const int64_t fold_ld, const int fold_row0, const int fold_col0, unsigned char* lds,
                                              unsigned& executed) {
   constexpr int WB = P == 6 ? 1 : 2;               // 32-row blocks of a wave tile: 64 x 32, or 32 x 32 (96 accumulators at P = 6)
@@ -432,7 +442,7 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const int bi, co
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const bool loads_first = MDG_I8_ROLES ? wave >= NW / 2 : true;
   const int wr = wave / WCOLS, wc = wave % WCOLS;
-  const int64_t groups = a.n / 32;
+  const int64_t groups = pr.n / 32;
   const int nk = a.nk;
 
   // staging: (GA + GB) P pieces of 1 KB per stage (A: P planes x 4 row groups, B: P planes x 2 or 4); wave w issues pieces w, w + NW, ...
@@ -470,7 +480,7 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const int bi, co
 #else
     const int64_t G = (isA ? bi * (TI / 32) : bj * (TJ / 32)) + g;
 #endif
-    const unsigned long long base = (unsigned long long)(uintptr_t)a.planes + (unsigned long long)((s * groups + G) * (int64_t)nk) * 1024ull;
+    const unsigned long long base = (unsigned long long)(uintptr_t)pr.planes + (unsigned long long)((s * groups + G) * (int64_t)nk) * 1024ull;
     pc_base[q] = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(base >> 32)) << 32) |
                  (unsigned)__builtin_amdgcn_readfirstlane((unsigned)base);
     pc_loff[q] = (isA ? s * PA : P * PA + s * PB) + g * 1024;
@@ -514,13 +524,13 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const int bi, co
     // accumulators fill the register file there), and reloaded here behind one s_waitcnt vmcnt(0) each -- which turns the 16
     // sigma loads of a block into 16 serialised memory round trips (26 us per flush and tile, 2 x 0.65 ms per launch)
     asm volatile("" : "+v"(row0));
-    const double sc_j = ldexp(1.0, a.emax[col] - 172);
+    const double sc_j = ldexp(1.0, pr.emax[col] - 172);
     // all read-modify-writes of a lane: loads first (independent, in flight together), then the arithmetic and the stores;
     // written as `*p += v` one by one the compiler must keep them in order and every element pays a full memory round trip
 #pragma unroll
     for (int b = 0; b < WB; b++) {  // one 32-row block at a time: 16 loads in flight per lane
       double* const p = fold + (int64_t)(row0 + b * 32 - fold_row0) * fold_ld + (col - fold_col0);
-      const int* const e = a.emax + row0 + b * 32;
+      const int* const e = pr.emax + row0 + b * 32;
       int er[16];
 #if MDG_I8_FOLD_ATOMIC
       // `+=` as a returnless global_atomic_add_f64: the addition happens at the L2, the workgroup neither waits for the old
@@ -563,9 +573,9 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const int bi, co
   };
 
   // piece masks: uniform-address loads; issued together with a stage's loads, for the stage after it
-  const int64_t mgroups = a.n / 32;
+  const int64_t mgroups = pr.n / 32;
   auto load_masks = [&](int kt, unsigned& va, unsigned& vb) {
-    const unsigned* z = (const unsigned*)(a.zmask + (int64_t)kt * mgroups);   // n / 32 is a multiple of 4: dword-aligned rows
+    const unsigned* z = (const unsigned*)(pr.zmask + (int64_t)kt * mgroups);   // n / 32 is a multiple of 4: dword-aligned rows
     va = z[bi];                                                               // groups 4 bi .. 4 bi + 3
     vb = TJ == 128 ? z[bj] : z[bj >> 1];   // groups 4 bj .. + 3; or 2 bj, 2 bj + 1 in one half of the dword (see b_half)
   };
@@ -797,10 +807,10 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
     const int route = *a.route_flag;
 #endif
     if (route != (P == 5 ? 0 : 1)) {
-      if (P == 6 && (route & 2) && a.route_counts && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.route_counts + 2, 1);
+      if (P == 6 && (route & 2) && a.route_counts && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.route_counts + 2, a.nprob);
       return;
     }
-    if (a.route_counts && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.route_counts + (P == 5 ? 0 : 1), 1);
+    if (a.route_counts && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.route_counts + (P == 5 ? 0 : 1), a.nprob);
   }
   unsigned executed = 0;
   const int lane = threadIdx.x & 63;
@@ -813,15 +823,16 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
       const int g = round * 8 + xcd;
       if (g >= a.ngroups) break;
       const int2 entry = a.sched[g * 32 + slot];
-      const int code = entry.x, chunk = entry.y;
+      const int code = __builtin_amdgcn_readfirstlane(entry.x), chunk = __builtin_amdgcn_readfirstlane(entry.y);
       if (code >= 0) {
-        const int bi = code >> 16, bj = code & 0xFFFF;
-        if (chunk == 0) {
-          i8_syrk_tile<P>(a, bi, bj, 0, a.nk, a.sigma, a.ld_sigma, 0, 0, lds, executed);
+        const SyrkProblem& pr = a.prob[code >> CODE_PROB];   // (uniform index into the kernel arguments: scalar loads)
+        const int bi = (code >> CODE_BI) & ((1 << CODE_BI) - 1), bj = code & ((1 << CODE_BI) - 1);
+        if (chunk == 0) {   // per-head statistics: the tile's columns start at the head's first feature
+          i8_syrk_tile<P>(a, pr, bi, bj, 0, a.nk, pr.sigma, pr.ld_sigma, 0, pr.block ? bi * TI : 0, lds, executed);
         } else {   // the last round: k-chunk q of Q of this tile, folded into its own (zeroed) partial tile
           const int q = chunk & 31, Q = (chunk >> 5) & 31, pslot = chunk >> 10;
           const int kb = (int)((int64_t)a.nk * q / Q), ke = (int)((int64_t)a.nk * (q + 1) / Q);
-          if (kb < ke) i8_syrk_tile<P>(a, bi, bj, kb, ke, a.partial + (int64_t)pslot * TI * TJ, TJ, bi * TI, bj * TJ, lds, executed);
+          if (kb < ke) i8_syrk_tile<P>(a, pr, bi, bj, kb, ke, a.partial + (int64_t)pslot * TI * TJ, TJ, bi * TI, bj * TJ, lds, executed);
         }
       }
 #ifdef MDG_I8_WGTIMES
@@ -874,8 +885,8 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
       while (bi * (bi + 1) > tile) bi--;
       bj = tile - bi * (bi + 1);
     }
-    if (bi >= a.n / TI || bj * TJ > bi * TI + TI - 1) return;
-    i8_syrk_tile<P>(a, bi, bj, 0, a.nk, a.sigma, a.ld_sigma, 0, 0, lds, executed);
+    if (bi >= a.prob[0].n / TI || bj * TJ > bi * TI + TI - 1) return;   // (one full-triangle statistic per launch on this path)
+    i8_syrk_tile<P>(a, a.prob[0], bi, bj, 0, a.nk, a.prob[0].sigma, a.prob[0].ld_sigma, 0, 0, lds, executed);
   }
   if (a.mfma_count && lane == 0) atomicAdd(a.mfma_count, (unsigned long long)executed);
 #ifdef MDG_I8_WGTIMES
@@ -895,14 +906,15 @@ __global__ __launch_bounds__(256) void i8_tail_combine_kernel(SyrkArgs a, int n_
   constexpr int PARTS = TI * TJ / COMBINE_ELEMS;
   if (*a.route_flag != (P == 5 ? 0 : 1)) return;     // the product launch of the other route produced the partials, or none did
   const int4 t = a.tail[blockIdx.x / PARTS];
-  const int bi = t.x >> 16, bj = t.x & 0xFFFF, Q = t.y;
+  const SyrkProblem& pr = a.prob[t.x >> CODE_PROB];
+  const int bi = (t.x >> CODE_BI) & ((1 << CODE_BI) - 1), bj = t.x & ((1 << CODE_BI) - 1), Q = t.y;
   const double* part = a.partial + (int64_t)t.z * TI * TJ;
 #pragma unroll
   for (int i = 0; i < COMBINE_ELEMS / 256; i++) {
     const int e = (blockIdx.x % PARTS) * COMBINE_ELEMS + i * 256 + threadIdx.x;
     const int row = bi * TI + e / TJ, col = bj * TJ + e % TJ;
     if (col > row) continue;
-    double* p = a.sigma + (int64_t)row * a.ld_sigma + col;
+    double* p = pr.sigma + (int64_t)row * pr.ld_sigma + col - (pr.block ? bi * TI : 0);
     double v = *p;
     for (int q = 0; q < Q; q++) v += part[(int64_t)q * TI * TJ + e];   // chunk order: fixed, so the sum is reproducible
     *p = v;
@@ -910,8 +922,6 @@ __global__ __launch_bounds__(256) void i8_tail_combine_kernel(SyrkArgs a, int n_
 }
 
 size_t planes_bytes(int64_t T, int64_t n) { return (size_t)NP * (size_t)n * (size_t)ceil_div(T, KS) * KS; }
-constexpr int INTS_TAIL = 4 + 8;   // flag[2] + mfma count (8 bytes) + the 8 arrival counters of the persistent launch's round barrier
-size_t ints_bytes(int64_t n) { return align_up((size_t)(3 * n + INTS_TAIL) * sizeof(int), 256); }   // emax, deep, nz, then INTS_TAIL
 size_t zmask_bytes(int64_t T, int64_t n) { return align_up((size_t)ceil_div(T, KS) * (size_t)(n / 32), 256); }
 
 
@@ -933,26 +943,47 @@ constexpr int TAIL_MAX_Q = 16;         // k-chunks per tile of the split round(s
 constexpr int TAIL_MAX_PIECES = 1024;  // partial tiles (chunks of all split tiles together)
 constexpr size_t PARTIAL_BYTES = (size_t)TAIL_MAX_PIECES * TI * 128 * sizeof(double);   // partial tiles of at most 128 x 128
 
-const Schedule* schedule_for(int rb, int cw) {   // cw: tile columns per 128 features (1: 128 x 128 tiles, 2: 128 x 64)
+// shapes: per statistic {row blocks of 128 features, block (0 = full lower triangle, 128 = per-head diagonal tiles)}
+const Schedule* schedule_for(const std::vector<std::pair<int, int>>& shapes, int cw) {   // cw: tile columns per 128 features (1: 128 x 128 tiles, 2: 128 x 64)
   static std::mutex mu;
-  static std::map<std::tuple<int, int, int>, Schedule> cache;
+  static std::map<std::vector<int>, Schedule> cache;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   std::lock_guard<std::mutex> lock(mu);
-  auto key = std::make_tuple(dev, rb, cw);
+  std::vector<int> key = {dev, cw};
+  for (auto& sh : shapes) {
+    key.push_back(sh.first);
+    key.push_back(sh.second);
+  }
   auto it = cache.find(key);
   if (it != cache.end()) return &it->second;
   std::vector<std::vector<int>> full, ragged;
-  for (int R = 0; R * 4 < rb; R++) {
-    const int r1 = std::min(rb, R * 4 + 4);
-    const int ncols = r1 * cw;                       // columns of the macro-row's last tile row
-    for (int c0 = 0; c0 < ncols; c0 += 8) {
+  for (size_t pi = 0; pi < shapes.size(); pi++) {
+    const int rb = shapes[pi].first, pbits = (int)pi << CODE_PROB;
+    if (shapes[pi].second) {   // per-head statistic: the diagonal tiles only
       std::vector<int> g;
-      for (int bi = R * 4; bi < r1; bi++)
-        for (int bj = c0; bj < c0 + 8; bj++)
-          if (bj < (bi + 1) * cw) g.push_back((bi << 16) | bj);
-      if (g.size() == 32) full.push_back(g);
-      else if (!g.empty()) ragged.push_back(g);
+      for (int h = 0; h < rb; h++)
+        for (int c = 0; c < cw; c++) {
+          g.push_back(pbits | (h << CODE_BI) | (h * cw + c));
+          if (g.size() == 32) {
+            full.push_back(g);
+            g.clear();
+          }
+        }
+      if (!g.empty()) ragged.push_back(g);
+      continue;
+    }
+    for (int R = 0; R * 4 < rb; R++) {
+      const int r1 = std::min(rb, R * 4 + 4);
+      const int ncols = r1 * cw;                       // columns of the macro-row's last tile row
+      for (int c0 = 0; c0 < ncols; c0 += 8) {
+        std::vector<int> g;
+        for (int bi = R * 4; bi < r1; bi++)
+          for (int bj = c0; bj < c0 + 8; bj++)
+            if (bj < (bi + 1) * cw) g.push_back(pbits | (bi << CODE_BI) | bj);
+        if (g.size() == 32) full.push_back(g);
+        else if (!g.empty()) ragged.push_back(g);
+      }
     }
   }
   std::sort(ragged.begin(), ragged.end(), [](const std::vector<int>& x, const std::vector<int>& y) { return x.size() > y.size(); });
@@ -1019,67 +1050,110 @@ const Schedule* schedule_for(int rb, int cw) {   // cw: tile columns per 128 fea
   return &cache.emplace(key, sch).first->second;
 }
 
+// Workspace layout of a call: [shared block: route flag, executed-MFMA counter, XCD arrival counters][partial tiles]
+// then per statistic [digit planes][column maxima, deep / nonzero counters][piece masks], then the fp64 fallback's split-K space.
+constexpr size_t SHARED_BYTES = 256;
+struct ProblemWs {
+  size_t planes, ints, zmask;   // byte offsets
+};
+size_t layout(int count, const mdg_cov_problem* pr, ProblemWs* out, size_t* fallback_off) {
+  size_t off = SHARED_BYTES + PARTIAL_BYTES, fb = 0;
+  for (int i = 0; i < count; i++) {
+    const int64_t cols = pr[i].n_feat * pr[i].batch;
+    ProblemWs w;
+    w.planes = off;
+    off += align_up(planes_bytes(pr[i].n_tokens, cols), 256);
+    w.ints = off;
+    off += align_up((size_t)(3 * cols) * sizeof(int), 256);
+    w.zmask = off;
+    off += zmask_bytes(pr[i].n_tokens, cols);
+    if (out) out[i] = w;
+    fb = std::max(fb, mdg_cov_accum_ws_bytes(pr[i].n_tokens, pr[i].n_feat, pr[i].batch));
+  }
+  if (fallback_off) *fallback_off = off;
+  return off + fb + 256;
+}
+
+bool problems_ok(int count, const mdg_cov_problem* pr) {
+  if (count < 1 || count > MAX_PROBLEMS || !pr) return false;
+  for (int i = 0; i < count; i++) {
+    if (pr[i].n_tokens != pr[0].n_tokens || pr[i].n_tokens < 0 || pr[i].n_feat <= 0 || pr[i].batch < 1) return false;
+    if (pr[i].batch == 1 ? pr[i].n_feat % TI != 0 : pr[i].n_feat != TI) return false;   // per-head statistics: head_dim 128 only
+    if (pr[i].n_feat * pr[i].batch >= (1 << 21)) return false;
+    if (pr[i].ld < pr[i].n_feat * pr[i].batch || pr[i].ld_sigma < pr[i].n_feat) return false;
+    if (pr[i].batch > 1 && (pr[i].ld_sigma != TI || pr[i].sigma_batch_stride != (int64_t)TI * TI)) return false;
+  }
+  return true;
+}
+
 }  // namespace
 }  // namespace mdg
 
 using namespace mdg;
 
-extern "C" size_t mdg_cov_accum_i8_ws_bytes(int64_t n_tokens, int64_t n_feat) {
-  if (n_tokens <= 0 || n_feat <= 0) return 0;
-  const size_t fallback = mdg_cov_accum_ws_bytes(n_tokens, n_feat, 1);
-  return align_up(planes_bytes(n_tokens, n_feat), 256) + ints_bytes(n_feat) + zmask_bytes(n_tokens, n_feat) + PARTIAL_BYTES + fallback + 256;
+extern "C" size_t mdg_cov_accum_i8_multi_ws_bytes(int count, const mdg_cov_problem* problems) {
+  if (!problems_ok(count, problems) || problems[0].n_tokens == 0) return 0;
+  return layout(count, problems, nullptr, nullptr);
 }
 
-extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat, int64_t ld, double* sigma, int64_t ld_sigma,
-                                void* ws, size_t ws_bytes, int* used_i8, int* route_counts, void* ev_start, void* ev_stop,
-                                void* stream) {
+extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems, void* ws, size_t ws_bytes, int* used_i8,
+                                      int* route_counts, void* ev_start, void* ev_stop, void* stream) {
   MDG_CLEAR();
   if (used_i8) *used_i8 = 0;
-  MDG_CHECK_ARG(n_tokens >= 0 && n_feat > 0, "mdg_cov_accum_i8: bad sizes (tokens=%lld feat=%lld)", (long long)n_tokens,
-                (long long)n_feat);
-  MDG_CHECK_ARG(n_feat % TI == 0, "mdg_cov_accum_i8: n_feat=%lld must be a multiple of %d (use mdg_cov_accum)",
-                (long long)n_feat, TI);
-  MDG_CHECK_ARG(ld >= n_feat && ld_sigma >= n_feat, "mdg_cov_accum_i8: leading dimensions too small");
-  MDG_CHECK_ARG(n_feat < (1 << 24), "mdg_cov_accum_i8: n_feat too large");
+  MDG_CHECK_ARG(problems_ok(count, problems),
+                "mdg_cov_accum_i8_multi: 1..%d statistics of the same token count; full ones need n_feat %% 128 == 0, per-head ones "
+                "head_dim 128 with contiguous [heads][128][128] sigma; leading dimensions at least the widths (use mdg_cov_accum)",
+                MAX_PROBLEMS);
+  const int64_t n_tokens = problems[0].n_tokens;
   if (n_tokens == 0) return MDG_OK;
-  MDG_CHECK_ARG(x && sigma, "mdg_cov_accum_i8: null pointer");
-  const size_t need = mdg_cov_accum_i8_ws_bytes(n_tokens, n_feat);
-  MDG_CHECK_ARG(ws && ws_bytes >= need, "mdg_cov_accum_i8: workspace %zu < required %zu", ws_bytes, need);
+  for (int i = 0; i < count; i++) MDG_CHECK_ARG(problems[i].x && problems[i].sigma, "mdg_cov_accum_i8_multi: null pointer");
+  ProblemWs pw[MAX_PROBLEMS];
+  size_t fb_off = 0;
+  const size_t need = layout(count, problems, pw, &fb_off);
+  MDG_CHECK_ARG(ws && ws_bytes >= need, "mdg_cov_accum_i8_multi: workspace %zu < required %zu", ws_bytes, need);
   hipStream_t st = (hipStream_t)stream;
-  const int n = (int)n_feat;
   const int nk = (int)ceil_div(n_tokens, KS);
-  signed char* planes = (signed char*)ws;
-  int* emax = (int*)((char*)ws + align_up(planes_bytes(n_tokens, n_feat), 256));
-  int* deep_cnt = emax + n;
-  int* nz_cnt = deep_cnt + n;
-  int* flag = nz_cnt + n;
-  unsigned long long* mfma_count = (unsigned long long*)(flag + 2);   // 8-byte aligned (n is a multiple of 128); zeroed below
-  unsigned char* zmask = (unsigned char*)emax + ints_bytes(n);
-  double* partial = (double*)(zmask + zmask_bytes(n_tokens, n));   // (256-byte aligned: every region before it is)
-  void* fb_ws = (char*)partial + PARTIAL_BYTES;
-  MDG_HIP(hipMemsetAsync(emax, 0, (size_t)(3 * n + INTS_TAIL) * sizeof(int), st));
-  const bool vec = ((uintptr_t)x % 16 == 0) && (ld % 8 == 0);
-  {
+  int* flag = (int*)ws;                                               // [0]: route bits;  [2..3]: executed-MFMA counter;  [4..11]: XCD counters
+  unsigned long long* mfma_count = (unsigned long long*)(flag + 2);
+  double* partial = (double*)((char*)ws + SHARED_BYTES);
+  void* fb_ws = (char*)ws + fb_off;
+  MDG_HIP(hipMemsetAsync(flag, 0, SHARED_BYTES, st));
+  SyrkArgs a;
+  a.nprob = count;
+  a.nk = nk;
+  std::vector<std::pair<int, int>> shapes;
+  for (int i = 0; i < count; i++) {
+    const mdg_cov_problem& q = problems[i];
+    const int n = (int)(q.n_feat * q.batch);    // columns of the activation matrix
+    signed char* planes = (signed char*)ws + pw[i].planes;
+    int* emax = (int*)((char*)ws + pw[i].ints);
+    int* deep_cnt = emax + n;
+    int* nz_cnt = deep_cnt + n;
+    unsigned char* zmask = (unsigned char*)ws + pw[i].zmask;
+    MDG_HIP(hipMemsetAsync(emax, 0, (size_t)(3 * n) * sizeof(int), st));
+    const bool vec = ((uintptr_t)q.x % 16 == 0) && (q.ld % 8 == 0);
     const int64_t rows_per_block = 2048;
-    if (vec)
+    if (vec) {
       hipLaunchKernelGGL(i8_colmax_vec_kernel, dim3((unsigned)(n / 128), (unsigned)ceil_div(n_tokens, rows_per_block)), dim3(256), 0,
-                         st, (const bf16_t*)x, ld, n_tokens, rows_per_block, emax);
-    else
+                         st, (const bf16_t*)q.x, q.ld, n_tokens, rows_per_block, emax);
+      hipLaunchKernelGGL(i8_split_vec_kernel, dim3((unsigned)(n / 128), (unsigned)ceil_div(nk, 2)), dim3(256), 0, st,
+                         (const bf16_t*)q.x, q.ld, n_tokens, n, nk, emax, planes, deep_cnt, nz_cnt, zmask);
+    } else {
       hipLaunchKernelGGL(i8_colmax_kernel, dim3((unsigned)ceil_div(n, 64), (unsigned)ceil_div(n_tokens, rows_per_block)), dim3(256),
-                         0, st, (const bf16_t*)x, ld, n_tokens, n, rows_per_block, emax);
+                         0, st, (const bf16_t*)q.x, q.ld, n_tokens, n, rows_per_block, emax);
+      hipLaunchKernelGGL(i8_split_kernel, dim3((unsigned)(n / 32), (unsigned)ceil_div(nk, SPLIT_STEPS)), dim3(256), 0, st,
+                         (const bf16_t*)q.x, q.ld, n_tokens, n, nk, emax, planes, deep_cnt, nz_cnt, zmask);
+    }
+    // every statistic ORs into the same flag: the launch takes the deepest route any of its columns asks for
+    hipLaunchKernelGGL(i8_depth_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, deep_cnt, nz_cnt, emax, n, flag);
+    MDG_LAUNCH_CHECK();
+    a.prob[i] = SyrkProblem{planes, emax, zmask, q.sigma, q.ld_sigma, n, q.batch > 1 ? TI : 0};
+    shapes.emplace_back(n / TI, q.batch > 1 ? TI : 0);
   }
-  if (vec)
-    hipLaunchKernelGGL(i8_split_vec_kernel, dim3((unsigned)(n / 128), (unsigned)ceil_div(nk, 2)), dim3(256), 0, st,
-                       (const bf16_t*)x, ld, n_tokens, n, nk, emax, planes, deep_cnt, nz_cnt, zmask);
-  else
-    hipLaunchKernelGGL(i8_split_kernel, dim3((unsigned)(n / 32), (unsigned)ceil_div(nk, SPLIT_STEPS)), dim3(256), 0, st,
-                       (const bf16_t*)x, ld, n_tokens, n, nk, emax, planes, deep_cnt, nz_cnt, zmask);
-  hipLaunchKernelGGL(i8_depth_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, deep_cnt, nz_cnt, emax, n, flag);
-  MDG_LAUNCH_CHECK();
+  for (int i = count; i < MAX_PROBLEMS; i++) a.prob[i] = a.prob[0];
   // All three routes are enqueued; the flag just written decides on the device which one does the work (the other launches'
   // workgroups exit on their first instruction: ~10 us each at the sigma_mlp grid).  No host round trip, graph-capturable.
-  SyrkArgs a;
-  a.planes = planes; a.emax = emax; a.sigma = sigma; a.ld_sigma = ld_sigma; a.n = n; a.nk = nk; a.zmask = zmask; a.mfma_count = mfma_count;
+  a.mfma_count = mfma_count;
   a.route_flag = flag; a.route_counts = route_counts;
   a.xcd_arrive = flag + 4;
 #ifdef MDG_I8_STAMPS
@@ -1095,18 +1169,22 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
   MDG_HIP(hipMemsetAsync(wg_dev, 0, 256 * 64 * 8, st));
   a.wgtimes = wg_dev;
 #endif
+  const int n = a.prob[0].n;
   const int rb = n / TI;
-  // large statistics: the persistent launch, one workgroup per CU, tiles from the static schedule
+  // the persistent launch: one workgroup per CU, tiles of all statistics from one static schedule
   const Schedule* sched_of[2] = {nullptr, nullptr};
 #if MDG_I8_LOCKSTEP
-  if (rb >= MDG_I8_LOCKSTEP_MIN_ROWS) {
+  if (rb >= MDG_I8_LOCKSTEP_MIN_ROWS || count > 1 || problems[0].batch > 1) {
     int dev = 0, n_cu = 0;
     MDG_HIP(hipGetDevice(&dev));
     MDG_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     if (n_cu == 256)   // 8 XCDs x 32 CUs is what the tables are cut for
-      for (int i = 0; i < 2; i++) sched_of[i] = schedule_for(rb, i + 1);
+      for (int i = 0; i < 2; i++) sched_of[i] = schedule_for(shapes, i + 1);
   }
 #endif
+  MDG_CHECK_ARG((count == 1 && problems[0].batch == 1) || (sched_of[0] && sched_of[1]),
+                "mdg_cov_accum_i8_multi: several statistics in one launch, and per-head statistics, need the persistent launch (a "
+                "256-CU device); use mdg_cov_accum_i8 per full statistic and mdg_cov_accum for the per-head ones");
   {  // partial tiles of the k-split last round (only one of the two product launches runs: they share the region)
     size_t zero_bytes = 0;
     for (int i = 0; i < 2; i++)
@@ -1152,9 +1230,12 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
   }
   if (ev_stop) MDG_HIP(hipEventRecord((hipEvent_t)ev_stop, st));
   // some column is mostly far below its maximum (flag bit 1): six planes do not carry fp64-level accuracy there
-  const int fb = cov_accum_gated(x, MDG_BF16, n_tokens, n_feat, 1, ld, 0, sigma, ld_sigma, 0, fb_ws,
-                                 ws_bytes - (size_t)((char*)fb_ws - (char*)ws), flag, 2, 2, stream);
-  if (fb != MDG_OK) return fb;
+  for (int i = 0; i < count; i++) {
+    const mdg_cov_problem& q = problems[i];
+    const int fb = cov_accum_gated(q.x, MDG_BF16, n_tokens, q.n_feat, q.batch, q.ld, 0, q.sigma, q.ld_sigma, q.sigma_batch_stride, fb_ws,
+                                   ws_bytes - fb_off, flag, 2, 2, stream);
+    if (fb != MDG_OK) return fb;
+  }
 #ifdef MDG_I8_STAMPS
   {
     static unsigned long long host[STAMP_WGS * NW * 8];
@@ -1217,12 +1298,39 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
   return MDG_OK;
 }
 
+static mdg_cov_problem single_problem(const void* x, int64_t n_tokens, int64_t n_feat, int64_t ld, double* sigma, int64_t ld_sigma) {
+  mdg_cov_problem q;
+  q.x = x; q.n_tokens = n_tokens; q.n_feat = n_feat; q.batch = 1; q.ld = ld;
+  q.sigma = sigma; q.ld_sigma = ld_sigma; q.sigma_batch_stride = 0;
+  return q;
+}
+
+extern "C" size_t mdg_cov_accum_i8_ws_bytes(int64_t n_tokens, int64_t n_feat) {
+  if (n_tokens <= 0 || n_feat <= 0) return 0;
+  const mdg_cov_problem q = single_problem(nullptr, n_tokens, n_feat, n_feat, nullptr, n_feat);
+  return mdg_cov_accum_i8_multi_ws_bytes(1, &q);
+}
+
+extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat, int64_t ld, double* sigma, int64_t ld_sigma,
+                                void* ws, size_t ws_bytes, int* used_i8, int* route_counts, void* ev_start, void* ev_stop,
+                                void* stream) {
+  MDG_CLEAR();
+  if (used_i8) *used_i8 = 0;
+  MDG_CHECK_ARG(n_tokens >= 0 && n_feat > 0, "mdg_cov_accum_i8: bad sizes (tokens=%lld feat=%lld)", (long long)n_tokens,
+                (long long)n_feat);
+  MDG_CHECK_ARG(n_feat % TI == 0, "mdg_cov_accum_i8: n_feat=%lld must be a multiple of %d (use mdg_cov_accum)",
+                (long long)n_feat, TI);
+  const mdg_cov_problem q = single_problem(x, n_tokens, n_feat, ld, sigma, ld_sigma);
+  return mdg_cov_accum_i8_multi(1, &q, ws, ws_bytes, used_i8, route_counts, ev_start, ev_stop, stream);
+}
+
 extern "C" int mdg_cov_accum_i8_stats(const void* ws, int64_t n_tokens, int64_t n_feat, unsigned long long* executed_mfma,
                                       void* stream) {
   MDG_CLEAR();
-  MDG_CHECK_ARG(ws && executed_mfma && n_tokens > 0 && n_feat > 0 && n_feat % TI == 0, "mdg_cov_accum_i8_stats: bad arguments");
-  const char* ints = (const char*)ws + align_up(planes_bytes(n_tokens, n_feat), 256);
-  const void* src = ints + (size_t)(3 * n_feat + 2) * sizeof(int);
+  (void)n_tokens;
+  (void)n_feat;
+  MDG_CHECK_ARG(ws && executed_mfma, "mdg_cov_accum_i8_stats: bad arguments");
+  const void* src = (const char*)ws + 2 * sizeof(int);   // the shared block at the start of every int8 workspace
   hipStream_t st = (hipStream_t)stream;
   MDG_HIP(hipMemcpyAsync(executed_mfma, src, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   MDG_HIP(hipStreamSynchronize(st));

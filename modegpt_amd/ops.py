@@ -117,6 +117,57 @@ def cov_accum_i8(sigma: torch.Tensor, x: torch.Tensor, events=None, mfma_stats: 
     return used.value
 
 
+def cov_accum_i8_multi(items, events=None, mfma_stats: Optional[dict] = None, report: bool = False) -> Optional[int]:
+    """Several statistics of ONE calibration batch through the int8 digit-plane kernels in one persistent product launch
+    (mdg_cov_accum_i8_multi): items = sequence of (sigma, x, n_heads), largest first, at most 4, all bf16 with the same token
+    count.  n_heads == 1: sigma [n, n], n a multiple of 128; n_heads > 1: per-head Grams, sigma [n_heads, 128, 128] of an
+    activation [tokens, n_heads * 128].  The tiles of all statistics share one tile schedule -- the small ones fill what the
+    large one's last round leaves idle -- and one route: the deepest any column of any of them asks for (more planes are
+    never less exact).  events / mfma_stats / report as in cov_accum_i8 (the executed / dense counts cover all statistics)."""
+    lib = _lib.load()
+    items = list(items)
+    arr = (_lib.CovProblem * len(items))()
+    dense_shapes = []
+    keep = []
+    for i, (sigma, x, n_heads) in enumerate(items):
+        _need_gpu(sigma, x)
+        if sigma.dtype != torch.float64 or not sigma.is_contiguous():
+            raise ValueError("sigma must be a contiguous float64 tensor")
+        if x.dtype != torch.bfloat16:
+            raise ValueError("cov_accum_i8_multi takes bf16 activations")
+        x2 = x.detach().reshape(-1, x.shape[-1])
+        if x2.stride(-1) != 1:
+            x2 = x2.contiguous()
+        feat = sigma.shape[-1]
+        if sigma.shape[-2] != feat or x2.shape[1] != n_heads * feat or (n_heads > 1 and (sigma.dim() != 3 or sigma.shape[0] != n_heads)):
+            raise ValueError(f"shape mismatch: x {tuple(x.shape)} vs sigma {tuple(sigma.shape)} with n_heads={n_heads}")
+        keep.append(x2)
+        arr[i] = _lib.CovProblem(x2.data_ptr(), x2.shape[0], feat, n_heads, x2.stride(0), sigma.data_ptr(), feat, feat * feat)
+        dense_shapes.append((x2.shape[0], feat, n_heads))
+    dev = keep[0].device
+    nbytes = lib.mdg_cov_accum_i8_multi_ws_bytes(len(items), arr)
+    if nbytes == 0 and keep[0].shape[0] > 0:
+        raise ValueError("these statistics cannot share an int8 launch (token counts differ, widths not multiples of 128, or "
+                         "per-head statistics with head_dim != 128)")
+    ws, wsp = _ws(nbytes, dev)
+    report = report or mfma_stats is not None
+    used = C.c_int(0)
+    with torch.cuda.device(dev):
+        check(lib.mdg_cov_accum_i8_multi(len(items), arr, wsp, nbytes, C.byref(used) if report else None,
+                                         _route_counters(dev).data_ptr(), None if events is None else events[0].cuda_event,
+                                         None if events is None else events[1].cuda_event, _stream(keep[0])),
+              "mdg_cov_accum_i8_multi")
+        if mfma_stats is not None and used.value in (5, 6):
+            done = C.c_ulonglong(0)
+            check(lib.mdg_cov_accum_i8_stats(wsp, 0, 0, C.byref(done), _stream(keep[0])), "mdg_cov_accum_i8_stats")
+            mfma_stats["executed"] = mfma_stats.get("executed", 0) + done.value
+            mfma_stats["dense"] = mfma_stats.get("dense", 0) + sum(i8_dense_mfma_count(t, f, used.value, h) for t, f, h in dense_shapes)
+    if not report:
+        return None
+    I8_STATS[{5: "i8_5", 6: "i8_6"}.get(used.value, "fallback_f64")] += len(items)
+    return used.value
+
+
 _ROUTE_COUNTERS = {}
 
 
@@ -140,12 +191,16 @@ def i8_route_counts(device=None, reset: bool = False) -> dict:
     return {"i8_5": v[0], "i8_6": v[1], "fallback_f64": v[2]}
 
 
-def i8_dense_mfma_count(n_tokens: int, n: int, planes: int) -> int:
+def i8_dense_mfma_count(n_tokens: int, n: int, planes: int, n_heads: int = 1) -> int:
     """v_mfma_i32_32x32x32_i8 instructions of the digit-plane product without zero-plane skipping: every 32 x 32 block of
     the tiles covering the lower triangle (128 x 128 tiles for five planes, 128 x 64 for six; the diagonal tiles whole), per
-    k-step of 32 tokens, planes (planes + 1) / 2 plane pairs."""
+    k-step of 32 tokens, planes (planes + 1) / 2 plane pairs.  n_heads > 1: per-head statistics of width n = 128 each -- one
+    diagonal 128 x 128 tile (16 blocks) per head."""
     rb, nk = n // 128, -(-n_tokens // 32)
-    blocks = rb * (rb + 1) // 2 * 16 if planes == 5 else rb * (rb + 1) * 8
+    if n_heads > 1:
+        blocks = n_heads * 16
+    else:
+        blocks = rb * (rb + 1) // 2 * 16 if planes == 5 else rb * (rb + 1) * 8
     return blocks * nk * (planes * (planes + 1) // 2)
 
 
@@ -161,8 +216,10 @@ def cov_accum_multi(items, mode: Optional[str] = None) -> None:
     """One launch for several covariance problems of the same calibration batch.  items: sequence of
     (sigma, x, n_heads), largest problem first.  Falls back to one cov_accum call per item when the fused kernel's
     preconditions do not hold (mixed dtypes, feature count not a multiple of 128, unaligned rows).
-    mode (default ops.COV_MODE): "i8" sends every single-matrix bf16 problem whose width is a multiple of 128 through
-    cov_accum_i8 and fuses only the rest."""
+    mode (default ops.COV_MODE): "i8" sends every bf16 statistic the int8 digit-plane kernels can take -- single matrices of
+    at least I8_MIN_FEATURES features (a multiple of 128) and, beside one of those, per-head statistics of head_dim 128 --
+    through them: the largest in a launch of its own (cov_accum_i8), the others together in one (cov_accum_i8_multi); only the
+    rest goes through the fp64 kernel."""
     items = [(s_, x_, h_) for (s_, x_, h_) in items if x_.numel() > 0]
     if not items:
         return
@@ -170,29 +227,57 @@ def cov_accum_multi(items, mode: Optional[str] = None) -> None:
     if mode not in ("f64", "i8"):
         raise ValueError(f"covariance mode must be 'f64' or 'i8', got {mode!r}")
     if mode == "i8":
-        rest, planes = [], []
+        rest, planes, heads = [], [], []
         for sigma, x, n_heads in items:
             # below ~2048 features the 128 x 128 tiles do not fill the 256 CUs and the fp64 kernel is the faster one
             # (scripts/probes/i8_small_n.py: 1536 features 1.35 vs 1.23 ms, 2048 features 1.40 vs 2.14 ms)
             if n_heads == 1 and x.dtype == torch.bfloat16 and sigma.dim() == 2 and sigma.shape[-1] % 128 == 0 \
                     and sigma.shape[-1] >= I8_MIN_FEATURES:
-                planes.append((sigma, x))
+                planes.append((sigma, x, 1))
+            elif n_heads > 1 and x.dtype == torch.bfloat16 and sigma.dim() == 3 and sigma.shape[-1] == 128:
+                heads.append((sigma, x, n_heads))      # per-head statistics of head_dim 128: diagonal tiles of the same launch
             else:
                 rest.append((sigma, x, n_heads))
+        tokens = {x.reshape(-1, x.shape[-1]).shape[0] for _, x, _ in planes + heads}
+        group = ((planes[1:] if len(planes) > 1 else planes) + heads) if planes else []
+        if planes and I8_FUSE and len(tokens) == 1 and len(group) <= 4 and _fusable_device(planes[0][1].device):
+            # The largest statistic (sigma_mlp) keeps a launch and a route of its own -- on a real gated MLP it is the heavy-tailed
+            # one (six planes) while the others take five, and a shared launch would drag them along (measured: -2 % on SiLU-gated
+            # data).  Everything else -- sigma_x and the per-head sigma_q / sigma_k tiles -- shares ONE persistent int8 launch: one
+            # tile schedule, one k-split last round, no fp64 launch for the heads.
+            side_rest = rest and COV_OVERLAP_SMALL   # (per-head statistics of another head_dim: fp64 kernel, on a side stream)
+            if side_rest:
+                dev = planes[0][1].device
+                main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    _cov_accum_fused(rest)
+            if len(planes) > 1:
+                cov_accum_i8(planes[0][0], planes[0][1], report=False)
+            if len(group) > 1:
+                cov_accum_i8_multi(group, report=False)
+            else:
+                cov_accum_i8(group[0][0], group[0][1], report=False)
+            if side_rest:
+                main.wait_stream(side)
+            elif rest:
+                _cov_accum_fused(rest)
+            return
+        rest = heads + rest
         if planes and rest and COV_OVERLAP_SMALL:
             # the small fp64 problems (per-head sigma_q / sigma_k) run on a side stream next to the LAST -- smallest -- int8
             # problem, whose few hundred tiles leave CUs idle in their final round; the large problem keeps the chip to itself
-            for sigma, x in planes[:-1]:
+            for sigma, x, _ in planes[:-1]:
                 cov_accum_i8(sigma, x, report=False)
             dev = planes[-1][1].device
             main, side = torch.cuda.current_stream(dev), _side_stream(dev)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 _cov_accum_fused(rest)
-            cov_accum_i8(*planes[-1], report=False)
+            cov_accum_i8(planes[-1][0], planes[-1][1], report=False)
             main.wait_stream(side)       # later work on the caller's stream (and any reuse of these buffers) is ordered after both
             return
-        for sigma, x in planes:
+        for sigma, x, _ in planes:
             cov_accum_i8(sigma, x, report=False)
         items = rest
         if not items:
@@ -201,6 +286,14 @@ def cov_accum_multi(items, mode: Optional[str] = None) -> None:
 
 
 _SIDE_STREAMS = {}
+I8_FUSE = os.environ.get("MODEGPT_I8_FUSE", "1") != "0"      # one int8 launch for all eligible statistics of a batch (cov_accum_i8_multi)
+
+
+def _fusable_device(device) -> bool:
+    """The fused int8 launch is a persistent launch over a tile schedule cut for 8 XCDs x 32 CUs."""
+    return torch.cuda.get_device_properties(device).multi_processor_count == 256
+
+
 COV_OVERLAP_SMALL = os.environ.get("MODEGPT_COV_OVERLAP", "1") != "0"
 
 

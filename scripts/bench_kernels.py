@@ -133,6 +133,18 @@ if "covi8" in which:
     X = acts(T, d); Sx = torch.zeros(d, d, dtype=F64, device=dev)
     t8 = timeit(lambda: ops.cov_accum_i8(Sx, X), n=3); t64 = timeit(lambda: ops.cov_accum(Sx, X), n=3)
     print(f"cov x   {T}x{d}: int8 digit planes {t8*1e3:.2f} ms   fp64 MFMA {t64*1e3:.2f} ms")
+if "covi8fused" in which:
+    # the four statistics of a Llama-3-8B calibration batch in ONE int8 launch (what the hooks enqueue): sigma_mlp, sigma_x, and
+    # the per-head sigma_q / sigma_k as diagonal tiles of the same tile schedule
+    H, X, Q, K = acts(T, d_ff), acts(T, d), acts(T, nh * hd), acts(T, nkv * hd)
+    S = [torch.zeros(d_ff, d_ff, dtype=F64, device=dev), torch.zeros(d, d, dtype=F64, device=dev),
+         torch.zeros(nh, hd, hd, dtype=F64, device=dev), torch.zeros(nkv, hd, hd, dtype=F64, device=dev)]
+    items = [(S[0], H, 1), (S[1], X, 1), (S[2], Q, nh), (S[3], K, nkv)]
+    used = ops.cov_accum_i8_multi(items, report=True)
+    t8 = timeit(lambda: ops.cov_accum_i8_multi(items), n=4)
+    tsep = timeit(lambda: (ops.cov_accum_i8(S[0], H, report=False), ops.cov_accum_i8(S[1], X, report=False),
+                           ops.cov_accum(S[2], Q, n_heads=nh), ops.cov_accum(S[3], K, n_heads=nkv)), n=4)
+    print(f"cov fused int8 launch (mlp + x + q + k, route {used}): {t8*1e3:.2f} ms   the same four as separate launches (two int8, two fp64): {tsep*1e3:.2f} ms")
 if "covi8p6" in which:
     # SiLU-gated activations (the MLP statistic of a real Llama): the depth statistic picks six planes
     gg = torch.randn(T, d_ff, device=dev, generator=g); uu = torch.randn(T, d_ff, device=dev, generator=g)

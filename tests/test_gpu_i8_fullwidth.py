@@ -178,3 +178,96 @@ def test_persistent_launch_shapes(ops, dev, n, T, kind):
     low = torch.tril(torch.ones(n, n, dtype=torch.bool, device=dev))
     ref = S64 * 2
     assert entrywise_err(S8, ref) < 1e-12 and bool(torch.isfinite(S8[low]).all())
+
+
+def _fused_case(ops, dev, widths, heads, T, kind_first, seed):
+    """(sigma_i8 list, sigma_f64 list, route) of one fused call: full statistics of `widths` (the first one of kind
+    `kind_first`, the others Gaussian) + per-head statistics `heads` = [n_heads, ...] of head_dim 128."""
+    items, refs = [], []
+    for i, n in enumerate(widths):
+        X = (silu_gated if (i == 0 and kind_first == "silu_gated") else gaussian)(dev, T, n, seed + i)
+        items.append((torch.zeros(n, n, dtype=F64, device=dev), X, 1))
+    for j, nh in enumerate(heads):
+        X = gaussian(dev, T, nh * 128, seed + 10 + j)
+        items.append((torch.zeros(nh, 128, 128, dtype=F64, device=dev), X, nh))
+    for sigma, X, nh in items:
+        R = torch.zeros_like(sigma)
+        ops.cov_accum(R, X, n_heads=nh)
+        refs.append(R)
+    route = ops.cov_accum_i8_multi(items, report=True)
+    return items, refs, route
+
+
+def _check_against(S, R):
+    if S.dim() == 2:
+        assert entrywise_err(S, R) < 1e-12
+    else:
+        for h in range(S.shape[0]):
+            assert entrywise_err(S[h], R[h]) < 1e-12, h
+
+
+@pytest.mark.parametrize("widths,heads,T,kind,planes", [
+    ([4096, 2048], [8, 2], 5000, "gaussian", 5),            # 528 + 136 + 8 + 2 tiles of 128 x 128, k-split tail across statistics
+    ([4096, 2048], [8, 2], 5000, "silu_gated", 6),          # the gated statistic takes every other one to six planes
+    ([2048], [32], 700, "gaussian", None),                  # (few tokens: some column's deep share may pass 1 / 64 -> either route)
+    ([14336, 4096], [32, 8], 32768, "gaussian", 5),         # the four hooks of a Llama-3-8B layer, one calibration batch
+    ([14336, 4096], [32, 8], 32768, "silu_gated", 6),
+    ([3328], [3], 2 * 65504 + 100, "gaussian", 5),          # across two int32 folds
+])
+def test_fused_int8_launch_of_a_layers_statistics(ops, dev, widths, heads, T, kind, planes):
+    """mdg_cov_accum_i8_multi: sigma_mlp, sigma_x and the per-head sigma_q / sigma_k (head_dim 128: diagonal tiles only) of one
+    batch in ONE persistent launch over a shared tile schedule, one route for all.  Every statistic against the v_mfma_f64
+    kernel entry-wise (1e-12), a second call doubling the result, and the device route counters advancing by the number of
+    statistics."""
+    ops.i8_route_counts(dev, reset=True)
+    items, refs, route = _fused_case(ops, dev, widths, heads, T, kind, 900 + T % 97)
+    assert route == planes or (planes is None and route in (5, 6))
+    planes = route
+    for (S, _, _), R in zip(items, refs):
+        _check_against(S, R)
+    ops.cov_accum_i8_multi(items, report=False)
+    for (S, _, _), R in zip(items, refs):
+        _check_against(S, 2 * R)
+    counts = ops.i8_route_counts(dev, reset=True)
+    assert counts[{5: "i8_5", 6: "i8_6"}[planes]] == 2 * len(items) and sum(counts.values()) == 2 * len(items)
+
+
+def test_fused_int8_launch_falls_back_as_a_whole(ops, dev):
+    """One column dominated by a single massive activation sends the WHOLE fused call to the fp64 kernel: every statistic then
+    equals ops.cov_accum's result bit for bit."""
+    T = 3000
+    Xa = gaussian(dev, T, 2048, 5)
+    Xb = gaussian(dev, T, 2048, 6).clone()
+    Xb[:, 17] = (Xb[:, 17].float() * 1e-6).to(torch.bfloat16)
+    Xb[5, 17] = 300.0
+    Xq = gaussian(dev, T, 4 * 128, 7)
+    items = [(torch.zeros(2048, 2048, dtype=F64, device=dev), Xa, 1), (torch.zeros(2048, 2048, dtype=F64, device=dev), Xb, 1),
+             (torch.zeros(4, 128, 128, dtype=F64, device=dev), Xq, 4)]
+    assert ops.cov_accum_i8_multi(items, report=True) == 0
+    for S, X, nh in items:
+        R = torch.zeros_like(S)
+        ops.cov_accum(R, X, n_heads=nh)
+        assert torch.equal(S, R)
+
+
+def test_cov_accum_multi_routes_a_llama_layer(ops, dev, monkeypatch):
+    """ops.cov_accum_multi in "i8" mode (what the adapter hooks call): sigma_mlp in a launch and on a route of its own (six
+    planes on SiLU-gated data), sigma_x + sigma_q + sigma_k together in one cov_accum_i8_multi launch (five planes); with
+    MODEGPT_I8_FUSE off the per-head statistics go through the fp64 kernel instead -- same results to 1e-12."""
+    T, f, d, nh, nkv = 4096, 4096, 2048, 8, 2
+    H, X, Q, K = silu_gated(dev, T, f, 1), gaussian(dev, T, d, 2), gaussian(dev, T, nh * 128, 3), gaussian(dev, T, nkv * 128, 4)
+
+    def run(fuse):
+        monkeypatch.setattr(ops, "I8_FUSE", fuse)
+        S = [torch.zeros(f, f, dtype=F64, device=dev), torch.zeros(d, d, dtype=F64, device=dev),
+             torch.zeros(nh, 128, 128, dtype=F64, device=dev), torch.zeros(nkv, 128, 128, dtype=F64, device=dev)]
+        ops.i8_route_counts(dev, reset=True)
+        ops.cov_accum_multi([(S[0], H, 1), (S[1], X, 1), (S[2], Q, nh), (S[3], K, nkv)], mode="i8")
+        return S, ops.i8_route_counts(dev, reset=True)
+
+    fused, c1 = run(True)
+    apart, c0 = run(False)
+    assert c1 == {"i8_5": 3, "i8_6": 1, "fallback_f64": 0}        # sigma_mlp alone on six planes; x, q, k share a five-plane launch
+    assert c0 == {"i8_5": 1, "i8_6": 1, "fallback_f64": 0}        # separate launches: sigma_mlp six planes, sigma_x five, heads fp64
+    for a, b in zip(fused, apart):
+        _check_against(a, b)
