@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 passes over the fused int8 digit-plane covariance launch of a Llama-3-8B calibration batch (scripts/bench_kernels.py covi8fused):
+# rocprofv3 passes over the int8 digit-plane covariance at the Llama-3-8B sigma_mlp shape (scripts/bench_kernels.py covi8: sigma_mlp launches, then sigma_x ones):
 #   trace: --kernel-trace --stats     fetch / write: --pmc FETCH_SIZE / WRITE_SIZE (HBM bytes)    mfma: MFMA busy counters
 export TMPDIR=/tmp
 R=$PWD
@@ -13,7 +13,7 @@ for pass in trace fetch write mfma; do
     write) ARGS="--kernel-trace --pmc WRITE_SIZE" ;;
     mfma)  ARGS="--kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT" ;;
   esac
-  timeout -k 10 200 rocprofv3 $ARGS -d $OUT -o p -- python3 scripts/bench_kernels.py covi8fused > $OUT.log 2>&1 || exit 1
+  timeout -k 10 200 rocprofv3 $ARGS -d $OUT -o p -- python3 scripts/bench_kernels.py covi8 > $OUT.log 2>&1 || exit 1
   python3 scripts/rocpd_summary.py $(ls $OUT/*.db | head -1) bygrid > $R/gpurun_out/covi8_$pass.csv || exit 1
   rm -rf $OUT
 done
