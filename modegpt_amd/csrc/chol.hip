@@ -11,6 +11,8 @@ int gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const void* A, int a
              int c_dtype, int64_t ldc, int64_t batch, int64_t a_bs, int64_t b_bs, int64_t c_bs, int flags,
              hipStream_t st);
 
+__device__ __forceinline__ int64_t ceil_div_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
 constexpr int NB = 128;
 constexpr int DP = NB + 1;  // LDS pitch (fp64) of the diagonal block: odd pitch -> conflict-free column walks
 
@@ -173,6 +175,87 @@ __global__ __launch_bounds__(1024) void potrf_diag_kernel(double* A, int64_t lda
   }
 }
 
+// The two short products of an inner step, as LDS-resident 128 x 128 x 128 tiles (K = the 128 columns of block k):
+//   MODE 0, panel solve   L(i, k) = A(i, k) inv(L_kk)^T                         one workgroup per 128-row tile i, in place
+//   MODE 1, rank-128 update   A(i, c) -= L(i, k) L(c, k)^T   for the panel's remaining columns c    one workgroup per tile (i, c)
+// The A operand (128 x 128) is loaded into LDS in one go, the B operand is read from L2 as MFMA fragments, 16 waves x 4 tiles
+// of 16 x 16, 32 v_mfma_f64_16x16x4_f64 steps over k in ascending order and v = -acc + C at the end: the arithmetic of the
+// general GEMM's tile code, bit for bit (scripts/probes/potrf_bits.py) -- but that kernel walks K in 8 serial 16-deep stages
+// behind an offset-table prologue: 38 us for the panel solve and 60 - 100 us for the update whatever their size, 2 x 191
+// launches on a layer's critical path.
+template <int MODE>
+__global__ __launch_bounds__(1024) void potrf_tile_kernel(double* A, int64_t lda, int64_t r0, int64_t nrows, int64_t k0, int64_t c0,
+                                                          int64_t ncols, const double* inv) {
+  constexpr int PT = 1024, SB = 16;
+  __shared__ double a[NB * DP];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mi = lane & 15, kq = lane >> 4;
+  const int64_t ctiles = MODE == 1 ? ceil_div_dev(ncols, NB) : 1;
+  const int64_t ti = blockIdx.x / ctiles, tc = blockIdx.x % ctiles;
+  const int64_t row0 = r0 + ti * NB, col0 = c0 + tc * NB;
+  if (MODE == 1 && row0 + NB - 1 < col0) return;             // entirely above the diagonal: nothing there is ever read
+  const int nr = (int)(r0 + nrows - row0 < NB ? r0 + nrows - row0 : NB);
+  const int nc = MODE == 1 ? (int)(c0 + ncols - col0 < NB ? c0 + ncols - col0 : NB) : NB;
+  double* Ai = A + row0 * lda + k0;                           // A operand: rows of tile i, the 128 columns of block k
+  const double* Bp = MODE == 1 ? A + col0 * lda + k0 : inv;   // B[k][j] = Bp[j * ldb + k]: rows of L(c, k), or of inv(L_kk)
+  const int64_t ldb = MODE == 1 ? lda : NB;
+  for (int e = tid; e < NB * NB; e += PT) {
+    const int i = e / NB, j = e % NB;
+    a[i * DP + j] = i < nr ? Ai[(int64_t)i * lda + j] : 0.;
+  }
+  const int ct = wave & 7, rt0 = (wave >> 3) * 4;             // wave -> column tile ct, four row tiles
+  const int bcol = ct * SB + mi;
+  double cold[4][4];
+  if (MODE == 1) {
+    double* C = A + row0 * lda + col0;
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) {
+        const int row = (rt0 + t) * SB + kq + 4 * reg;
+        cold[t][reg] = (row < nr && bcol < nc) ? C[(int64_t)row * lda + bcol] : 0.;
+      }
+  }
+  __syncthreads();
+  d4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) acc[t] = (d4){0., 0., 0., 0.};
+  // the wave's B fragments, 8 k-steps per batch of loads (one round trip to L2 per batch instead of one per step; 16 waves of
+  // 1024 threads leave 128 registers per lane, so not all 32 at once)
+  constexpr int KB = 8;
+  for (int kb = 0; kb < NB / 4; kb += KB) {
+    double bv[KB];
+#pragma unroll
+    for (int u = 0; u < KB; u++) bv[u] = bcol < nc ? Bp[(int64_t)bcol * ldb + (kb + u) * 4 + kq] : 0.;
+#pragma unroll
+    for (int u = 0; u < KB; u++) {
+      const int kk = (kb + u) * 4 + kq;
+#pragma unroll
+      for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[((rt0 + t) * SB + mi) * DP + kk], bv[u], acc[t], 0, 0, 0);
+    }
+  }
+  if (MODE == 0) {
+    __syncthreads();   // (in place: every wave has read its rows before any is overwritten -- other waves' rows are in LDS only)
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) {
+        const int row = (rt0 + t) * SB + kq + 4 * reg;
+        if (row < nr) Ai[(int64_t)row * lda + bcol] = acc[t][reg];
+      }
+  } else {
+    double* C = A + row0 * lda + col0;
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) {
+        const int row = (rt0 + t) * SB + kq + 4 * reg;
+        if (row < nr && bcol < nc) C[(int64_t)row * lda + bcol] = -1.0 * acc[t][reg] + 1.0 * cold[t][reg];
+      }
+  }
+}
+
 // dst lower triangle (incl. diagonal) = src + ridge*I ; optional row/col gather through idx.
 __global__ __launch_bounds__(256) void copy_lower_kernel(const double* src, int64_t lds_, const int64_t* idx, double* dst,
                                                          int64_t ldd, int64_t n, double ridge) {
@@ -224,6 +307,9 @@ static int read_flag(int* dflag, hipStream_t st, int* host) {
 // panel.  Outer level: one rank-512 lower-only update of everything behind the outer panel.  A rank-128 update of a
 // 128x128 fp64 tile moves 512 KB for 4.2 MFLOP (8 flop/B: HBM-bound at ~30 TF); rank-512 quadruples the intensity
 // and puts the bulk of the n^3/3 flops back under the MFMA roof.
+#ifndef MDG_CHOL_TILE_KERNELS
+#define MDG_CHOL_TILE_KERNELS 1   // panel solve and rank-128 update as LDS-resident 128^3 tiles (potrf_tile_kernel) instead of the general GEMM
+#endif
 #ifndef MDG_CHOL_NBO
 #define MDG_CHOL_NBO 1024   // (512: 63.0 + 72.2 ms for the ridge scores + Nystrom solve of a Llama-3-8B layer; 1024: 62.5 + 69.7; 256: 66.4 + 76.3)
 #endif
@@ -243,14 +329,25 @@ int potrf_lower(double* A, int64_t n, int64_t lda, double* inv_diag, hipStream_t
       const int64_t rest = n - k0 - nb;
       if (rest <= 0) break;
       double* A21 = A + (k0 + nb) * lda + k0;
+      const int64_t w = Jend - (k0 + nb);
+#if MDG_CHOL_TILE_KERNELS
+      // L21 = A21 * inv(L11)^T, then the rank-128 update of the remaining columns of this outer panel only (nb == 128 here: a
+      // ragged block is the last one and has nothing below it)
+      hipLaunchKernelGGL(potrf_tile_kernel<0>, dim3((unsigned)ceil_div(rest, NB)), dim3(1024), 0, st, A, lda, k0 + nb, rest, k0,
+                         (int64_t)0, (int64_t)0, inv);
+      if (w > 0)
+        hipLaunchKernelGGL(potrf_tile_kernel<1>, dim3((unsigned)(ceil_div(rest, NB) * ceil_div(w, NB))), dim3(1024), 0, st, A, lda,
+                           k0 + nb, rest, k0, k0 + nb, w, inv);
+      MDG_LAUNCH_CHECK();
+#else
       // L21 = A21 * inv(L11)^T  (in place: one tile column, each workgroup reads only its own rows)
       MDG_TRY(gemm_f64(rest, nb, nb, 1.0, A21, MDG_F64, lda, 1, nullptr, inv, MDG_F64, 1, NB, 0.0, A21, MDG_F64, lda, 1,
                        0, 0, 0, 0, st));
       // rank-128 update of the remaining columns of this outer panel only
-      const int64_t w = Jend - (k0 + nb);
       if (w > 0)
         MDG_TRY(gemm_f64(rest, w, nb, -1.0, A21, MDG_F64, lda, 1, nullptr, A21, MDG_F64, 1, lda, 1.0,
                          A + (k0 + nb) * lda + (k0 + nb), MDG_F64, lda, 1, 0, 0, 0, 0, st));
+#endif
     }
     const int64_t rest = n - Jend;
     if (rest > 0) {  // rank-(Jend-J0) update of the trailing matrix, lower tiles only
