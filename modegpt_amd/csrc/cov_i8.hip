@@ -395,6 +395,9 @@ constexpr int STAMP_WGS = 1024;
 #ifndef MDG_I8_LOCKSTEP
 #define MDG_I8_LOCKSTEP 1           // persistent launch (one workgroup per CU, static tile lists) for statistics of at least ...
 #endif
+#ifndef MDG_I8_DYNAMIC
+#define MDG_I8_DYNAMIC 1            // workgroups pull tiles from per-XCD queues (0: fixed tile lists per workgroup)
+#endif
 #ifndef MDG_I8_LOCKSTEP_BARRIER
 #define MDG_I8_LOCKSTEP_BARRIER 0   // 1: barrier of an XCD's workgroups between rounds (halves the L2 misses, 2-6 % slower)
 #endif
@@ -818,23 +821,52 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
   if (a.sched && threadIdx.x == 0) a.wgtimes[blockIdx.x * 64] = wall_clock64();
 #endif
   if (a.sched) {
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7;
+    auto work = [&](const int2 entry) {
+      const int code = __builtin_amdgcn_readfirstlane(entry.x), chunk = __builtin_amdgcn_readfirstlane(entry.y);
+      if (code < 0) return;
+      const SyrkProblem& pr = a.prob[code >> CODE_PROB];   // (uniform index into the kernel arguments: scalar loads)
+      const int bi = (code >> CODE_BI) & ((1 << CODE_BI) - 1), bj = code & ((1 << CODE_BI) - 1);
+      if (chunk == 0) {   // per-head statistics: the tile's columns start at the head's first feature
+        i8_syrk_tile<P>(a, pr, bi, bj, 0, a.nk, pr.sigma, pr.ld_sigma, 0, pr.block ? bi * TI : 0, lds, executed);
+      } else {   // the last round: k-chunk q of Q of this tile, folded into its own (zeroed) partial tile
+        const int q = chunk & 31, Q = (chunk >> 5) & 31, pslot = chunk >> 10;
+        const int kb = (int)((int64_t)a.nk * q / Q), ke = (int)((int64_t)a.nk * (q + 1) / Q);
+        if (kb < ke) i8_syrk_tile<P>(a, pr, bi, bj, kb, ke, a.partial + (int64_t)pslot * TI * TJ, TJ, bi * TI, bj * TJ, lds, executed);
+      }
+    };
+#if MDG_I8_DYNAMIC
+    // The schedule's groups are QUEUES, one per XCD (XCD x owns groups x, x + 8, ...): a workgroup pulls the next tile of its
+    // XCD's queue with one atomic, and when that queue is empty helps the other XCDs with theirs.  The 32 tiles of a group
+    // are still taken together by the 32 CUs of one XCD (same panels in the same L2), but a CU that runs a few percent faster
+    // -- clocks differ from CU to CU and from board to board under the power cap -- simply takes more tiles, where fixed
+    // lists made the whole launch wait for the slowest workgroup.  Which CU computes a tile does not change its result.
+    __shared__ int next_entry;
+#ifdef MDG_I8_WGTIMES
+    int done = 0;
+#endif
+    for (int victim = 0; victim < 8; victim++) {
+      const int x = (xcd + victim) & 7;
+      const int entries = ((a.ngroups - x + 7) >> 3) * 32;     // of XCD x's groups
+      for (;;) {
+        __syncthreads();                                         // the previous tile is complete in every wave
+        if (threadIdx.x == 0)
+          next_entry = __hip_atomic_fetch_add(a.xcd_arrive + x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int t = __builtin_amdgcn_readfirstlane(next_entry);
+        if (t >= entries) break;
+        work(a.sched[((t >> 5) * 8 + x) * 32 + (t & 31)]);
+#ifdef MDG_I8_WGTIMES
+        if (threadIdx.x == 0 && done < 60) a.wgtimes[blockIdx.x * 64 + 2 + done++] = wall_clock64();
+#endif
+      }
+    }
+#else
+    const int slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
     for (int round = 0;; round++) {
       const int g = round * 8 + xcd;
       if (g >= a.ngroups) break;
-      const int2 entry = a.sched[g * 32 + slot];
-      const int code = __builtin_amdgcn_readfirstlane(entry.x), chunk = __builtin_amdgcn_readfirstlane(entry.y);
-      if (code >= 0) {
-        const SyrkProblem& pr = a.prob[code >> CODE_PROB];   // (uniform index into the kernel arguments: scalar loads)
-        const int bi = (code >> CODE_BI) & ((1 << CODE_BI) - 1), bj = code & ((1 << CODE_BI) - 1);
-        if (chunk == 0) {   // per-head statistics: the tile's columns start at the head's first feature
-          i8_syrk_tile<P>(a, pr, bi, bj, 0, a.nk, pr.sigma, pr.ld_sigma, 0, pr.block ? bi * TI : 0, lds, executed);
-        } else {   // the last round: k-chunk q of Q of this tile, folded into its own (zeroed) partial tile
-          const int q = chunk & 31, Q = (chunk >> 5) & 31, pslot = chunk >> 10;
-          const int kb = (int)((int64_t)a.nk * q / Q), ke = (int)((int64_t)a.nk * (q + 1) / Q);
-          if (kb < ke) i8_syrk_tile<P>(a, pr, bi, bj, kb, ke, a.partial + (int64_t)pslot * TI * TJ, TJ, bi * TI, bj * TJ, lds, executed);
-        }
-      }
+      work(a.sched[g * 32 + slot]);
 #ifdef MDG_I8_WGTIMES
       if (threadIdx.x == 0 && round < 60) a.wgtimes[blockIdx.x * 64 + 2 + round] = wall_clock64();
 #endif
@@ -851,6 +883,7 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
       __syncthreads();
 #endif
     }
+#endif
   } else {
     // Tile (bi, bj): bi = 128-row block, bj = TJ-row block of the lower region (bj <= bi for 128 x 128 tiles, bj <= 2 bi + 1 for
     // 128 x 64).  XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2, so workgroup w belongs
