@@ -35,7 +35,7 @@
 //                      multiplied: exact, and 28 - 37 % of the MFMAs on SiLU-gated / Gaussian data.  Both instantiations
 //                      and the fp64 kernel are enqueued for every call; the device picks one (each workgroup of the others
 //                      exits on its first instruction).  Statistics of 2048 features and more (everything ops.py sends
-//                      here) run as a persistent launch: one workgroup per CU, static XCD-grouped tile lists, the last, partly
+//                      here) run as a persistent launch: one workgroup per CU pulling tiles from per-XCD queues, the last, partly
 //                      filled round cut into k-chunks that fold into fp64 partial tiles
 //   i8_tail_combine_kernel<P>  adds the partial tiles of that last round to sigma, in chunk order
 #include <algorithm>
@@ -393,7 +393,7 @@ constexpr int STAMP_WGS = 1024;
 #define MDG_I8_SB6 2
 #endif
 #ifndef MDG_I8_LOCKSTEP
-#define MDG_I8_LOCKSTEP 1           // persistent launch (one workgroup per CU, static tile lists) for statistics of at least ...
+#define MDG_I8_LOCKSTEP 1           // persistent launch (one workgroup per CU, tiles from a host-built schedule) for statistics of at least ...
 #endif
 #ifndef MDG_I8_DYNAMIC
 #define MDG_I8_DYNAMIC 1            // workgroups pull tiles from per-XCD queues (0: fixed tile lists per workgroup)
@@ -780,12 +780,14 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
 // of up to 32 that form a compact block of the lower region (4 tile rows x 8 tile columns: 12 distinct panels for 32 tiles
 // instead of 64), one group per XCD and round.  Measured on one box, sigma_mlp 32768 x 14336, five / six planes per call:
 //   one tile per workgroup, 2 x 2 super-blocks (round 1's launch)      25.3-25.5 / 38.9-39.0 ms   58 / -- GB of L2 misses
-//   persistent, the workgroups run through their lists independently   24.5-24.6 / 38.2-38.3 ms   53 / 67 GB        <- default
+//   persistent, every workgroup through a fixed list of its own        24.5-24.6 / 38.2-38.3 ms   53 / 67 GB        (-DMDG_I8_DYNAMIC=0)
 //   persistent + a barrier of the XCD's 32 workgroups between rounds   25.4-25.6 / 40.4-40.6 ms   32 / 54 GB
+//   persistent, tiles pulled from per-XCD queues (later in the round, other kernel improvements included; fixed lists at that
+//   point: 22.05 ms)                                                   21.3 / 35.5 ms             34 GB             <- default
 // (-DMDG_I8_LOCKSTEP_BARRIER=1: the CUs of an XCD start every group together and, pulling the same panel slices through the
 // same L2, stay together).  The lock-step launch halves the L2-miss traffic and is SLOWER: the misses are not what bounds the
 // kernel (the power cap is: mdg_probe_mfma_i8), and 32 CUs folding into sigma and refilling their rings
-// at the same instant cost more than the hits return.  Without the barrier the static lists still save the per-tile
+// at the same instant cost more than the hits return.  Without the barrier the persistent launch still saves the per-tile
 // workgroup launch / drain: 3 %.
 template <int P>  // planes used: 5 or 6
 __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
