@@ -420,7 +420,12 @@ constexpr int NW = 8;     // waves per workgroup
 #ifndef MDG_I8_RING5
 #define MDG_I8_RING5 3
 #endif
-constexpr int ring_depth(int planes) { return planes == 6 ? 4 : MDG_I8_RING5; }
+#ifndef MDG_I8_WIDE5
+#define MDG_I8_WIDE5 1    // five planes: 128 x 128 tiles worked by 64 x 32 wave tiles (0: the six-plane kernel's shape, 128 x 64 / 32 x 32, ring of
+                          // 4 + fragment prefetch: 32.4 instead of 23.0 ms per sigma_mlp call -- 9 unconditional MFMAs a step are too few to hide a barrier behind)
+#endif
+constexpr bool wide_tile(int planes) { return planes == 5 && MDG_I8_WIDE5; }
+constexpr int ring_depth(int planes) { return wide_tile(planes) ? MDG_I8_RING5 : 4; }
 
 // One output tile (bi, bj) of the lower region: bi = 128-row block, bj = TJ-row block (bj <= bi for 128 x 128 tiles, bj <= 2 bi + 1
 // for 128 x 64); the k-steps [kb, ke), then the fold: element (row, col) of the statistic goes to
@@ -430,7 +435,7 @@ template <int P>
 __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProblem& pr, const int bi, const int bj, const int kb, const int ke, double* const fold,
                                              const int64_t fold_ld, const int fold_row0, const int fold_col0, unsigned char* lds,
                                              unsigned& executed) {
-  constexpr int WB = P == 6 ? 1 : 2;               // 32-row blocks of a wave tile: 64 x 32, or 32 x 32 (96 accumulators at P = 6)
+  constexpr int WB = wide_tile(P) ? 2 : 1;         // 32-row blocks of a wave tile: 64 x 32, or 32 x 32 (96 accumulators at P = 6)
   constexpr int TJ = WB == 2 ? 128 : 64;           // tile columns (rows of the J operand); waves are laid out (128 / 32 WB) x (TJ / 32)
   constexpr int PB = TJ * KS;
   constexpr int GA = TI / 32, GB = TJ / 32;        // 32-row groups (1 KB pieces per plane and stage) of the two operands
@@ -439,7 +444,7 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
   constexpr int PIECES = (GA + GB) * P;            // 1 KB pieces per stage
   constexpr bool SKIP = MDG_I8_SKIP_ZERO;
   constexpr int RING = ring_depth(P);              // LDS stages
-  constexpr bool PREFETCH = P == 6;                // the next step's fragments are read before the barrier (needs RING = 4)
+  constexpr bool PREFETCH = !wide_tile(P);         // the next step's fragments are read before the barrier (needs RING = 4)
   // the wave index through readfirstlane: hipcc then knows it is wave-uniform and the staging code becomes scalar (SGPR piece
   // addresses, s_cbranch on the piece tests, M0 from SGPRs) instead of exec-masked branches with a v_readfirstlane per piece
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -791,7 +796,7 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
 // workgroup launch / drain: 3 %.
 template <int P>  // planes used: 5 or 6
 __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
-  constexpr int WB = P == 6 ? 1 : 2;               // 32-row blocks of a wave tile: 64 x 32, or 32 x 32 (96 accumulators at P = 6)
+  constexpr int WB = wide_tile(P) ? 2 : 1;         // 32-row blocks of a wave tile: 64 x 32, or 32 x 32 (96 accumulators at P = 6)
   constexpr int TJ = WB == 2 ? 128 : 64;           // tile columns (rows of the J operand); waves are laid out (128 / 32 WB) x (TJ / 32)
   constexpr int PB = TJ * KS;
   constexpr int GA = TI / 32, GB = TJ / 32;        // 32-row groups (1 KB pieces per plane and stage) of the two operands
@@ -800,7 +805,7 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
   constexpr int PIECES = (GA + GB) * P;            // 1 KB pieces per stage
   constexpr bool SKIP = MDG_I8_SKIP_ZERO;
   constexpr int RING = ring_depth(P);              // LDS stages
-  constexpr bool PREFETCH = P == 6;                // the next step's fragments are read before the barrier (needs RING = 4)
+  constexpr bool PREFETCH = !wide_tile(P);         // the next step's fragments are read before the barrier (needs RING = 4)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   // The route is chosen on the DEVICE: mdg_cov_accum_i8 enqueues the five-plane product, the six-plane product and the fp64
   // kernel back to back, and each exits at once unless the depth statistic of this call (i8_depth_kernel) selects it -- the
@@ -937,7 +942,7 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
 constexpr int COMBINE_ELEMS = 1024;   // tile elements per workgroup of the combine pass (4 per thread, all chunks' loads in flight together)
 template <int P>
 __global__ __launch_bounds__(256) void i8_tail_combine_kernel(SyrkArgs a, int n_tail) {
-  constexpr int TJ = P == 6 ? 64 : 128;
+  constexpr int TJ = wide_tile(P) ? 128 : 64;
   constexpr int PARTS = TI * TJ / COMBINE_ELEMS;
   if (*a.route_flag != (P == 5 ? 0 : 1)) return;     // the product launch of the other route produced the partials, or none did
   const int4 t = a.tail[blockIdx.x / PARTS];
@@ -1235,7 +1240,7 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
       a.force_route = planes_used == 5 ? 0 : 1;
     }
 #endif
-    const bool wide = planes_used == 5;                                        // 128 x 128 tiles; six planes: 128 x 64
+    const bool wide = wide_tile(planes_used);                                  // 128 x 128 tiles; six planes: 128 x 64
     const int tj = wide ? 128 : 64;
     const size_t lds = (size_t)ring_depth(planes_used) * planes_used * (PA + tj * KS);
     const int si = planes_used == 5 ? MDG_I8_SB5 : MDG_I8_SB6;                 // super-block rows (see the kernel); 0 = row-major
@@ -1255,11 +1260,11 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
     if (planes_used == 6) {
       MDG_HIP(hipFuncSetAttribute((const void*)i8_syrk_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL((i8_syrk_kernel<6>), grid, dim3(64 * NW), lds, st, a);
-      if (sch && sch->n_tail) hipLaunchKernelGGL((i8_tail_combine_kernel<6>), dim3(sch->n_tail * (TI * 64 / COMBINE_ELEMS)), dim3(256), 0, st, a, sch->n_tail);
+      if (sch && sch->n_tail) hipLaunchKernelGGL((i8_tail_combine_kernel<6>), dim3(sch->n_tail * (TI * tj / COMBINE_ELEMS)), dim3(256), 0, st, a, sch->n_tail);
     } else {
       MDG_HIP(hipFuncSetAttribute((const void*)i8_syrk_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL((i8_syrk_kernel<5>), grid, dim3(64 * NW), lds, st, a);
-      if (sch && sch->n_tail) hipLaunchKernelGGL((i8_tail_combine_kernel<5>), dim3(sch->n_tail * (TI * 128 / COMBINE_ELEMS)), dim3(256), 0, st, a, sch->n_tail);
+      if (sch && sch->n_tail) hipLaunchKernelGGL((i8_tail_combine_kernel<5>), dim3(sch->n_tail * (TI * tj / COMBINE_ELEMS)), dim3(256), 0, st, a, sch->n_tail);
     }
     MDG_LAUNCH_CHECK();
   }
