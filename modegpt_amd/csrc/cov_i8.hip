@@ -615,6 +615,7 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
   int buf = 0;                 // (kt - kb) % RING
 #ifdef MDG_I8_STAMPS
   unsigned long long ta = 0, tb = 0, tc = 0, td = 0, te = 0, s_wait = 0, s_issue = 0, s_comp = 0, s_tail = 0, t_begin;
+  const unsigned executed_before = executed;
   MDG_STAMP(t_begin);
 #endif
   const int r = lane & 31, h = lane >> 5;
@@ -774,7 +775,7 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
     unsigned long long t_end;
     MDG_STAMP(t_end);
     unsigned long long* o = a.stamps + ((size_t)blockIdx.x * NW + wave) * 8;
-    o[0] = s_wait; o[1] = s_issue; o[2] = s_comp; o[3] = s_tail; o[4] = t_end - t_begin; o[5] = executed; o[6] = nk;
+    o[0] = s_wait; o[1] = s_issue; o[2] = s_comp; o[3] = s_tail; o[4] = t_end - t_begin; o[5] = executed - executed_before; o[6] = ke - kb;   // (of the workgroup's LAST tile or k-chunk)
   }
 #endif
 }
