@@ -108,12 +108,14 @@ int mdg_cov_accum_i8_stats(const void* ws, int64_t n_tokens, int64_t n_feat, uns
 /* Up to 4 statistics of ONE calibration batch (the four hooks of a layer) through the int8 digit-plane kernels with ONE
  * persistent product launch: the tiles of all statistics share one static tile schedule, so the small ones fill what the large
  * one's last round leaves idle instead of ending launches of their own, and one route -- the deepest any column of any
- * statistic asks for (more planes are never less exact; if one needs the fp64 kernel, all take it).  `problems` is a HOST array,
+ * statistic on the int8 path asks for (more planes are never less exact); a statistic whose columns are too heavy-tailed for six
+ * planes leaves the launch alone and goes through mdg_cov_accum (its tiles are skipped on the device).  `problems` is a HOST array,
  * largest statistic first, all with the same n_tokens, bf16.  batch == 1: sigma [n_feat][ld_sigma], n_feat a multiple of 128.
  * batch > 1: per-head Grams of an activation [n_tokens][batch * 128] -- n_feat must be 128, sigma contiguous
  * [batch][128][128] (ld_sigma 128, sigma_batch_stride 16384); only the diagonal tiles are computed.  Several statistics need a
  * 256-CU device (the schedule is cut for 8 XCDs x 32 CUs); otherwise call mdg_cov_accum_i8 per statistic.
- * used_i8 / route_counts / ev_start / ev_stop as in mdg_cov_accum_i8 (route_counts += the number of statistics);
+ * used_i8 / route_counts / ev_start / ev_stop as in mdg_cov_accum_i8 (route_counts += the number of statistics per route;
+ * used_i8 = 5 or 6, the planes of the statistics that stayed on the int8 path, 0 when all of them went to the fp64 kernel);
  * mdg_cov_accum_i8_stats(ws, 0, 0, ...) reads the executed-MFMA count of the whole launch.  mdg_cov_accum_i8 is this call with
  * one statistic. */
 size_t mdg_cov_accum_i8_multi_ws_bytes(int count, const mdg_cov_problem* problems);

@@ -332,7 +332,8 @@ struct SyrkArgs {
 #ifdef MDG_EXPERIMENT
   int force_route = -1;                // MDG_I8_PLANES=5|6 of scripts/bench_kernels.py: run that product kernel whatever the data say
 #endif
-  const int* route_flag;               // written by i8_depth_kernel: 0 -> five planes, 1 -> six planes, bit 1 set -> the fp64 kernel
+  const int* route_flag;               // [nprob] per statistic, written by i8_depth_kernel: bit 0 -> needs six planes, bit 1 -> the fp64 kernel;
+                                       // see launch_route()
   int* route_counts;                   // optional device counters [five planes, six planes, fp64 fallback], += 1 by the launch that runs
   const int2* sched;                   // persistent launch: [ngroups][32] entries {tile code (-1 = none), k-chunk code
                                        // (0 = all k-steps; else slot << 10 | Q << 5 | q: chunk q of Q, folded into partial tile `slot`)};
@@ -348,6 +349,23 @@ struct SyrkArgs {
   unsigned long long* wgtimes;         // diagnostic build only: [256][2 + 32] wall clock (100 MHz) at workgroup start / end / after each tile
 #endif
 };
+// The route of a launch from the per-statistic flags: a statistic with bit 1 set leaves the int8 path ALONE (its tiles are
+// skipped here, a gated mdg_cov_accum launch does it); the others share the launch on six planes if any of them asks for six,
+// else on five.  Returns 0 / 1 (five / six planes), or -1 when no statistic is left on the int8 path; `fallbacks` = how many left.
+__device__ __forceinline__ int launch_route(const SyrkArgs& a, int& live, int& fallbacks) {
+  int six = 0;
+  live = fallbacks = 0;
+  for (int p = 0; p < a.nprob; p++) {
+    const int f = a.route_flag[p];
+    if (f & 2) fallbacks++;
+    else {
+      live++;
+      six |= f & 1;
+    }
+  }
+  return live ? six : -1;
+}
+
 #ifdef MDG_I8_STAMPS
 #define MDG_STAMP(x) x = __builtin_amdgcn_s_memtime()
 constexpr int STAMP_WGS = 1024;
@@ -812,16 +830,14 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
   // kernel back to back, and each exits at once unless the depth statistic of this call (i8_depth_kernel) selects it -- the
   // host never waits for the flag.  The six-plane launch also books the fp64 fallback in the route counters.
   {
+    int live, fallbacks;
+    int route = launch_route(a, live, fallbacks);
 #ifdef MDG_EXPERIMENT
-    const int route = a.force_route >= 0 ? a.force_route : *a.route_flag;
-#else
-    const int route = *a.route_flag;
+    if (a.force_route >= 0 && route >= 0) route = a.force_route;
 #endif
-    if (route != (P == 5 ? 0 : 1)) {
-      if (P == 6 && (route & 2) && a.route_counts && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.route_counts + 2, a.nprob);
-      return;
-    }
-    if (a.route_counts && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.route_counts + (P == 5 ? 0 : 1), a.nprob);
+    if (P == 6 && fallbacks && a.route_counts && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.route_counts + 2, fallbacks);
+    if (route != (P == 5 ? 0 : 1)) return;
+    if (a.route_counts && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.route_counts + (P == 5 ? 0 : 1), live);
   }
   unsigned executed = 0;
   const int lane = threadIdx.x & 63;
@@ -832,7 +848,7 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
     const int xcd = blockIdx.x & 7;
     auto work = [&](const int2 entry) {
       const int code = __builtin_amdgcn_readfirstlane(entry.x), chunk = __builtin_amdgcn_readfirstlane(entry.y);
-      if (code < 0) return;
+      if (code < 0 || (a.route_flag[code >> CODE_PROB] & 2)) return;   // (a statistic that went to the fp64 kernel: not ours)
       const SyrkProblem& pr = a.prob[code >> CODE_PROB];   // (uniform index into the kernel arguments: scalar loads)
       const int bi = (code >> CODE_BI) & ((1 << CODE_BI) - 1), bj = code & ((1 << CODE_BI) - 1);
       if (chunk == 0) {   // per-head statistics: the tile's columns start at the head's first feature
@@ -945,8 +961,10 @@ template <int P>
 __global__ __launch_bounds__(256) void i8_tail_combine_kernel(SyrkArgs a, int n_tail) {
   constexpr int TJ = wide_tile(P) ? 128 : 64;
   constexpr int PARTS = TI * TJ / COMBINE_ELEMS;
-  if (*a.route_flag != (P == 5 ? 0 : 1)) return;     // the product launch of the other route produced the partials, or none did
+  int live, fallbacks;
+  if (launch_route(a, live, fallbacks) != (P == 5 ? 0 : 1)) return;     // the product launch of the other route produced the partials, or none did
   const int4 t = a.tail[blockIdx.x / PARTS];
+  if (a.route_flag[t.x >> CODE_PROB] & 2) return;
   const SyrkProblem& pr = a.prob[t.x >> CODE_PROB];
   const int bi = (t.x >> CODE_BI) & ((1 << CODE_BI) - 1), bj = t.x & ((1 << CODE_BI) - 1), Q = t.y;
   const double* part = a.partial + (int64_t)t.z * TI * TJ;
@@ -1154,7 +1172,8 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
   MDG_CHECK_ARG(ws && ws_bytes >= need, "mdg_cov_accum_i8_multi: workspace %zu < required %zu", ws_bytes, need);
   hipStream_t st = (hipStream_t)stream;
   const int nk = (int)ceil_div(n_tokens, KS);
-  int* flag = (int*)ws;                                               // [0]: route bits;  [2..3]: executed-MFMA counter;  [4..11]: XCD counters
+  int* flag = (int*)ws;                                               // [2..3]: executed-MFMA counter;  [4..11]: tile-queue counters;
+  int* pflag = flag + 12;                                             // [12..15]: route bits per statistic (i8_depth_kernel)
   unsigned long long* mfma_count = (unsigned long long*)(flag + 2);
   double* partial = (double*)((char*)ws + SHARED_BYTES);
   void* fb_ws = (char*)ws + fb_off;
@@ -1185,8 +1204,8 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
       hipLaunchKernelGGL(i8_split_kernel, dim3((unsigned)(n / 32), (unsigned)ceil_div(nk, SPLIT_STEPS)), dim3(256), 0, st,
                          (const bf16_t*)q.x, q.ld, n_tokens, n, nk, emax, planes, deep_cnt, nz_cnt, zmask);
     }
-    // every statistic ORs into the same flag: the launch takes the deepest route any of its columns asks for
-    hipLaunchKernelGGL(i8_depth_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, deep_cnt, nz_cnt, emax, n, flag);
+    // a flag per statistic: the launch takes the deepest route any statistic still on the int8 path asks for (launch_route)
+    hipLaunchKernelGGL(i8_depth_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, deep_cnt, nz_cnt, emax, n, pflag + i);
     MDG_LAUNCH_CHECK();
     a.prob[i] = SyrkProblem{planes, emax, zmask, q.sigma, q.ld_sigma, n, q.batch > 1 ? TI : 0};
     shapes.emplace_back(n / TI, q.batch > 1 ? TI : 0);
@@ -1195,7 +1214,7 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
   // All three routes are enqueued; the flag just written decides on the device which one does the work (the other launches'
   // workgroups exit on their first instruction: ~10 us each at the sigma_mlp grid).  No host round trip, graph-capturable.
   a.mfma_count = mfma_count;
-  a.route_flag = flag; a.route_counts = route_counts;
+  a.route_flag = pflag; a.route_counts = route_counts;
   a.xcd_arrive = flag + 4;
 #ifdef MDG_I8_STAMPS
   static unsigned long long* stamps_dev = nullptr;
@@ -1270,11 +1289,12 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
     MDG_LAUNCH_CHECK();
   }
   if (ev_stop) MDG_HIP(hipEventRecord((hipEvent_t)ev_stop, st));
-  // some column is mostly far below its maximum (flag bit 1): six planes do not carry fp64-level accuracy there
+  // some column of a statistic is mostly far below its maximum (its flag's bit 1): six planes do not carry fp64-level accuracy
+  // there -- that statistic, and only that one, goes through the fp64 kernel
   for (int i = 0; i < count; i++) {
     const mdg_cov_problem& q = problems[i];
     const int fb = cov_accum_gated(q.x, MDG_BF16, n_tokens, q.n_feat, q.batch, q.ld, 0, q.sigma, q.ld_sigma, q.sigma_batch_stride, fb_ws,
-                                   ws_bytes - fb_off, flag, 2, 2, stream);
+                                   ws_bytes - fb_off, pflag + i, 2, 2, stream);
     if (fb != MDG_OK) return fb;
   }
 #ifdef MDG_I8_STAMPS
@@ -1328,12 +1348,18 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
   }
 #endif
   if (used_i8) {   // measurement / test mode: report the route this call took (costs the host a round trip)
-    int depth = 0;
-    MDG_HIP(hipMemcpyAsync(&depth, flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    int pf[MAX_PROBLEMS] = {};
+    MDG_HIP(hipMemcpyAsync(pf, pflag, sizeof(pf), hipMemcpyDeviceToHost, st));
     MDG_HIP(hipStreamSynchronize(st));
-    *used_i8 = (depth & 2) ? 0 : ((depth & 1) ? 6 : 5);
+    int live = 0, six = 0;
+    for (int i = 0; i < count; i++)
+      if (!(pf[i] & 2)) {
+        live++;
+        six |= pf[i] & 1;
+      }
+    *used_i8 = live ? (six ? 6 : 5) : 0;     // the route of the statistics that stayed on the int8 path; 0: all went to the fp64 kernel
 #ifdef MDG_EXPERIMENT
-    if (const char* ev = getenv("MDG_I8_PLANES")) if (!(depth & 2)) *used_i8 = atoi(ev);
+    if (const char* ev = getenv("MDG_I8_PLANES")) if (live) *used_i8 = atoi(ev);
 #endif
   }
   return MDG_OK;

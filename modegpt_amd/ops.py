@@ -123,7 +123,9 @@ def cov_accum_i8_multi(items, events=None, mfma_stats: Optional[dict] = None, re
     count.  n_heads == 1: sigma [n, n], n a multiple of 128; n_heads > 1: per-head Grams, sigma [n_heads, 128, 128] of an
     activation [tokens, n_heads * 128].  The tiles of all statistics share one tile schedule -- the small ones fill what the
     large one's last round leaves idle -- and one route: the deepest any column of any of them asks for (more planes are
-    never less exact).  events / mfma_stats / report as in cov_accum_i8 (the executed / dense counts cover all statistics)."""
+    never less exact); a statistic too heavy-tailed for six planes leaves the launch alone (fp64 kernel).  events / mfma_stats /
+    report as in cov_accum_i8 (report: the planes of the statistics that stayed, 0 if none did; the executed / dense counts cover
+    all statistics and assume none fell back)."""
     lib = _lib.load()
     items = list(items)
     arr = (_lib.CovProblem * len(items))()

@@ -232,9 +232,9 @@ def test_fused_int8_launch_of_a_layers_statistics(ops, dev, widths, heads, T, ki
     assert counts[{5: "i8_5", 6: "i8_6"}[planes]] == 2 * len(items) and sum(counts.values()) == 2 * len(items)
 
 
-def test_fused_int8_launch_falls_back_as_a_whole(ops, dev):
-    """One column dominated by a single massive activation sends the WHOLE fused call to the fp64 kernel: every statistic then
-    equals ops.cov_accum's result bit for bit."""
+def test_fused_int8_launch_lets_one_statistic_fall_back_alone(ops, dev):
+    """One column dominated by a single massive activation sends THAT statistic to the fp64 kernel (its result then equals
+    ops.cov_accum's bit for bit); the other statistics of the launch stay on their digit planes."""
     T = 3000
     Xa = gaussian(dev, T, 2048, 5)
     Xb = gaussian(dev, T, 2048, 6).clone()
@@ -243,11 +243,22 @@ def test_fused_int8_launch_falls_back_as_a_whole(ops, dev):
     Xq = gaussian(dev, T, 4 * 128, 7)
     items = [(torch.zeros(2048, 2048, dtype=F64, device=dev), Xa, 1), (torch.zeros(2048, 2048, dtype=F64, device=dev), Xb, 1),
              (torch.zeros(4, 128, 128, dtype=F64, device=dev), Xq, 4)]
-    assert ops.cov_accum_i8_multi(items, report=True) == 0
+    ops.i8_route_counts(dev, reset=True)
+    assert ops.cov_accum_i8_multi(items, report=True) == 5
+    assert ops.i8_route_counts(dev, reset=True) == {"i8_5": 2, "i8_6": 0, "fallback_f64": 1}
+    refs = []
     for S, X, nh in items:
         R = torch.zeros_like(S)
         ops.cov_accum(R, X, n_heads=nh)
-        assert torch.equal(S, R)
+        refs.append(R)
+    assert torch.equal(items[1][0], refs[1])
+    assert not torch.equal(items[0][0], refs[0])           # (an int8 result: equal to 1e-12, not to the bit)
+    _check_against(items[0][0], refs[0])
+    _check_against(items[2][0], refs[2])
+    # all of them heavy-tailed: nothing is left on the int8 path
+    both = [(torch.zeros(2048, 2048, dtype=F64, device=dev), Xb, 1), (torch.zeros(2048, 2048, dtype=F64, device=dev), Xb, 1)]
+    assert ops.cov_accum_i8_multi(both, report=True) == 0
+    assert torch.equal(both[0][0], refs[1]) and torch.equal(both[1][0], refs[1])
 
 
 def test_cov_accum_multi_routes_a_llama_layer(ops, dev, monkeypatch):
