@@ -61,10 +61,7 @@ constexpr int PA = TI * KS;      // bytes of one plane of the I operand in a sta
 // every digit vector the split pass can produce: scripts/probes/i8_int32_bound.py) -- 65535 tokens = 2047 k-steps stay below
 // 2^31.  (First versions: 512, from the cruder bound 6 pairs x 128 x 128 per token; one fold per launch costs 0.65 ms at the
 // sigma_mlp shape.)
-#ifndef MDG_I8_FLUSH_STEPS
-#define MDG_I8_FLUSH_STEPS 2047
-#endif
-constexpr int FLUSH_STEPS = MDG_I8_FLUSH_STEPS;
+constexpr int FLUSH_STEPS = 2047;
 constexpr int TOP_SHIFT = 8 * NP - 10;  // 38: the column maximum's significand sits below bit 46 of the 48-bit integer
 constexpr int DEEP_BINADES = 10;  // an element is "deep" when its exponent is at least this far below the column maximum
 
@@ -329,9 +326,6 @@ struct SyrkArgs {
   SyrkProblem prob[MAX_PROBLEMS];
   int nprob, nk;
   unsigned long long* mfma_count;      // += v_mfma instructions this launch executed (the dense count is known on the host)
-#ifdef MDG_EXPERIMENT
-  int force_route = -1;                // MDG_I8_PLANES=5|6 of scripts/bench_kernels.py: run that product kernel whatever the data say
-#endif
   const int* route_flag;               // [nprob] per statistic, written by i8_depth_kernel: bit 0 -> needs six planes, bit 1 -> the fp64 kernel;
                                        // see launch_route()
   int* route_counts;                   // optional device counters [five planes, six planes, fp64 fallback], += 1 by the launch that runs
@@ -401,49 +395,18 @@ constexpr int STAMP_WGS = 1024;
 // to pin the order: 27.0 / 41.6 ms -- in lock-step both waves of a SIMD stall in their load issue together); fragment reads
 // ahead of the load issue; static s_setprio 1 for waves 4-7 (26.4 ms); four stages + fragment prefetch for five planes too
 // (24.7 ms); super-blocks of 1 / 4 x 4 tiles for six planes (39.4 / 39.0 ms).
-#ifndef MDG_I8_SKIP_ZERO
-#define MDG_I8_SKIP_ZERO 1    // skip the LDS-DMA load, the fragment read and the MFMAs of all-zero pieces
-#endif
-#ifndef MDG_I8_SB5
-#define MDG_I8_SB5 2    // 2 x 2 tiles of 128 x 128 (with zero-plane skipping: 26.7 ms against 27.5 for 4 x 4, 27.6 row-major)
-#endif
-#ifndef MDG_I8_SB6
-#define MDG_I8_SB6 2
-#endif
-#ifndef MDG_I8_LOCKSTEP
-#define MDG_I8_LOCKSTEP 1           // persistent launch (one workgroup per CU, tiles from a host-built schedule) for statistics of at least ...
-#endif
-#ifndef MDG_I8_DYNAMIC
-#define MDG_I8_DYNAMIC 1            // workgroups pull tiles from per-XCD queues (0: fixed tile lists per workgroup)
-#endif
-#ifndef MDG_I8_LOCKSTEP_BARRIER
-#define MDG_I8_LOCKSTEP_BARRIER 0   // 1: barrier of an XCD's workgroups between rounds (halves the L2 misses, 2-6 % slower)
-#endif
-#ifndef MDG_I8_LOCKSTEP_MIN_ROWS
-#define MDG_I8_LOCKSTEP_MIN_ROWS 16   // ... this many 128-row blocks (n >= 2048: everything ops.py routes here); below, one tile per workgroup
-#endif
-#ifndef MDG_I8_DEFER
-#define MDG_I8_DEFER 4      // MFMAs a loads-first wave holds back across the barrier (0: 25.3, 2: 26.0, 3: 24.9, 4: 24.6, 5: 25.0, 6: 27.8 ms per call)
-#endif
-#ifndef MDG_I8_FOLD_ATOMIC
-#define MDG_I8_FOLD_ATOMIC 0   // 1: fold into sigma with returnless global_atomic_add_f64 instead of load / add / store -- bit-identical
-                               // (scripts/probes/i8_fold_bits.py) and no register spill left, but 0.9 % SLOWER per launch on two boxes
-                               // (21.72 / 22.27 -> 21.91 / 22.46 ms): the folds of different CUs are not synchronised, so their
-                               // latency already hides behind the other CUs' MFMAs, and the kernel is bound by power, not by stalls
-#endif
-#ifndef MDG_I8_ROLES
-#define MDG_I8_ROLES 1  // 0: every wave loads first (the lock-step order of the first versions)
-#endif
-constexpr int NW = 8;     // waves per workgroup
-#ifndef MDG_I8_RING5
-#define MDG_I8_RING5 3
-#endif
-#ifndef MDG_I8_WIDE5
-#define MDG_I8_WIDE5 1    // five planes: 128 x 128 tiles worked by 64 x 32 wave tiles (0: the six-plane kernel's shape, 128 x 64 / 32 x 32, ring of
-                          // 4 + fragment prefetch: 32.4 instead of 23.0 ms per sigma_mlp call -- 9 unconditional MFMAs a step are too few to hide a barrier behind)
-#endif
-constexpr bool wide_tile(int planes) { return planes == 5 && MDG_I8_WIDE5; }
-constexpr int ring_depth(int planes) { return wide_tile(planes) ? MDG_I8_RING5 : 4; }
+// Build-time variants that were measured and dropped (lock-step round barrier, fixed tile lists, returnless atomic fold, the
+// narrow five-plane tile, every-wave-loads-first order, deferred MFMAs on six planes, whole tiles in the last round, the
+// timing experiments) live in scripts/probes/cov_i8_variants.patch with their numbers; what is compiled here is the shipped
+// path.  Two diagnostic builds remain: -DMDG_I8_STAMPS (s_memtime phases of a k-step) and -DMDG_I8_WGTIMES (per-workgroup
+// wall clock).
+constexpr int SB5 = 2, SB6 = 2;       // one-tile-per-workgroup launches (n < 2048): super-blocks of 2 x 2 (2 x 4) tiles per XCD
+constexpr int PERSISTENT_MIN_ROWS = 16;   // statistics of at least this many 128-row blocks (n >= 2048) run as the persistent launch
+constexpr int DEFER5 = 4;             // MFMAs a loads-first wave of the five-plane kernel holds back across the barrier (0: 25.3, 2: 26.0, 3: 24.9, 4: 24.6, 5: 25.0, 6: 27.8 ms per call)
+constexpr int NW = 8;                 // waves per workgroup
+constexpr int RING5 = 3;              // LDS stages of the five-plane kernel (six planes: 4)
+constexpr bool wide_tile(int planes) { return planes == 5; }   // 128 x 128 tiles (six planes: 128 x 64)
+constexpr int ring_depth(int planes) { return wide_tile(planes) ? RING5 : 4; }
 
 // One output tile (bi, bj) of the lower region: bi = 128-row block, bj = TJ-row block (bj <= bi for 128 x 128 tiles, bj <= 2 bi + 1
 // for 128 x 64); the k-steps [kb, ke), then the fold: element (row, col) of the statistic goes to
@@ -460,13 +423,12 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
   constexpr int WCOLS = TJ / 32;
   constexpr int STAGE_BYTES = P * (PA + PB);       // 40 KB (P = 5, 128 x 128) / 36 KB (P = 6, 128 x 64)
   constexpr int PIECES = (GA + GB) * P;            // 1 KB pieces per stage
-  constexpr bool SKIP = MDG_I8_SKIP_ZERO;
   constexpr int RING = ring_depth(P);              // LDS stages
   constexpr bool PREFETCH = !wide_tile(P);         // the next step's fragments are read before the barrier (needs RING = 4)
   // the wave index through readfirstlane: hipcc then knows it is wave-uniform and the staging code becomes scalar (SGPR piece
   // addresses, s_cbranch on the piece tests, M0 from SGPRs) instead of exec-masked branches with a v_readfirstlane per piece
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const bool loads_first = MDG_I8_ROLES ? wave >= NW / 2 : true;
+  const bool loads_first = wave >= NW / 2;
   const int wr = wave / WCOLS, wc = wave % WCOLS;
   const int64_t groups = pr.n / 32;
   const int nk = a.nk;
@@ -474,13 +436,8 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
   // staging: (GA + GB) P pieces of 1 KB per stage (A: P planes x 4 row groups, B: P planes x 2 or 4); wave w issues pieces w, w + NW, ...
   // mA / mB: piece masks of the stage's A and B row groups, one byte per 32-row group; planes at or beyond a group's depth
   // (group_depth below) are all-zero there in this k-step and are neither loaded nor multiplied
-#ifndef MDG_I8_MIN_DEPTH6
-#define MDG_I8_MIN_DEPTH6 4   // (experiments: 6 runs the six-plane kernel's mask machinery without skipping anything)
-#endif
-  constexpr int MIN_DEPTH = P == 6 ? MDG_I8_MIN_DEPTH6 : P - 2;
-#ifndef MDG_EXPERIMENT
+  constexpr int MIN_DEPTH = P - 2;   // planes below this are always staged and multiplied (3 of five, 4 of six)
   static_assert(MIN_DEPTH <= ALWAYS_WRITTEN_PLANES, "the split pass leaves all-zero pieces of the deeper planes unwritten");
-#endif
   auto group_depth = [&](unsigned m, int g) {   // 1 + deepest plane with a nonzero in group g, but at least MIN_DEPTH
     const unsigned byte = (m >> (8 * g)) & 0xFFu;
     return max(MIN_DEPTH, min(P, 32 - __builtin_clz(byte | 1u)));
@@ -501,18 +458,14 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
     const bool isA = p < GA * P;
     const int pp = isA ? p : p - GA * P;
     const int s = isA ? pp / GA : pp / GB, g = isA ? pp % GA : pp % GB;
-#ifdef MDG_I8_EXPERIMENT_SAME_PANEL   // (timing experiment, wrong results: every tile streams panel 0 -- all loads hit in L2)
-    const int64_t G = g;
-#else
     const int64_t G = (isA ? bi * (TI / 32) : bj * (TJ / 32)) + g;
-#endif
     const unsigned long long base = (unsigned long long)(uintptr_t)pr.planes + (unsigned long long)((s * groups + G) * (int64_t)nk) * 1024ull;
     pc_base[q] = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(base >> 32)) << 32) |
                  (unsigned)__builtin_amdgcn_readfirstlane((unsigned)base);
     pc_loff[q] = (isA ? s * PA : P * PA + s * PB) + g * 1024;
     pc_shift[q] = (isA ? 0 : 32) + 8 * g;
     pc_cmask[q] = (0xFFu << s) & 0xFFu;          // bits s .. 7 of the group's mask byte: some plane >= s holds a nonzero
-    pc_force[q] = (!SKIP || s < MIN_DEPTH) ? 1u : 0u;   // planes below MIN_DEPTH are always staged (the unconditional MFMA block reads them)
+    pc_force[q] = s < MIN_DEPTH ? 1u : 0u;   // planes below MIN_DEPTH are always staged (the unconditional MFMA block reads them)
   }
   const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)lds);
   const unsigned lane16 = lane * 16;
@@ -524,15 +477,9 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
     for (int q = 0; q < NQ; q++) {
       if (!pc_valid[q]) continue;
       const unsigned present = ((unsigned)(m64 >> pc_shift[q]) & pc_cmask[q]) | pc_force[q];
-#if defined(MDG_I8_EXPERIMENT_NO_LOADS)      // (timing experiments, wrong results) 1: no load instruction after the prologue;
-      if (present && (MDG_I8_EXPERIMENT_NO_LOADS == 2 || kt < RING - 1))   // 2: the instruction is issued under EXEC = 0 (no memory access)
-        asm volatile("s_mov_b64 exec, %3\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, -1"
-                     ::"s"(lbase + pc_loff[q]), "v"(voff), "s"(pc_base[q]), "s"(kt < RING - 1 ? ~0ull : 0ull) : "memory");
-#else
       if (present)   // (an all-zero piece is not loaded: nothing will read it)
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lbase + pc_loff[q]), "v"(voff), "s"(pc_base[q])
                      : "memory");   // (M0 is written; nothing the compiler emits in this kernel reads it)
-#endif
     }
   };
 
@@ -558,21 +505,6 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
       double* const p = fold + (int64_t)(row0 + b * 32 - fold_row0) * fold_ld + (col - fold_col0);
       const int* const e = pr.emax + row0 + b * 32;
       int er[16];
-#if MDG_I8_FOLD_ATOMIC
-      // `+=` as a returnless global_atomic_add_f64: the addition happens at the L2, the workgroup neither waits for the old
-      // values nor holds them in registers.  One tile = one workgroup per launch touches an element, so there is no ordering
-      // to lose: the same correctly rounded fp64 addition, bit for bit.
-#pragma unroll
-      for (int reg = 0; reg < 16; reg++) er[reg] = e[(reg & 3) + 8 * (reg >> 2)];
-#pragma unroll
-      for (int reg = 0; reg < 16; reg++) {
-        const int off = (reg & 3) + 8 * (reg >> 2);
-        double v = 0.;
-#pragma unroll
-        for (int k = P - 1; k >= 0; k--) v += ldexp((double)acc[k][b][reg], 80 - 8 * k);
-        if (col <= row0 + b * 32 + off) unsafeAtomicAdd(p + (int64_t)off * fold_ld, v * sc_j * ldexp(1.0, er[reg] - 172));
-      }
-#else
       double old[16];
 #pragma unroll
       for (int reg = 0; reg < 16; reg++) {
@@ -588,7 +520,6 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
         for (int k = P - 1; k >= 0; k--) v += ldexp((double)acc[k][b][reg], 80 - 8 * k);
         if (col <= row0 + b * 32 + off) p[(int64_t)off * fold_ld] = old[reg] + v * sc_j * ldexp(1.0, er[reg] - 172);
       }
-#endif
     }
 #pragma unroll
     for (int k = 0; k < P; k++)
@@ -615,17 +546,15 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
   unsigned mA[D + 1], mB[D + 1], vA = ~0u, vB = ~0u;
 #pragma unroll
   for (int i = 0; i <= D; i++) mA[i] = mB[i] = ~0u;
-  if (SKIP) {
 #pragma unroll
-    for (int i = 0; i < D; i++)
-      if (kb + i < ke) {
-        unsigned t0, t1;
-        load_masks(kb + i, t0, t1);
-        mA[i] = __builtin_amdgcn_readfirstlane(t0);
-        mB[i] = b_half(__builtin_amdgcn_readfirstlane(t1));
-      }
-    if (ke - kb > D) load_masks(kb + D, vA, vB);
-  }
+  for (int i = 0; i < D; i++)
+    if (kb + i < ke) {
+      unsigned t0, t1;
+      load_masks(kb + i, t0, t1);
+      mA[i] = __builtin_amdgcn_readfirstlane(t0);
+      mB[i] = b_half(__builtin_amdgcn_readfirstlane(t1));
+    }
+  if (ke - kb > D) load_masks(kb + D, vA, vB);
 #pragma unroll
   for (int i = 0; i < D; i++)
     if (kb + i < ke) issue_stage(kb + i, i, mA[i], mB[i]);
@@ -657,8 +586,8 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
     const unsigned char* base = lds + stage_buf * STAGE_BYTES;
     int dAb[WB];
 #pragma unroll
-    for (int b = 0; b < WB; b++) dAb[b] = SKIP ? group_depth(mAk, wr * WB + b) : P;
-    const int dBw = SKIP ? group_depth(mBk, wc) : P;
+    for (int b = 0; b < WB; b++) dAb[b] = group_depth(mAk, wr * WB + b);
+    const int dBw = group_depth(mBk, wc);
     int deep_mfmas = 0;
 #pragma unroll
     for (int d = MIN_DEPTH; d < P; d++) {
@@ -684,11 +613,9 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
   };
   constexpr int UNCOND_PAIRS = P == 5 ? 9 : (MIN_DEPTH == 4 ? 15 : 21);   // pairs (s, t), s, t < MIN_DEPTH, s + t < P
   constexpr int N_UNCOND = UNCOND_PAIRS * WB;                               // unconditional MFMAs per wave and k-step
-#ifndef MDG_I8_DEFER6
-#define MDG_I8_DEFER6 0     // six planes: 37.2 ms per call without, 55 ms with 3 - 5 deferred (the loads-first waves then lose their fragment prefetch)
-#endif
-  constexpr int DEFER = !MDG_I8_ROLES ? 0 : (PREFETCH ? MDG_I8_DEFER6 : MDG_I8_DEFER);   // of them, held back across the barrier by the loads-first waves
-  // (with PREFETCH and DEFER both on, only the multiply-first waves prefetch: a loads-first wave still needs its old fragments after the barrier)
+  // of them, held back across the barrier by the loads-first waves (six planes: none -- 37.2 ms per call without, 55 ms with 3 - 5
+  // deferred: the loads-first waves then lose their fragment prefetch)
+  constexpr int DEFER = PREFETCH ? 0 : DEFER5;
   auto rotate = [&]() {
 #pragma unroll
     for (int i = 0; i < D; i++) {
@@ -714,12 +641,10 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
       if (loads_first) wait_loads();  // this wave's loads of the previous step
       __builtin_amdgcn_s_barrier();   // stage kt (PREFETCH: kt + 1 too) complete in LDS, stage kt - 1 no longer read
       auto refill = [&]() {           // stage kt + D into the buffer stage kt - 1 just left; masks of the stage after it behind it
-        if (SKIP) {
-          mA[D] = __builtin_amdgcn_readfirstlane(vA);
-          mB[D] = b_half(__builtin_amdgcn_readfirstlane(vB));
-        }
+        mA[D] = __builtin_amdgcn_readfirstlane(vA);
+        mB[D] = b_half(__builtin_amdgcn_readfirstlane(vB));
         if (kt + D < ke) issue_stage(kt + D, ahead(D), mA[D], mB[D]);
-        if (SKIP && kt + D + 1 < ke) load_masks(kt + D + 1, vA, vB);
+        if (kt + D + 1 < ke) load_masks(kt + D + 1, vA, vB);
       };
       MDG_STAMP(tb);
       // the unconditional MFMAs of a step, in (s, t, block) order; [lo, hi) selects a run of them
@@ -798,21 +723,19 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
 #endif
 }
 
-// Persistent launch (large statistics): 8 x 32 workgroups, one per CU, each working through a host-built list of tiles
+// Persistent launch (large statistics): 8 x 32 workgroups, one per CU, pulling tiles from a host-built schedule
 // (SyrkArgs::sched) instead of one tile per workgroup.  Workgroup b belongs to logical XCD b % 8 (what the dispatcher's
-// round-robin gives -- if it ever does not, only locality is lost) and is its slot b / 8.  The tiles are dealt out in GROUPS
-// of up to 32 that form a compact block of the lower region (4 tile rows x 8 tile columns: 12 distinct panels for 32 tiles
-// instead of 64), one group per XCD and round.  Measured on one box, sigma_mlp 32768 x 14336, five / six planes per call:
+// round-robin gives -- if it ever does not, only locality is lost).  The tiles are dealt out in GROUPS of up to 32 that form
+// a compact block of the lower region (4 tile rows x 8 tile columns: 12 distinct panels for 32 tiles instead of 64), one
+// group per XCD and round.  Measured on one box, sigma_mlp 32768 x 14336, five / six planes per call:
 //   one tile per workgroup, 2 x 2 super-blocks (round 1's launch)      25.3-25.5 / 38.9-39.0 ms   58 / -- GB of L2 misses
-//   persistent, every workgroup through a fixed list of its own        24.5-24.6 / 38.2-38.3 ms   53 / 67 GB        (-DMDG_I8_DYNAMIC=0)
+//   persistent, every workgroup through a fixed list of its own        24.5-24.6 / 38.2-38.3 ms   53 / 67 GB
 //   persistent + a barrier of the XCD's 32 workgroups between rounds   25.4-25.6 / 40.4-40.6 ms   32 / 54 GB
-//   persistent, tiles pulled from per-XCD queues (later in the round, other kernel improvements included; fixed lists at that
-//   point: 22.05 ms)                                                   21.3 / 35.5 ms             34 GB             <- default
-// (-DMDG_I8_LOCKSTEP_BARRIER=1: the CUs of an XCD start every group together and, pulling the same panel slices through the
-// same L2, stay together).  The lock-step launch halves the L2-miss traffic and is SLOWER: the misses are not what bounds the
-// kernel (the power cap is: mdg_probe_mfma_i8), and 32 CUs folding into sigma and refilling their rings
-// at the same instant cost more than the hits return.  Without the barrier the persistent launch still saves the per-tile
-// workgroup launch / drain: 3 %.
+//   persistent, tiles pulled from per-XCD queues (later in round 2, other kernel improvements included; fixed lists at that
+//   point: 22.05 ms)                                                   21.3 / 35.5 ms             34 GB             <- shipped
+// The lock-step variant halves the L2-miss traffic and is SLOWER: the misses are not what bounds the kernel (the power cap
+// is: mdg_probe_mfma_i8), and 32 CUs folding into sigma and refilling their rings at the same instant
+// cost more than the hits return.  (The fixed-list and barrier variants: scripts/probes/cov_i8_variants.patch.)
 template <int P>  // planes used: 5 or 6
 __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
   constexpr int WB = wide_tile(P) ? 2 : 1;         // 32-row blocks of a wave tile: 64 x 32, or 32 x 32 (96 accumulators at P = 6)
@@ -822,7 +745,6 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
   constexpr int WCOLS = TJ / 32;
   constexpr int STAGE_BYTES = P * (PA + PB);       // 40 KB (P = 5, 128 x 128) / 36 KB (P = 6, 128 x 64)
   constexpr int PIECES = (GA + GB) * P;            // 1 KB pieces per stage
-  constexpr bool SKIP = MDG_I8_SKIP_ZERO;
   constexpr int RING = ring_depth(P);              // LDS stages
   constexpr bool PREFETCH = !wide_tile(P);         // the next step's fragments are read before the barrier (needs RING = 4)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -831,10 +753,7 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
   // host never waits for the flag.  The six-plane launch also books the fp64 fallback in the route counters.
   {
     int live, fallbacks;
-    int route = launch_route(a, live, fallbacks);
-#ifdef MDG_EXPERIMENT
-    if (a.force_route >= 0 && route >= 0) route = a.force_route;
-#endif
+    const int route = launch_route(a, live, fallbacks);
     if (P == 6 && fallbacks && a.route_counts && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.route_counts + 2, fallbacks);
     if (route != (P == 5 ? 0 : 1)) return;
     if (a.route_counts && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.route_counts + (P == 5 ? 0 : 1), live);
@@ -859,7 +778,6 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
         if (kb < ke) i8_syrk_tile<P>(a, pr, bi, bj, kb, ke, a.partial + (int64_t)pslot * TI * TJ, TJ, bi * TI, bj * TJ, lds, executed);
       }
     };
-#if MDG_I8_DYNAMIC
     // The schedule's groups are QUEUES, one per XCD (XCD x owns groups x, x + 8, ...): a workgroup pulls the next tile of its
     // XCD's queue with one atomic, and when that queue is empty helps the other XCDs with theirs.  The 32 tiles of a group
     // are still taken together by the 32 CUs of one XCD (same panels in the same L2), but a CU that runs a few percent faster
@@ -885,29 +803,6 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
 #endif
       }
     }
-#else
-    const int slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
-    for (int round = 0;; round++) {
-      const int g = round * 8 + xcd;
-      if (g >= a.ngroups) break;
-      work(a.sched[g * 32 + slot]);
-#ifdef MDG_I8_WGTIMES
-      if (threadIdx.x == 0 && round < 60) a.wgtimes[blockIdx.x * 64 + 2 + round] = wall_clock64();
-#endif
-      if (g + 8 >= a.ngroups) break;          // this XCD's last round
-#if MDG_I8_LOCKSTEP_BARRIER
-      // round barrier of the XCD's workgroups: for speed only (nothing below depends on it), so the spin is bounded
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(a.xcd_arrive + xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int target = slots * (round + 1);
-        for (int spin = 0; spin < 4000 && __hip_atomic_load(a.xcd_arrive + xcd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; spin++)
-          __builtin_amdgcn_s_sleep(32);
-      }
-      __syncthreads();
-#endif
-    }
-#endif
   } else {
     // Tile (bi, bj): bi = 128-row block, bj = TJ-row block of the lower region (bj <= bi for 128 x 128 tiles, bj <= 2 bi + 1 for
     // 128 x 64).  XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2, so workgroup w belongs
@@ -916,8 +811,8 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
     // each distinct panel row through that L2 once.  Super-blocks (R, C), C <= R, cover the lower region; tiles of a diagonal
     // super-block that lie above it exit at once.
     int bi, bj;
-    constexpr int SI = P == 5 ? MDG_I8_SB5 : MDG_I8_SB6;   // super-block: SI x SI (or SI x 2 SI) tiles; 0 = plain row-major order
-    if (SI > 0) {
+    constexpr int SI = P == 5 ? SB5 : SB6;   // super-block: SI x SI (or SI x 2 SI) tiles
+    {
       constexpr int TPS = TJ == 128 ? SI * SI : SI * 2 * SI;   // tiles per super-block
       constexpr int SJ = TJ == 128 ? SI : 2 * SI;              // tile columns of a super-block
       const int w = blockIdx.x;
@@ -929,18 +824,6 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
       const int C = sb - R * (R + 1) / 2;
       bi = SI * R + t_in / SJ;
       bj = SJ * C + t_in % SJ;
-    } else if (TJ == 128) {
-      const int tile = blockIdx.x;  // bi (bi + 1) / 2 tiles precede row bi
-      bi = (int)((sqrtf(8.f * tile + 1.f) - 1.f) * 0.5f);
-      while ((bi + 1) * (bi + 2) / 2 <= tile) bi++;
-      while (bi * (bi + 1) / 2 > tile) bi--;
-      bj = tile - bi * (bi + 1) / 2;
-    } else {
-      const int tile = blockIdx.x;  // bi (bi + 1) tiles precede row bi
-      bi = (int)((sqrtf(4.f * tile + 1.f) - 1.f) * 0.5f);
-      while ((bi + 1) * (bi + 2) <= tile) bi++;
-      while (bi * (bi + 1) > tile) bi--;
-      bj = tile - bi * (bi + 1);
     }
     if (bi >= a.prob[0].n / TI || bj * TJ > bi * TI + TI - 1) return;   // (one full-triangle statistic per launch on this path)
     i8_syrk_tile<P>(a, a.prob[0], bi, bj, 0, a.nk, a.prob[0].sigma, a.prob[0].ld_sigma, 0, 0, lds, executed);
@@ -995,9 +878,6 @@ struct Schedule {
   int4* tail = nullptr;    // [n_tail] {tile code, Q, first partial slot, 0}
   int ngroups = 0, n_tail = 0, pieces = 0;
 };
-#ifndef MDG_I8_TAIL_SPLIT
-#define MDG_I8_TAIL_SPLIT 1     // 0: the last round runs whole tiles on (tiles mod 256) CUs
-#endif
 constexpr int TAIL_MAX_Q = 16;         // k-chunks per tile of the split round(s) (a chunk should stay much longer than the 2-3 k-steps of ring fill)
 constexpr int TAIL_MAX_PIECES = 1024;  // partial tiles (chunks of all split tiles together)
 constexpr size_t PARTIAL_BYTES = (size_t)TAIL_MAX_PIECES * TI * 128 * sizeof(double);   // partial tiles of at most 128 x 128
@@ -1081,7 +961,7 @@ const Schedule* schedule_for(const std::vector<std::pair<int, int>>& shapes, int
     if (cost < best - 0.02) { best = cost; Q = q; }
   }
   Schedule sch;
-  if (MDG_I8_TAIL_SPLIT && Q >= 2) {
+  if (Q >= 2) {
     for (size_t i = 0; i < whole_groups; i++) emit(groups[i]);
     // piece t Q + q = chunk q of tile t; piece p runs in tail round p / 256 on XCD p % 8; its partial tile is slot p
     const int pieces = R * Q, tail_rounds = (pieces + 255) / 256;
@@ -1233,15 +1113,13 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
   const int rb = n / TI;
   // the persistent launch: one workgroup per CU, tiles of all statistics from one static schedule
   const Schedule* sched_of[2] = {nullptr, nullptr};
-#if MDG_I8_LOCKSTEP
-  if (rb >= MDG_I8_LOCKSTEP_MIN_ROWS || count > 1 || problems[0].batch > 1) {
+  if (rb >= PERSISTENT_MIN_ROWS || count > 1 || problems[0].batch > 1) {
     int dev = 0, n_cu = 0;
     MDG_HIP(hipGetDevice(&dev));
     MDG_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     if (n_cu == 256)   // 8 XCDs x 32 CUs is what the tables are cut for
       for (int i = 0; i < 2; i++) sched_of[i] = schedule_for(shapes, i + 1);
   }
-#endif
   MDG_CHECK_ARG((count == 1 && problems[0].batch == 1) || (sched_of[0] && sched_of[1]),
                 "mdg_cov_accum_i8_multi: several statistics in one launch, and per-head statistics, need the persistent launch (a "
                 "256-CU device); use mdg_cov_accum_i8 per full statistic and mdg_cov_accum for the per-head ones");
@@ -1254,19 +1132,13 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
   a.partial = partial;
   if (ev_start) MDG_HIP(hipEventRecord((hipEvent_t)ev_start, st));
   for (int planes_used = 5; planes_used <= 6; planes_used++) {
-#ifdef MDG_EXPERIMENT   // knob of scripts/bench_kernels.py (force one product kernel); compiled out of the product library
-    if (const char* ev = getenv("MDG_I8_PLANES")) {
-      if (atoi(ev) != planes_used) continue;
-      a.force_route = planes_used == 5 ? 0 : 1;
-    }
-#endif
     const bool wide = wide_tile(planes_used);                                  // 128 x 128 tiles; six planes: 128 x 64
     const int tj = wide ? 128 : 64;
     const size_t lds = (size_t)ring_depth(planes_used) * planes_used * (PA + tj * KS);
-    const int si = planes_used == 5 ? MDG_I8_SB5 : MDG_I8_SB6;                 // super-block rows (see the kernel); 0 = row-major
-    const int sr = si ? (rb + si - 1) / si : 0, nsb = sr * (sr + 1) / 2;       // super-block rows, super-blocks
+    const int si = planes_used == 5 ? SB5 : SB6;                               // super-block rows (see the kernel)
+    const int sr = (rb + si - 1) / si, nsb = sr * (sr + 1) / 2;                // super-block rows, super-blocks
     const int tps = wide ? si * si : 2 * si * si;                              // tiles per super-block
-    dim3 grid(si ? (unsigned)((nsb + 7) / 8 * 8 * tps) : (unsigned)(wide ? rb * (rb + 1) / 2 : rb * (rb + 1)));
+    dim3 grid((unsigned)((nsb + 7) / 8 * 8 * tps));
     const Schedule* sch = sched_of[wide ? 0 : 1];
     a.sched = nullptr;
     a.tail = nullptr;
@@ -1358,9 +1230,6 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
         six |= pf[i] & 1;
       }
     *used_i8 = live ? (six ? 6 : 5) : 0;     // the route of the statistics that stayed on the int8 path; 0: all went to the fp64 kernel
-#ifdef MDG_EXPERIMENT
-    if (const char* ev = getenv("MDG_I8_PLANES")) if (live) *used_i8 = atoi(ev);
-#endif
   }
   return MDG_OK;
 }

@@ -1,4 +1,5 @@
 # Build-flag sweep of the int8 product kernel on the GPU box (run through gpurun): rebuilds cov_i8.o with each flag set,
+# NOTE (round 3): the -D knobs this script sweeps were moved out of cov_i8.hip; apply scripts/probes/cov_i8_variants.patch first.
 # relinks the library and runs scripts/bench_kernels.py covi8 (Gaussian columns: five planes) and covi8p6 (SiLU-gated: six).
 #   usage: bash scripts/probes/i8_variants.sh "-DA=1 -DB=2" "-DA=2" ...      (I8_MODE="covi8 covi8p6" by default)
 set -e

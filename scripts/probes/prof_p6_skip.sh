@@ -1,5 +1,6 @@
 #!/bin/bash
 # PMC comparison of the six-plane kernel with and without zero-plane skipping on SiLU-gated data (why is skipping slower there?)
+# NOTE (round 3): -DMDG_I8_SKIP_ZERO6 lived in round 1; the later knob set is in scripts/probes/cov_i8_variants.patch.
 export TMPDIR=/tmp
 R=$PWD
 for skip in 0 1; do

@@ -58,5 +58,5 @@ def test_fold_interval_in_the_kernel_source_matches():
     import os
     import re
     src = open(os.path.join(os.path.dirname(__file__), "..", "modegpt_amd", "csrc", "cov_i8.hip")).read()
-    assert int(re.search(r"#define MDG_I8_FLUSH_STEPS (\d+)", src).group(1)) == FLUSH_STEPS
+    assert int(re.search(r"constexpr int FLUSH_STEPS = (\d+);", src).group(1)) == FLUSH_STEPS
     assert int(re.search(r"constexpr int TOP_SHIFT = 8 \* NP - (\d+)", src).group(1)) == 8 * NP_ - TOP_SHIFT
