@@ -14,20 +14,18 @@ and weights are resident in HBM before the timed region.  With N GPUs every rank
 (weak scaling, no data-path collective) and ONE all-gather at the end of the timed region reassembles all N*K
 compressed layers on every rank.
 
-The JSON line also carries
-  roofline     -- the dominant kernel.  Default covariance route (--cov-mode i8, exact int8 digit planes): i8_syrk_kernel on
-                  sigma_mlp, int8 MFMA bound -- algorithmic int8 ops of its launches in the timed region (plane pairs x SYRK
-                  count) / their summed durations, timed alone by HIP events the library records around that kernel on the
-                  launch stream; the v_mfma_f64 kernel on the same batch is reported beside it as roofline.f64_route.
-                  --cov-mode f64: cov_accum_multi_kernel, fp64 MFMA bound -- SYRK flops of the fused launches / their
-                  durations (HIP events around each launch)
-  cpu_baseline -- this repo's CPU oracle (torch-CPU fp64 restatement of the reference) timed on the host cores
-                  on a bounded sample of the same workload (N = 1, rank 0 only)
-  value_f64_route / value_gated -- the SAME step loop timed again (N = 1 only, after the headline): everything on v_mfma_f64
-                  (--cov-mode f64: the reference's accumulation, no int8 route), and with SiLU-gated sigma_mlp activations (what
-                  a real Llama MLP feeds the hook: the depth statistic then picks six digit planes instead of five)
-  roofline.decomposition -- the compress_nystrom / compress_qk / compress_vo chain of the timed steps: fp64 flops executed
-                  (model below) / HIP-event time / the fp64 MFMA peak
+The JSON line carries numbers and short labels only ("The bench line, field by field", explains each):
+  roofline     -- the dominant kernel.  Default covariance route (--cov-mode i8: error-free split into int8 digit planes, truncated
+                  plane-pair product): i8_syrk_kernel on sigma_mlp, int8 MFMA bound, priced on the MFMAs it ISSUED, timed alone by
+                  HIP events the library records around it on the launch stream; .algorithmic restates it in SURVEY 8(d)'s fp64-SYRK
+                  units; .error_bound is the per-call guaranteed bound the device computed; .f64_route the v_mfma_f64 kernel on the
+                  same batch.  --cov-mode f64: cov_accum_multi_kernel, fp64 MFMA bound
+  cpu_baseline -- this repo's CPU oracle (torch-CPU fp64 restatement of the reference) timed on the host cores on a bounded
+                  sample of the same workload (N = 1, rank 0 only); full_size_parity_vs_oracle: its outputs against the GPU's
+  value_f64_route / value_gated / value_massive -- the SAME step loop timed again (N = 1 only, after the headline): everything
+                  on v_mfma_f64; SiLU-gated sigma_mlp activations (what a real Llama MLP feeds the hook: six planes); four
+                  massive-activation columns in sigma_mlp and sigma_x (they leave the launch alone, through the fp64 column kernel)
+  i8_vs_f64_outputs -- the headline leg's compressed tensors against the f64 leg's, same layers, full token count
 """
 from __future__ import annotations
 
@@ -249,10 +247,7 @@ def cpu_baseline(shape, weights, covs_dev, sample, n_tokens_full, keep, ridges, 
     t_dec = time.perf_counter() - t0
     t_cov_full = t_cov_sample * (n_tokens_full / sample_tokens)
     parity = {
-        "sigma_vs_oracle_entrywise_max": sigma_err,
-        "sigma_check": (f"the four statistics of the first {sample_tokens} tokens of batch 0 through the engine's default route "
-                        "(int8 digit planes for sigma_mlp / sigma_x unless --cov-mode f64) against the oracle's fp64 H^T H of the "
-                        "same rows: max over the lower triangle of |diff| / sqrt(s_ii s_jj)"),
+        "sigma_vs_oracle_entrywise_max": sigma_err, "sigma_tokens": sample_tokens,
         "mlp_idx_identical": bool(torch.equal(out["aux"]["mlp"][0], gpu_out["mlp_idx"].cpu())),
         "qk_mask_identical": bool(torch.equal(out["mask"], gpu_out["mask"].cpu())),
         "up_identical": bool(torch.equal(out["mlp"]["up"], gpu_out["up"].cpu())),
@@ -262,10 +257,8 @@ def cpu_baseline(shape, weights, covs_dev, sample, n_tokens_full, keep, ridges, 
     }
     return {
         "value": 1.0 / (t_cov_full + t_dec), "unit": "layers/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": (f"oracle (torch-CPU fp64, {torch.get_num_threads()} threads): covariance of the 4 hooks timed on "
-                   f"{sample_tokens} tokens = {t_cov_sample:.2f} s, scaled x{n_tokens_full // sample_tokens} to "
-                   f"{n_tokens_full} tokens = {t_cov_full:.0f} s; mlp+qk+vo decomposition/rebuild of one layer timed "
-                   f"in full = {t_dec:.2f} s"),
+        "sample": (f"oracle, torch-CPU fp64: 4 hooks' covariance on {sample_tokens} tokens {t_cov_sample:.2f} s x"
+                   f"{n_tokens_full // sample_tokens} = {t_cov_full:.0f} s; decomposition of one layer in full {t_dec:.2f} s"),
         "full_size_parity_vs_oracle": parity,
     }
 
@@ -294,10 +287,9 @@ def rope_gather_roofline(shape, keep, dev, launches=20):
     us = e0.elapsed_time(e1) / launches * 1e3
     nbytes = 2 * x.numel() * x.element_size()            # every element read once and written once
     gbs = nbytes / (us * 1e-6) / 1e9
-    return {"kernel": "rope_gather_kernel (compressed-head RoPE: cos/sin gathered by the rotary mask, fused transpose)",
-            "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-            "avg_launch_us": us, "bytes_per_launch": nbytes, "launches": launches, "dtype": "bf16",
-            "workload": f"q projection [16, 2048, {n_h} x {r}] of {hd}-wide heads, {n_kv} kv masks"}
+    return {"kernel": "rope_gather_kernel", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gbs / HBM_PEAK_GBS, "avg_launch_us": us, "bytes_per_launch": nbytes, "launches": launches,
+            "workload": f"q [16, 2048, {n_h} x {r}] bf16"}
 
 
 def parse_args(argv=None):
@@ -433,10 +425,11 @@ def main():
     pipe = Pipeline(shape, adapter, batches, a.keep, n_texts, timer, enabled=pipelined)
     for i in range(a.steps):
         pipe.submit(first + a.warmup + i)
-    records, last = [], None
+    records, last, done = [], None, []
     for li, tensors, mask, covs in pipe.drain():
         records.append(sharding.pack_layer(li, {k: tensors.get(k) for k in sharding.TENSOR_ORDER}, mask))
         last = (li, tensors, mask, covs)
+        done.append((li, tensors, mask, None))          # (compressed tensors of every timed layer: compared with the f64 leg's below)
     gathered = sharding.allgather_records(records, a.steps, world)  # the single RCCL all-gather (no-op copy at N=1)
     torch.cuda.synchronize()
     if world > 1:
@@ -450,14 +443,18 @@ def main():
     del gathered, records
 
     i8 = ops.COV_MODE == "i8" and shape["arch"] != "opt"
-    stats = {}
+    stats, bounds = {}, []
     if i8:
         # The product kernel skips digit planes that are all-zero over a tile panel; `achieved` prices the MFMA work it
-        # actually issued.  Route and executed / dense instruction ratio of the timed launches are read back from the library
-        # on a replay of the same batches (the data and the integer route statistic are deterministic), outside the timed region.
+        # actually issued.  Route, error bound and executed / dense instruction ratio of the timed launches are read back from the
+        # library on a replay of the same batches (the data and the integer route statistics are deterministic), outside the timed region.
         replay = torch.zeros(shape["d_ff"], shape["d_ff"], dtype=torch.float64, device=dev)
         routes_before = dict(ops.I8_STATS)
-        planes_per_batch = [ops.cov_accum_i8(replay, b["h"], mfma_stats=stats) for b in batches]
+        planes_per_batch = []
+        for b in batches:
+            info = {}
+            planes_per_batch.append(ops.cov_accum_i8(replay, b["h"], mfma_stats=stats, route_info=info))
+            bounds.append(info)
         ops.I8_STATS.update(routes_before)
         del replay
         timer.price_i8(planes_per_batch)
@@ -468,7 +465,7 @@ def main():
     # HBM bytes per launch come from a separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run of the same kernel on the
     # same launch shape (PMC passes cannot ride along a timed run); only valid for the default workload.
     traffic, tfile = None, None
-    for cand in (("r02_cov_i8_hbm_traffic.json", "r01_cov_i8_hbm_traffic.json") if i8 else ("r01_cov_hbm_traffic.json",)):
+    for cand in (("r03_cov_i8_hbm_traffic.json", "r02_cov_i8_hbm_traffic.json") if i8 else ("r01_cov_hbm_traffic.json",)):
         tpath = os.path.join(ROOT, "profiles", cand)
         if os.path.exists(tpath) and a.model == "llama-3-8b" and a.batch_size == 16:
             with open(tpath) as f:
@@ -477,66 +474,44 @@ def main():
     dec_tf = dec_flops / (dec_ms * 1e-3) / 1e12 if n_dec else None
     decomposition = None if not n_dec else {
         "bound": "mfma", "achieved": dec_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dec_tf / FP64_MFMA_PEAK_TFLOPS,
-        "kernel": "the compress_nystrom + compress_qk + compress_vo chain of one layer (potrf / triangular inverse / gathered GEMM / "
-                  "potrs / Gram-route VO: gemm_f64_kernel around potrf_diag_kernel and syevj_kernel), HIP events around the chain",
-        "avg_ms_per_layer": dec_ms / n_dec, "flop_per_layer": dec_flops / n_dec, "layers": n_dec,
-        "flop_count": "executed: 2 n^3 / 3 (Cholesky + triangular inverse for the ridge scores) + 2 r n d + r^3 / 3 + 2 r^2 d (Nystrom) "
-                      "+ 2 (n_kv hd) d^2 + head-sized products (VO Gram route); bench.py decomposition_flops()",
-        "share_of_step": dec_ms / n_dec / (elapsed / a.steps * 1e3),
-        "timed": ("on the side stream, beside the next layer's covariance kernels (pipelined): the figure includes the time its "
-                  "workgroups wait for CUs; --no-pipeline times the chain alone") if pipelined else "alone on the caller's stream"}
+        "avg_ms_per_layer": dec_ms / n_dec, "flop_per_layer": dec_flops / n_dec, "share_of_step": dec_ms / n_dec / (elapsed / a.steps * 1e3)}
+    # The JSON line carries numbers and short labels only; what each field means is written down in DESIGN.md section 7
+    # ("The bench line, field by field").
     out = {
         "metric": "transformer layers compressed/sec (covariance+decomp+rebuild), Llama-3-8B @30%",
         "value": world * a.steps / elapsed, "unit": "layers/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": ("fp64 result emulated on int8 MFMA digit planes (int32 accumulate, folded in f64; <= 1e-12 entry-wise of the "
-                  "fp64 product, measured per run in cpu_baseline.full_size_parity_vs_oracle)") if i8 else "f64",
+        "dtype": "f64 emulated on int8 MFMA digit planes (error <= 1.1e-11 guaranteed per call, <= 1e-12 measured)" if i8 else "f64",
         "data": "synthetic",
-        "config": {"workload": f"{a.model} shapes, {n_texts} calibration samples x 2048 tokens in {a.batches} batches "
-                               f"of {a.batch_size}, keep ratio {a.keep} (compression {1 - a.keep:.0%}), ridges "
-                               f"{ridges}, one layer per step per GPU", "layers_per_gpu": a.steps,
-                   "activations": "Gaussian columns x per-feature scale log-uniform[0.05, 2] (SURVEY 8d's generator); the same "
-                                  "loop on SiLU-gated sigma_mlp activations: value_gated",
-                   "parallelism": f"layer-sharded x{world}, one all-gather",
-                   "pipelined": pipelined,
-                   "pipelined_is": "--pipeline: layer L's decomposition chain on a high-priority side stream beside layer L + 1's "
-                                   "covariance kernels (bench.py Pipeline); default: one after the other (see value_pipelined)"},
+        "config": {"workload": f"{a.model} shapes, {n_texts} samples x 2048 tokens in {a.batches} batches of {a.batch_size}, keep {a.keep}, "
+                               f"tests.sh ridges, Gaussian columns x log-uniform[0.05, 2] scales (SURVEY 8d)",
+                   "layers_per_gpu": a.steps, "parallelism": f"layer-sharded x{world}, one all-gather", "pipelined": pipelined},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                     "traffic_unit": f"HBM bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), profiles/{tfile}",
-                     "kernel": "cov_accum_multi_kernel (v_mfma_f64_16x16x4_f64; sigma_mlp + sigma_x + sigma_q + sigma_k of "
-                               "one calibration batch in one launch)", "launches": n_launch,
-                     "avg_launch_ms": ms / n_launch, "flop_per_launch": flops / n_launch,
-                     "flop_count": "SYRK: tokens * sum over the four problems of n * (n + 1) per launch"},
+                     "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_from": tfile,
+                     "kernel": "cov_accum_multi_kernel (v_mfma_f64_16x16x4_f64)", "launches": n_launch,
+                     "avg_launch_ms": ms / n_launch, "flop_per_launch": flops / n_launch},
     }
     if i8:
         f = shape["d_ff"]
         executed_fraction = stats["executed"] / stats["dense"] if stats.get("dense") else 1.0
         dense_equivalent = achieved
         achieved = achieved * executed_fraction
+        syrk_tf = n_launch * batches[0]["h"].shape[0] * f * (f + 1) / (ms * 1e-3) / 1e12
         out["roofline"] = {
             "bound": "mfma", "achieved": achieved, "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s",
-            "frac": achieved / INT8_MFMA_PEAK_TOPS, "executed_fraction": executed_fraction,
+            "frac": achieved / INT8_MFMA_PEAK_TOPS, "traffic": traffic, "traffic_from": tfile,
+            "kernel": "i8_syrk_kernel on sigma_mlp (v_mfma_i32_32x32x32_i8), issued MFMAs", "launches": n_launch,
+            "avg_launch_ms": ms / n_launch, "op_per_launch": flops / n_launch, "executed_fraction": executed_fraction,
             "dense_equivalent_tops": dense_equivalent,
-            "achieved_is": "int8 ops of the v_mfma instructions the kernel issued (mdg_cov_accum_i8_stats: executed / dense "
-                           "instruction count of these batches x the dense op count below) / their summed durations; "
-                           "dense_equivalent_tops counts the skipped all-zero planes as if multiplied",
-            "traffic": traffic,
-            "traffic_unit": f"HBM bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), profiles/{tfile}",
-            "kernel": "i8_syrk_kernel on sigma_mlp (v_mfma_i32_32x32x32_i8; the 15 (5 planes) or 21 (6 planes) digit-plane "
-                      "pair products of one calibration batch per launch, timed alone by events the library records around it)",
-            "launches": n_launch, "avg_launch_ms": ms / n_launch, "op_per_launch": flops / n_launch,
-            "op_count": "dense count: plane pairs (15 or 21, see routes) x tokens x n (n + 1), the SYRK count of each product, "
-                        "2 ops per multiply-add",
-            "fp64_syrk_equivalent_tflops": n_launch * batches[0]["h"].shape[0] * f * (f + 1) / (ms * 1e-3) / 1e12,
+            "algorithmic": {"fp64_syrk_tflops": syrk_tf, "x_fp64_mfma_peak": syrk_tf / FP64_MFMA_PEAK_TFLOPS,
+                            "frac_of_int8_peak": syrk_tf / INT8_MFMA_PEAK_TOPS},
             "routes": ops.i8_route_counts(dev),
-            "routes_are": "every int8-route request of this process so far (warm-up, timed steps, the replay above), counted on "
-                          "the device by the kernel that ran",
-            "note": "sigma_x goes through the same kernel; sigma_q / sigma_k (1.4 % of the work) and any batch whose columns the "
-                    "per-column depth statistic finds too heavy-tailed for six planes go through the v_mfma_f64 kernel (--cov-mode f64 runs everything there)",
-            "power_note": "while this kernel loops the device sits at its power cap (rocm-smi: 1330 W, sclk 1.94 GHz instead of 2.4; "
-                          "scripts/probes/i8_clock_power.py): at that clock the int8 pipe peaks at 4.0 POP/s; `peak` above is the guide's 2.4 GHz figure"}
+            "error_bound": {"guaranteed_max": max(b_["bound"] for b_ in bounds), "sq_max": max(b_["sq"] for b_ in bounds),
+                            "x_max": max(b_["x"] for b_ in bounds), "planes": sorted(set(planes_per_batch)),
+                            "fp64_columns_per_batch_max": max(len(b_["columns"]) for b_ in bounds)}}
     out["roofline"]["decomposition"] = decomposition
+    ids = [first + a.warmup + i for i in range(a.steps)]
+    headline_out = {li: (tensors, mask) for li, tensors, mask, _ in done}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         li, tensors, mask, covs = last
         gpu_out = dict(tensors)
@@ -548,12 +523,8 @@ def main():
         out["roofline"]["measured_mfma_f64_issue_rate_tflops"] = ops.probe_mfma_f64(4096)
         if i8:
             zero, rnd = ops.probe_mfma_i8(random_operands=False), ops.probe_mfma_i8(random_operands=True)
-            out["roofline"]["measured_i8_mfma_rate_tops"] = {
-                "zero_operands": zero, "random_operands": rnd,
-                "frac_of_random_operand_rate": out["roofline"]["achieved"] / rnd,
-                "what": "mdg_probe_mfma_i8: v_mfma_i32_32x32x32_i8 back to back from registers (no LDS, no memory), two waves per "
-                        "SIMD on every CU, operands changing every MFMA.  With random bytes the board is at its power cap and the "
-                        "clock gives way: that rate, not the nominal `peak`, is the ceiling of any int8 kernel on random data"}
+            out["roofline"]["measured_i8_mfma_rate_tops"] = {"zero_operands": zero, "random_operands": rnd,
+                                                             "frac_of_random_operand_rate": out["roofline"]["achieved"] / rnd}
         h = batches[0]["h"]
         if i8:  # the same sigma_mlp batch through the v_mfma_f64 kernel, for the record, and the two routes against each other
             scratch = torch.zeros_like(covs["mlp"])
@@ -565,13 +536,13 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             tf = 2 * h.shape[0] * shape["d_ff"] * (shape["d_ff"] + 1) / (e0.elapsed_time(e1) * 1e-3) / 1e12
-            out["roofline"]["f64_route"] = {"kernel": "cov_accum_kernel (v_mfma_f64_16x16x4_f64) on the same sigma_mlp batch",
-                                            "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                            "frac": tf / FP64_MFMA_PEAK_TFLOPS, "avg_launch_ms": e0.elapsed_time(e1) / 2}
+            out["roofline"]["f64_route"] = {"kernel": "cov_accum_kernel (v_mfma_f64_16x16x4_f64), same batch", "achieved": tf,
+                                            "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS,
+                                            "avg_launch_ms": e0.elapsed_time(e1) / 2}
             s8 = torch.zeros_like(scratch)
             for _ in range(3):
                 ops.cov_accum_i8(s8, h, report=False)
-            out["roofline"]["sigma_i8_vs_f64_entrywise_max"] = entrywise_err(s8, scratch)   # one full batch x 3, both routes
+            out["roofline"]["error_bound"]["sigma_i8_vs_f64_entrywise_max"] = entrywise_err(s8, scratch)   # one full batch x 3, both routes
             del scratch, s8
         # the first rows of batch 0 through the engine's default route, for the sigma check against the oracle
         n_sample = min(8192, h.shape[0])
@@ -580,35 +551,33 @@ def main():
         engine.accumulate(sig_sample, sample_dev, shape)
         sample = {k: v.cpu() for k, v in sample_dev.items()}
         out["cpu_baseline"] = cpu_baseline(shape, layers[li], covs, sample, n_texts * 2048, a.keep, ridges, gpu_out, sig_sample)
+        out["full_size_parity_vs_oracle"] = out["cpu_baseline"].pop("full_size_parity_vs_oracle")
         del sig_sample
         if shape["arch"] != "opt":
             out["next_rows"] = {"rope_gather": rope_gather_roofline(shape, a.keep, dev)}
     elif rank == 0:
         out["cpu_baseline"] = None
-    del last
+    del last, done
     if rank == 0 and world == 1 and not a.no_extra_legs and shape["arch"] != "opt":
-        ids = [first + a.warmup + i for i in range(a.steps)]
         if i8:
-            # (1) the faithful route: the SAME step loop with every covariance on v_mfma_f64 (SURVEY section 7's parity path)
+            # (1) the faithful route: the SAME step loop with every covariance on v_mfma_f64 (SURVEY section 7's parity path) --
+            #     and its compressed tensors against the headline leg's, layer by layer, at the full token count
             ops.COV_MODE = "f64"
             t64 = LaunchTimer()
-            sec, _ = timed_steps(shape, adapter, ids, batches, a.keep, n_texts, t64, pipelined)
+            sec, outs64 = timed_steps(shape, adapter, ids, batches, a.keep, n_texts, t64, pipelined)
             nl, fl, msl = t64.summary()
-            out["value_f64_route"] = {"value": len(ids) / sec, "unit": "layers/s", "ms_per_step": sec / len(ids) * 1e3, "steps": len(ids),
-                                      "dtype": "f64", "cov_kernel_tflops": fl / (msl * 1e-3) / 1e12,
+            out["value_f64_route"] = {"value": len(ids) / sec, "ms_per_step": sec / len(ids) * 1e3, "steps": len(ids),
+                                      "cov_kernel_tflops": fl / (msl * 1e-3) / 1e12,
                                       "cov_kernel_frac_of_fp64_peak": fl / (msl * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
-                                      "avg_launch_ms": msl / nl,
-                                      "what": "same workload and loop, --cov-mode f64: cov_accum_multi_kernel (v_mfma_f64) for all four statistics"}
+                                      "avg_launch_ms": msl / nl}
+            out["i8_vs_f64_outputs"] = compare_outputs(headline_out, outs64, n_texts * 2048)
+            del outs64
             ops.COV_MODE = "i8"
             # (1b) the default route with layer L's decomposition beside layer L + 1's covariance (bench.py Pipeline)
             if not pipelined:
                 tp = LaunchTimer()
                 sec, _ = timed_steps(shape, adapter, ids, batches, a.keep, n_texts, tp, True)
-                n_d, _, d_ms = tp.decomposition_summary()
-                out["value_pipelined"] = {"value": len(ids) / sec, "unit": "layers/s", "ms_per_step": sec / len(ids) * 1e3, "steps": len(ids),
-                                          "decomposition_ms_per_layer_on_the_side_stream": d_ms / n_d,
-                                          "what": "same workload, layer L's compress_* chain on a high-priority side stream beside layer "
-                                                  "L + 1's covariance kernels; of `steps` layers the last one's chain has nothing to hide behind"}
+                out["value_pipelined"] = {"value": len(ids) / sec, "ms_per_step": sec / len(ids) * 1e3}
             # (2) SiLU-gated sigma_mlp activations, what a real Llama MLP feeds the hook (LlamaAdapter.py:127-136): six planes
             gated = []
             for b, bt in enumerate(batches):
@@ -617,29 +586,72 @@ def main():
                 g.mul_(torch.randn(bt["h"].shape, generator=gen, device=dev, dtype=torch.float32))
                 gated.append({"h": g.to(torch.bfloat16), "x": bt["x"], "q": bt["q"], "k": bt["k"]})
                 del g
-            before = ops.i8_route_counts(dev)
-            step(shape, adapter, ids[0], gated, a.keep, n_texts)                                  # warm-up of the six-plane kernel
-            tg = LaunchTimer()
-            sec, _ = timed_steps(shape, adapter, ids, gated, a.keep, n_texts, tg, pipelined)
-            after = ops.i8_route_counts(dev)
-            st6 = {}
-            scratch = torch.zeros(f, f, dtype=torch.float64, device=dev)
-            used = ops.cov_accum_i8(scratch, gated[0]["h"], mfma_stats=st6)
-            del scratch, gated
-            nl, _, msl = tg.summary()
-            frac6 = st6["executed"] / st6["dense"] if st6.get("dense") else 1.0
-            pairs = {5: 15, 6: 21}.get(used, 15)
-            tops_dense = pairs * nl * tokens * f * (f + 1) / (msl * 1e-3) / 1e12
-            out["value_gated"] = {"value": len(ids) / sec, "unit": "layers/s", "ms_per_step": sec / len(ids) * 1e3, "steps": len(ids),
-                                  "planes": used, "avg_launch_ms": msl / nl, "executed_fraction": frac6,
-                                  "achieved": tops_dense * frac6, "peak": INT8_MFMA_PEAK_TOPS, "unit_kernel": "TOP/s",
-                                  "frac": tops_dense * frac6 / INT8_MFMA_PEAK_TOPS, "dense_equivalent_tops": tops_dense,
-                                  "routes": {k: after[k] - before[k] for k in after},
-                                  "what": "same loop, sigma_mlp activations silu(g) * u (g, u ~ N(0,1)) instead of Gaussian columns; "
-                                          "sigma_x / sigma_q / sigma_k inputs unchanged"}
+            out["value_gated"] = extra_leg(shape, adapter, ids, gated, a.keep, n_texts, pipelined, dev, tokens)
+            del gated
+            # (3) massive activations: four BOS-like columns (bulk 12-15 binades under three spikes per batch) in the residual
+            #     stream statistic AND in the MLP statistic -- they leave the int8 launch alone, through the fp64 column kernel
+            massive = []
+            for b, bt in enumerate(batches):
+                gen = torch.Generator(device=dev).manual_seed(777 + b)
+                nb = dict(bt)
+                for key, cols in (("h", (5, 129, shape["d_ff"] // 2 + 77, shape["d_ff"] - 1)), ("x", (3, 1000, 2533, shape["d"] - 2))):
+                    t = bt[key].clone()
+                    for i, c in enumerate(cols):
+                        top = t[:, c].float().abs().max()
+                        t[:, c] = (t[:, c].float() * 2.0 ** -(12 + i)).to(torch.bfloat16)
+                        rows = torch.randperm(t.shape[0], device=dev, generator=gen)[:3]
+                        t[rows, c] = (top * (1.0 + torch.rand(3, device=dev, generator=gen))).to(torch.bfloat16)
+                    nb[key] = t
+                massive.append(nb)
+            out["value_massive"] = extra_leg(shape, adapter, ids, massive, a.keep, n_texts, pipelined, dev, tokens)
+            out["value_massive"]["vs_value"] = out["value_massive"]["value"] / out["value"]
     if rank == 0:
         print(json.dumps(out))
     sharding.finalize()
+
+
+def compare_outputs(headline, outs64, n_tokens):
+    """The headline leg's compressed tensors (default int8 route) against the --cov-mode f64 leg's, same layers, full token count:
+    selections (gathered rows, rotary mask) must be bit-identical, solved tensors agree to the stated tolerance."""
+    res = {"layers": 0, "tokens": n_tokens, "up_identical": True, "gate_identical": True, "q_proj_identical": True,
+           "k_proj_identical": True, "mask_identical": True, "down_max_rel": 0.0, "v_proj_max_rel": 0.0, "o_proj_max_rel": 0.0,
+           "down_bf16_mismatch_frac": 0.0}
+    for li, t64, m64, _ in outs64:
+        if li not in headline:
+            continue
+        t8, m8 = headline[li]
+        res["layers"] += 1
+        for k in ("up", "gate", "q_proj", "k_proj"):
+            if k in t8 and t8[k] is not None:
+                res[k + "_identical"] = res[k + "_identical"] and bool(torch.equal(t8[k], t64[k]))
+        res["mask_identical"] = res["mask_identical"] and bool(torch.equal(m8, m64))
+        for k in ("down", "v_proj", "o_proj"):
+            a8, a64 = t8[k].double(), t64[k].double()
+            res[k + "_max_rel"] = max(res[k + "_max_rel"], float(((a8 - a64).abs().max() / a64.abs().max()).item()))
+        res["down_bf16_mismatch_frac"] = max(res["down_bf16_mismatch_frac"], float((t8["down"] != t64["down"]).double().mean().item()))
+    return res
+
+
+def extra_leg(shape, adapter, ids, data, keep, n_texts, pipelined, dev, tokens):
+    """The same step loop on other sigma_mlp / sigma_x data (value_gated, value_massive): layers/s, the sigma_mlp product launch
+    timed alone and priced on the MFMAs it issued, the routes the device took and the bound it computed."""
+    f = shape["d_ff"]
+    before = ops.i8_route_counts(dev)
+    step(shape, adapter, ids[0], data, keep, n_texts)                                   # warm-up (the six-plane kernel's first launch)
+    tg = LaunchTimer()
+    sec, _ = timed_steps(shape, adapter, ids, data, keep, n_texts, tg, pipelined)
+    after = ops.i8_route_counts(dev)
+    st6, info = {}, {}
+    scratch = torch.zeros(f, f, dtype=torch.float64, device=dev)
+    used = ops.cov_accum_i8(scratch, data[0]["h"], mfma_stats=st6, route_info=info)
+    del scratch
+    nl, _, msl = tg.summary()
+    frac = st6["executed"] / st6["dense"] if st6.get("dense") else 1.0
+    pairs = {5: 15, 6: 21}.get(used, 15)
+    tops_dense = pairs * nl * tokens * f * (f + 1) / (msl * 1e-3) / 1e12
+    return {"value": len(ids) / sec, "ms_per_step": sec / len(ids) * 1e3, "steps": len(ids), "planes": used, "avg_launch_ms": msl / nl,
+            "executed_fraction": frac, "achieved": tops_dense * frac, "frac": tops_dense * frac / INT8_MFMA_PEAK_TOPS,
+            "routes": {k: after[k] - before[k] for k in after}, "error_bound": info.get("bound"), "fp64_columns_mlp": info.get("columns")}
 
 
 if __name__ == "__main__":

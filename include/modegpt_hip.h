@@ -26,11 +26,14 @@
 extern "C" {
 #endif
 
-#define MDG_ABI_VERSION 6 /* 2: w_dtype on mdg_nystrom_down / mdg_vo_compress, mdg_rope_gather added; 3: mdg_cov_accum_i8_stats added;
+#define MDG_ABI_VERSION 7 /* 2: w_dtype on mdg_nystrom_down / mdg_vo_compress, mdg_rope_gather added; 3: mdg_cov_accum_i8_stats added;
                              4: mdg_cov_accum_i8 chooses its route on the device (route_counts argument, no host synchronisation);
                                 mdg_comm_* / mdg_allgather_layers added;
                              5: mdg_potrs_lower takes a workspace (mdg_potrs_lower_ws_bytes);
-                             6: mdg_cov_accum_i8_multi added (several statistics in one int8 launch); the int8 workspace layout changed */
+                             6: mdg_cov_accum_i8_multi added (several statistics in one int8 launch); the int8 workspace layout changed;
+                             7: the int8 route is derived from a per-call error bound, single columns can leave the int8 path for an fp64
+                                column kernel (route_counts has 4 entries, mdg_cov_accum_i8_route added, workspace layout changed);
+                                mdg_shutdown added */
 
 enum mdg_status {
   MDG_OK = 0,
@@ -54,6 +57,11 @@ int mdg_abi_version(void);
 const char* mdg_last_error(void);
 /* Fills name (<= cap bytes) with the gcnArchName of `device`; MDG_ERR_NO_DEVICE if HIP sees no GPU. */
 int mdg_device_info(int device, char* name, int cap, int* n_cu, int64_t* hbm_bytes);
+/* Releases what the library keeps across calls: the device copies of the int8 product's tile schedules (a few KB per shape,
+ * built at first use).  The library owns no HIP streams or events -- those are the caller's -- and makes no HIP call from a static
+ * destructor; call this before the process tears the HIP runtime down (modegpt_amd/_lib.py registers it with atexit), with no
+ * library call in flight.  Safe to call repeatedly; the next covariance call rebuilds what it needs. */
+int mdg_shutdown(void);
 
 /* ------------------------------------------------------------------ covariance (calibration hooks)
  * sigma[b] (lower triangle incl. diagonal tiles) += X_b^T X_b, products and sums in fp64 of the exactly
@@ -80,22 +88,32 @@ typedef struct {
 } mdg_cov_problem;
 size_t mdg_cov_accum_multi_ws_bytes(int n, const mdg_cov_problem* problems, int dtype);
 int mdg_cov_accum_multi(int n, const mdg_cov_problem* problems, int dtype, void* ws, size_t ws_bytes, void* stream);
-/* The same accumulation for ONE bf16 matrix through the int8 matrix cores, exactly (csrc/cov_i8.hip): every bf16 value is
- * split into six balanced base-256 digits against a per-column power-of-two scale; the digit-plane products with
- * s + t < P are formed by v_mfma_i32_32x32x32_i8 with exact int32 accumulation and folded into sigma in fp64 every 65504
- * tokens (the exact int32 bound).  Each call measures, per column, the share of its nonzero elements more than 10 binades below the column maximum and picks
- * P = 5 (share <= 1/64 everywhere: within ~2e-13 of sigma's scale), P = 6 (<= 1/4: <= ~1e-13 on gated activations) or
- * runs mdg_cov_accum on the batch itself (heavier tails, columns dominated by a few massive activations).
- * The route is chosen ON THE DEVICE: the call enqueues the five-plane product, the six-plane product and the fp64 kernel back to
- * back, and the launches the depth statistic does not select exit at once -- the call only enqueues and never waits for the
- * host (it can be captured in a hipGraph) when used_i8 is NULL.
- * route_counts (DEVICE pointer to 3 ints, optional): [0] += 1 when five planes ran, [1] six planes, [2] the fp64 kernel; the
- *   caller keeps it across calls and reads it whenever it likes (calibration reads it once, at the end).
+/* The same accumulation for ONE bf16 matrix through the int8 matrix cores (csrc/cov_i8.hip): an ERROR-FREE SPLIT of every bf16 value
+ * into six balanced base-256 digits against a per-column power-of-two scale, and a TRUNCATED PRODUCT -- the digit-plane products with
+ * s + t < P are formed by v_mfma_i32_32x32x32_i8 with exact int32 accumulation and folded into sigma in fp64 every 65504 tokens (the
+ * exact int32 bound); the pairs with s + t >= P are dropped.  What the dropped pairs can amount to is bounded per call from integer
+ * plane energies the split pass accumulates (Cauchy-Schwarz over the tokens; derivation in csrc/cov_i8.hip at i8_route_kernel and
+ * DESIGN.md section 7, host model tests/i8_model.py):
+ *     |sigma_ij - exact| <= (SQ_P + X_P) sqrt(sigma_ii sigma_jj)   entry-wise, for any input,
+ * and the route is the smallest P in {5, 6} with SQ_P <= 1e-12 (the part of the bound that is attained) and X_P <= 1e-11 (cross
+ * terms; 20-50x above what uncorrelated columns produce).  GUARANTEED: <= 1.1e-11; MEASURED on every distribution family of
+ * scripts/probes/i8_fuzz.py and at the product's widths: <= 1e-12.  Columns that alone break the bound -- a bulk 10-15 binades under a
+ * few massive activations, columns holding an Inf / NaN -- leave the int8 path one by one (at most MDG_I8_MAX_COLUMNS per statistic
+ * and call): the fold skips their rows and columns of sigma and an fp64 column kernel (plain fp64 sums of products, the reference's
+ * arithmetic, LlamaAdapter.py:127-147) computes them.  Only when that is not enough does the whole statistic run through
+ * mdg_cov_accum.
+ * The route is chosen ON THE DEVICE: the call enqueues the five-plane product, the six-plane product, the column kernel and the fp64
+ * kernel back to back, and the launches the route does not select exit at once -- the call only enqueues and never waits for the host
+ * (it can be captured in a hipGraph) when used_i8 is NULL.  Every decision is a function of integer sums: run-to-run bit-identical.
+ * route_counts (DEVICE pointer to 4 ints, optional): [0] += 1 when five planes ran, [1] six planes, [2] the fp64 kernel for the whole
+ *   statistic, [3] += the number of columns handed to the fp64 column kernel; the caller keeps it across calls and reads it whenever
+ *   it likes (calibration reads it once, at the end).
  * used_i8 (HOST pointer, optional; measurement and tests): receives the route of THIS call -- 5, 6, or 0 for the fp64 kernel --
  *   at the price of one stream synchronisation.
- * n_feat must be a multiple of 128.  ws: mdg_cov_accum_i8_ws_bytes (about 6 bytes per element of x).
+ * n_feat must be a multiple of 128, n_tokens < 2^28.  ws: mdg_cov_accum_i8_ws_bytes (about 6 bytes per element of x).
  * ev_start / ev_stop: optional hipEvent_t recorded on `stream` right before / after the two product launches (bench.py times
  * the dominant kernel alone with them); NULL otherwise. */
+#define MDG_I8_MAX_COLUMNS 32
 size_t mdg_cov_accum_i8_ws_bytes(int64_t n_tokens, int64_t n_feat);
 int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat, int64_t ld, double* sigma, int64_t ld_sigma, void* ws,
                      size_t ws_bytes, int* used_i8, int* route_counts, void* ev_start, void* ev_stop, void* stream);
@@ -105,12 +123,19 @@ int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat, int64_t ld
  * most -- and on real activations well below -- the dense (tiles) x (k-steps) x (waves) x (MFMAs per step).  Copies 8 bytes
  * device -> host on `stream` and synchronises it.  bench.py prices the kernel with this count. */
 int mdg_cov_accum_i8_stats(const void* ws, int64_t n_tokens, int64_t n_feat, unsigned long long* executed_mfma, void* stream);
+/* The route the LAST mdg_cov_accum_i8 / mdg_cov_accum_i8_multi call on workspace `ws` took for statistic `stat` of `problems` (the
+ * array that call was given): *planes = 5, 6, or 0 (whole statistic through mdg_cov_accum); *n_columns and columns[MDG_I8_MAX_COLUMNS]
+ * (-1 padded) = the columns the fp64 column kernel computed, in the order the route took them; bound[0] = SQ_P, bound[1] = X_P of
+ * the columns that stayed (their sum bounds the entry-wise error relative to sqrt(sigma_ii sigma_jj) of this call's tokens).  Any
+ * output pointer may be NULL.  Copies device -> host on `stream` and synchronises it: tests and measurements only. */
+int mdg_cov_accum_i8_route(int count, const mdg_cov_problem* problems, int stat, const void* ws, int* planes, int* n_columns,
+                           int* columns, double* bound, void* stream);
 /* Up to 4 statistics of ONE calibration batch (the four hooks of a layer) through the int8 digit-plane kernels with ONE
  * persistent product launch: the tiles of all statistics share one static tile schedule, so the small ones fill what the large
- * one's last round leaves idle instead of ending launches of their own, and one route -- the deepest any column of any
- * statistic on the int8 path asks for (more planes are never less exact); a statistic whose columns are too heavy-tailed for six
- * planes leaves the launch alone and goes through mdg_cov_accum (its tiles are skipped on the device).  `problems` is a HOST array,
- * largest statistic first, all with the same n_tokens, bf16.  batch == 1: sigma [n_feat][ld_sigma], n_feat a multiple of 128.
+ * one's last round leaves idle instead of ending launches of their own, and one route -- the deepest any statistic on the int8 path
+ * asks for (more planes never loosen a bound); every statistic has its own bound, its own columns for the fp64 column kernel, and
+ * leaves the launch alone for mdg_cov_accum when its bound cannot be met (its tiles are skipped on the device).  `problems` is a HOST
+ * array, largest statistic first, all with the same n_tokens, bf16.  batch == 1: sigma [n_feat][ld_sigma], n_feat a multiple of 128.
  * batch > 1: per-head Grams of an activation [n_tokens][batch * 128] -- n_feat must be 128, sigma contiguous
  * [batch][128][128] (ld_sigma 128, sigma_batch_stride 16384); only the diagonal tiles are computed.  Several statistics need a
  * 256-CU device (the schedule is cut for 8 XCDs x 32 CUs); otherwise call mdg_cov_accum_i8 per statistic.

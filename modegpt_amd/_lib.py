@@ -27,18 +27,21 @@ class CovProblem(C.Structure):
                 ("ld_sigma", _i64), ("sigma_batch_stride", _i64)]
 
 
-ABI_VERSION = 6   # include/modegpt_hip.h MDG_ABI_VERSION this binding table was written against
+ABI_VERSION = 7   # include/modegpt_hip.h MDG_ABI_VERSION this binding table was written against
 
 # name -> (restype, argtypes); must list every symbol the header declares (tests/test_abi.py checks it)
 SIGNATURES = {
     "mdg_abi_version": (_i32, []),
     "mdg_last_error": (C.c_char_p, []),
     "mdg_device_info": (_i32, [_i32, C.c_char_p, _i32, C.POINTER(_i32), C.POINTER(_i64)]),
+    "mdg_shutdown": (_i32, []),
     "mdg_cov_accum_ws_bytes": (_sz, [_i64, _i64, _i64]),
     "mdg_cov_accum": (_i32, [_ptr, _i32, _i64, _i64, _i64, _i64, _i32, _ptr, _i64, _i64, _ptr, _sz, _ptr]),
     "mdg_cov_accum_i8_ws_bytes": (_sz, [_i64, _i64]),
     "mdg_cov_accum_i8": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _i64, _ptr, _sz, C.POINTER(_i32), _ptr, _ptr, _ptr, _ptr]),
     "mdg_cov_accum_i8_stats": (_i32, [_ptr, _i64, _i64, C.POINTER(C.c_ulonglong), _ptr]),
+    "mdg_cov_accum_i8_route": (_i32, [_i32, C.POINTER(CovProblem), _i32, _ptr, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32),
+                                       C.POINTER(_f64), _ptr]),
     "mdg_cov_accum_i8_multi_ws_bytes": (_sz, [_i32, C.POINTER(CovProblem)]),
     "mdg_cov_accum_i8_multi": (_i32, [_i32, C.POINTER(CovProblem), _ptr, _sz, C.POINTER(_i32), _ptr, _ptr, _ptr, _ptr]),
     "mdg_cov_accum_multi_ws_bytes": (_sz, [_i32, C.POINTER(CovProblem), _i32]),
@@ -109,6 +112,10 @@ def load() -> C.CDLL:
     if lib.mdg_abi_version() != ABI_VERSION:
         raise ModeGPTLibraryError("libmodegpt_hip.so ABI version mismatch")
     _lib = lib
+    # the library's cached device allocations are released while the HIP runtime is still alive (Python's atexit runs before
+    # the C++ static destructors); the library itself makes no HIP call at exit
+    import atexit
+    atexit.register(lib.mdg_shutdown)
     return lib
 
 

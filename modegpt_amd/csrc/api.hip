@@ -87,6 +87,11 @@ extern "C" int mdg_device_info(int device, char* name, int cap, int* n_cu, int64
   return MDG_OK;
 }
 
+extern "C" int mdg_shutdown(void) {
+  MDG_CLEAR();
+  return mdg::release_i8_schedules();
+}
+
 extern "C" int mdg_probe_mfma_f64(int iters, double* tflops, void* stream) {
   MDG_CLEAR();
   MDG_CHECK_ARG(iters > 0 && tflops, "mdg_probe_mfma_f64: bad arguments");

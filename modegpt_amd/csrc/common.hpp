@@ -30,6 +30,7 @@ void set_error(const char* fmt, ...);
 // mdg_cov_accum with a device-side gate (cov.hip): the launches are enqueued unconditionally, and every workgroup exits at once
 // unless (*gate & gate_mask) == gate_want when it runs (gate == nullptr: always runs).  mdg_cov_accum_i8 enqueues its fp64
 // fallback this way, so that the route is chosen on the device and the call never waits for the host.
+int release_i8_schedules();   // cov_i8.hip: frees the cached tile schedules (mdg_shutdown)
 int cov_accum_gated(const void* x, int dtype, int64_t n_tokens, int64_t n_feat, int64_t batch, int64_t ld, int relu, double* sigma,
                     int64_t ld_sigma, int64_t sigma_bs, void* ws, size_t ws_bytes, const int* gate, int gate_mask, int gate_want,
                     void* stream);

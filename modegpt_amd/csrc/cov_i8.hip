@@ -63,7 +63,13 @@ constexpr int PA = TI * KS;      // bytes of one plane of the I operand in a sta
 // sigma_mlp shape.)
 constexpr int FLUSH_STEPS = 2047;
 constexpr int TOP_SHIFT = 8 * NP - 10;  // 38: the column maximum's significand sits below bit 46 of the 48-bit integer
-constexpr int DEEP_BINADES = 10;  // an element is "deep" when its exponent is at least this far below the column maximum
+
+// Per-column integers the split pass accumulates for the route (i8_route_kernel; host model: tests/i8_model.py), as [NSTAT][n]
+// unsigned long long: q_s = sum over tokens of d_s^2 for the six planes, the signed sum of d_0 d_1 (so that the energy of the top
+// two digits together, hence a lower bound on the column's norm, is an integer too), and two counters packed into one word.
+constexpr int NSTAT = 8;
+constexpr int STAT_D0D1 = 6, STAT_COUNTS = 7;     // [7]: (elements rounded to an integer: more than 38 binades down) << 32 | nonzero elements
+constexpr int EMAX_COLUMN_OUT = 0x100;            // bit set in emax[j] by the route kernel: column j is computed by the fp64 column kernel
 
 // bf16 bits -> (signed 9-bit significand, effective exponent >= 1);  value = sig * 2^(ee - 134)
 __device__ __forceinline__ void bf16_parts(unsigned b, int& sig, int& ee) {
@@ -114,16 +120,16 @@ constexpr int ALWAYS_WRITTEN_PLANES = 4;
 // k-step.  A workgroup walks SPLIT_STEPS k-steps of its row group, 8 at a time.
 constexpr int SPLIT_STEPS = 64;
 __global__ __launch_bounds__(256) void i8_split_kernel(const bf16_t* x, int64_t ld, int64_t T, int n, int nk, const int* emax,
-                                                       signed char* planes, int* deep_cnt, int* nz_cnt, unsigned char* zmask) {
-  __shared__ int deep_lds[32], nz_lds[32];
+                                                       signed char* planes, unsigned long long* stats, unsigned char* zmask) {
+  __shared__ unsigned long long st_lds[NSTAT][32];
   const int r = threadIdx.x & 31;
   const int G = blockIdx.x;
   const int j = G * 32 + r;
   const int E = emax[j];
   const int64_t groups = n / 32;
-  if (threadIdx.x < 32) deep_lds[threadIdx.x] = nz_lds[threadIdx.x] = 0;
+  for (int i = threadIdx.x; i < NSTAT * 32; i += 256) (&st_lds[0][0])[i] = 0;
   __syncthreads();
-  int deep = 0, nz = 0;
+  long long q[NSTAT] = {};
   for (int kq = 0; kq < SPLIT_STEPS; kq += 8) {
     const int kt = blockIdx.y * SPLIT_STEPS + kq + (threadIdx.x >> 5);
     if (kt >= nk) break;
@@ -132,13 +138,12 @@ __global__ __launch_bounds__(256) void i8_split_kernel(const bf16_t* x, int64_t 
     for (int h = 0; h < 2; h++) {
       unsigned dig[NP][4] = {};  // 16 bytes per plane
 #pragma unroll
-      for (int q = 0; q < 16; q++) {
-        const int64_t t = (int64_t)kt * KS + h * 16 + q;
+      for (int qq = 0; qq < 16; qq++) {
+        const int64_t t = (int64_t)kt * KS + h * 16 + qq;
         int sig = 0, ee = 1;
         if (t < T) bf16_parts(x[t * ld + j], sig, ee);
         const int sh = E - ee;
-        deep += (sig != 0 && sh >= DEEP_BINADES);
-        nz += (sig != 0);
+        q[STAT_COUNTS] += (long long)(sig != 0) + ((long long)(sig != 0 && sh > TOP_SHIFT) << 32);
         long long N;
         if (sh <= TOP_SHIFT) {
           N = (long long)sig << (TOP_SHIFT - sh);
@@ -147,13 +152,18 @@ __global__ __launch_bounds__(256) void i8_split_kernel(const bf16_t* x, int64_t 
           const int mag = dn > 9 ? 0 : ((sig < 0 ? -sig : sig) + (1 << (dn - 1))) >> dn;
           N = sig < 0 ? -mag : mag;
         }
+        int d[NP];
 #pragma unroll
         for (int s = NP - 1; s >= 1; s--) {
-          const int b = (int)((N + 128) & 255) - 128;  // balanced digit in [-128, 127]
-          dig[s][q >> 2] |= (unsigned)(b & 255) << (8 * (q & 3));
-          N = (N - b) >> 8;
+          d[s] = (int)((N + 128) & 255) - 128;  // balanced digit in [-128, 127]
+          dig[s][qq >> 2] |= (unsigned)(d[s] & 255) << (8 * (qq & 3));
+          N = (N - d[s]) >> 8;
         }
-        dig[0][q >> 2] |= (unsigned)((int)N & 255) << (8 * (q & 3));
+        d[0] = (int)N;
+        dig[0][qq >> 2] |= (unsigned)(d[0] & 255) << (8 * (qq & 3));
+#pragma unroll
+        for (int s = 0; s < NP; s++) q[s] += d[s] * d[s];
+        q[STAT_D0D1] += d[0] * d[1];
       }
 #pragma unroll
       for (int s = 0; s < NP; s++) {
@@ -164,11 +174,12 @@ __global__ __launch_bounds__(256) void i8_split_kernel(const bf16_t* x, int64_t 
     }
     write_piece_mask(any, zmask, (int64_t)kt * groups + G);   // the 32 lanes of a half-wave hold the 32 rows of the piece
   }
-  if (deep) atomicAdd(&deep_lds[r], deep);
-  if (nz) atomicAdd(&nz_lds[r], nz);
+#pragma unroll
+  for (int i = 0; i < NSTAT; i++)
+    if (q[i]) atomicAdd(&st_lds[i][r], (unsigned long long)q[i]);
   __syncthreads();
-  if (threadIdx.x < 32 && deep_lds[threadIdx.x]) atomicAdd(deep_cnt + G * 32 + threadIdx.x, deep_lds[threadIdx.x]);
-  if (threadIdx.x < 32 && nz_lds[threadIdx.x]) atomicAdd(nz_cnt + G * 32 + threadIdx.x, nz_lds[threadIdx.x]);
+  for (int i = threadIdx.x; i < NSTAT * 32; i += 256)
+    if (st_lds[i >> 5][i & 31]) atomicAdd(stats + (int64_t)(i >> 5) * n + G * 32 + (i & 31), st_lds[i >> 5][i & 31]);
 }
 
 // ---- the same two passes for the usual case of 16-byte addressable rows (ld % 8 == 0, aligned base): 16-byte loads.
@@ -203,40 +214,52 @@ __global__ __launch_bounds__(256) void i8_colmax_vec_kernel(const bf16_t* x, int
   if (threadIdx.x < 128) atomicMax(emax + blockIdx.x * 128 + threadIdx.x, best_lds[threadIdx.x]);
 }
 
-// workgroup = 128 features (4 row groups) x 64 tokens (2 k-steps): the tile goes through LDS, one thread then owns one
-// feature of one k-step
+// workgroup = 128 features (4 row groups) x SPLIT_TILES tiles of 64 tokens (2 k-steps): a tile goes through LDS (the next one's
+// loads are in flight meanwhile), one thread then owns one feature of one k-step.  The column statistics of the route are kept
+// in registers over the tiles and leave the workgroup as 8 atomics per feature.
+constexpr int SPLIT_TILES = 8;
 __global__ __launch_bounds__(256) void i8_split_vec_kernel(const bf16_t* x, int64_t ld, int64_t T, int n, int nk, const int* emax,
-                                                           signed char* planes, int* deep_cnt, int* nz_cnt, unsigned char* zmask) {
+                                                           signed char* planes, unsigned long long* stats, unsigned char* zmask) {
   __shared__ __attribute__((aligned(16))) bf16_t tile[64 * 128];
-  __shared__ int deep_lds[128], nz_lds[128];
+  __shared__ int st_lds[NSTAT + 1][128];
   const int f0 = blockIdx.x * 128;
-  const int kt0 = blockIdx.y * 2;
-  const int64_t tok0 = (int64_t)kt0 * KS;
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const int c = threadIdx.x + 256 * q;  // 16-byte chunk: token c / 16, columns (c % 16) * 8 ..
-    const int64_t t = tok0 + (c >> 4);
-    i32x4 v = (i32x4)0;
-    if (t < T) v = *(const i32x4*)(x + t * ld + f0 + (c & 15) * 8);
-    *(i32x4*)(tile + c * 8) = v;
-  }
-  if (threadIdx.x < 128) deep_lds[threadIdx.x] = nz_lds[threadIdx.x] = 0;
-  __syncthreads();
   const int f = threadIdx.x & 127, ks = threadIdx.x >> 7;
-  const int kt = kt0 + ks;
   const int E = emax[f0 + f];
   const int64_t groups = n / 32;
   const int G = (f0 + f) >> 5, r = f & 31;
-  int deep = 0, nz = 0;
-  if (kt < nk) {   // (uniform per wave: a wave holds 64 features of ONE k-step)
+  for (int i = threadIdx.x; i < (NSTAT + 1) * 128; i += 256) (&st_lds[0][0])[i] = 0;
+  int q[NSTAT + 1] = {};   // q_0 .. q_5, sum d_0 d_1, nonzero elements, rounded elements: < 2^23 each over 8 tiles
+  auto load_tile = [&](int tile_index, i32x4 (&v)[4]) {
+    const int64_t tok0 = (int64_t)tile_index * 2 * KS;
+#pragma unroll
+    for (int c4 = 0; c4 < 4; c4++) {
+      const int c = threadIdx.x + 256 * c4;  // 16-byte chunk: token c / 16, columns (c % 16) * 8 ..
+      const int64_t t = tok0 + (c >> 4);
+      v[c4] = (i32x4)0;
+      if (t < T) v[c4] = *(const i32x4*)(x + t * ld + f0 + (c & 15) * 8);
+    }
+  };
+  const int tile0 = blockIdx.y * SPLIT_TILES, tiles = (nk + 1) / 2;
+  for (int it = 0; it < SPLIT_TILES && tile0 + it < tiles; it++) {
+    __syncthreads();              // (the previous tile has been read by every thread)
+    {
+      i32x4 v[4];
+      load_tile(tile0 + it, v);
+#pragma unroll
+      for (int c4 = 0; c4 < 4; c4++) *(i32x4*)(tile + (threadIdx.x + 256 * c4) * 8) = v[c4];
+    }
+    __syncthreads();
+    const int kt = (tile0 + it) * 2 + ks;
+    if (kt >= nk) continue;   // (uniform per wave: a wave holds 64 features of ONE k-step)
     unsigned any[NP] = {};
-    unsigned dig[2][NP][4];
+    unsigned deep_dig[2][NP - ALWAYS_WRITTEN_PLANES][4];   // planes 4, 5 wait for the piece mask; planes 0 - 3 are stored as they are made
     // Balanced base-256 digits without a carry loop: N + 128 (256^0 + ... + 256^4) has the bytes d_i + 128 in its lower five
     // positions -- the addition's own carries are the digit carries -- and the top digit above them; d_i = byte ^ 0x80.  Four
     // elements at a time, byte k of each gathered into one dword by v_perm_b32: ~27 VALU operations per element where the
     // digit-by-digit loop in 64-bit arithmetic took ~60 (the pass was VALU-bound: 1.1 ms at the sigma_mlp shape for 2.8 GB).
 #pragma unroll
     for (int h = 0; h < 2; h++) {
+      unsigned dig[NP][4];
 #pragma unroll
       for (int q4 = 0; q4 < 4; q4++) {
         unsigned lo[4], hi[4];
@@ -245,8 +268,7 @@ __global__ __launch_bounds__(256) void i8_split_vec_kernel(const bf16_t* x, int6
           int sig, ee;
           bf16_parts(tile[(ks * 32 + h * 16 + q4 * 4 + e) * 128 + f], sig, ee);
           const int sh = E - ee;
-          deep += (sig != 0 && sh >= DEEP_BINADES);
-          nz += (sig != 0);
+          q[NSTAT - 1] += (sig != 0);
           long long N;
           if (sh <= TOP_SHIFT) {
             N = (long long)sig << (TOP_SHIFT - sh);
@@ -254,6 +276,7 @@ __global__ __launch_bounds__(256) void i8_split_vec_kernel(const bf16_t* x, int6
             const int dn = sh - TOP_SHIFT;
             const int mag = dn > 9 ? 0 : ((sig < 0 ? -sig : sig) + (1 << (dn - 1))) >> dn;
             N = sig < 0 ? -mag : mag;
+            q[NSTAT] += (sig != 0);      // rounded to an integer: the remainder term rho of the bound
           }
           const unsigned long long biased = (unsigned long long)N + 0x0000008080808080ull;
           lo[e] = (unsigned)biased;
@@ -268,42 +291,279 @@ __global__ __launch_bounds__(256) void i8_split_vec_kernel(const bf16_t* x, int6
           const unsigned t23 = __builtin_amdgcn_perm(byte < 4 ? lo[3] : hi[3], byte < 4 ? lo[2] : hi[2], sel);
           unsigned w = t01 | (t23 << 16);
           if (s2 > 0) w ^= 0x80808080u;
-          dig[h][s2][q4] = w;
+          dig[s2][q4] = w;
+          q[s2] = __builtin_amdgcn_sdot4((int)w, (int)w, q[s2], false);   // sum of the four digits' squares (v_dot4c_i32_i8)
         }
+        q[STAT_D0D1] = __builtin_amdgcn_sdot4((int)dig[0][q4], (int)dig[1][q4], q[STAT_D0D1], false);
       }
 #pragma unroll
-      for (int s2 = 0; s2 < NP; s2++) any[s2] |= dig[h][s2][0] | dig[h][s2][1] | dig[h][s2][2] | dig[h][s2][3];
+      for (int s2 = 0; s2 < NP; s2++) {
+        any[s2] |= dig[s2][0] | dig[s2][1] | dig[s2][2] | dig[s2][3];
+        if (s2 < ALWAYS_WRITTEN_PLANES) {
+          signed char* piece = planes + ((s2 * groups + G) * (int64_t)nk + kt) * 1024;
+          *(i32x4*)(piece + h * 512 + r * 16) = (i32x4){(int)dig[s2][0], (int)dig[s2][1], (int)dig[s2][2], (int)dig[s2][3]};
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; i++) deep_dig[h][s2 - ALWAYS_WRITTEN_PLANES][i] = dig[s2][i];
+        }
+      }
     }
     const unsigned present = write_piece_mask(any, zmask, (int64_t)kt * groups + G);
 #pragma unroll
-    for (int s2 = 0; s2 < NP; s2++)
-      if (s2 < ALWAYS_WRITTEN_PLANES || (present >> s2) != 0) {   // some plane >= s2 holds a nonzero here: the product kernels load
-                                                                  // every plane below a group's depth (uniform per half-wave = per piece)
+    for (int s2 = ALWAYS_WRITTEN_PLANES; s2 < NP; s2++)
+      if ((present >> s2) != 0) {   // some plane >= s2 holds a nonzero here: the product kernels load every plane below a
+                                    // group's depth (uniform per half-wave = per piece)
         signed char* piece = planes + ((s2 * groups + G) * (int64_t)nk + kt) * 1024;
 #pragma unroll
         for (int h = 0; h < 2; h++)
-          *(i32x4*)(piece + h * 512 + r * 16) = (i32x4){(int)dig[h][s2][0], (int)dig[h][s2][1], (int)dig[h][s2][2], (int)dig[h][s2][3]};
+          *(i32x4*)(piece + h * 512 + r * 16) = (i32x4){(int)deep_dig[h][s2 - ALWAYS_WRITTEN_PLANES][0], (int)deep_dig[h][s2 - ALWAYS_WRITTEN_PLANES][1],
+                                                        (int)deep_dig[h][s2 - ALWAYS_WRITTEN_PLANES][2], (int)deep_dig[h][s2 - ALWAYS_WRITTEN_PLANES][3]};
       }
   }
-  if (deep) atomicAdd(&deep_lds[f], deep);
-  if (nz) atomicAdd(&nz_lds[f], nz);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i <= NSTAT; i++)
+    if (q[i]) atomicAdd(&st_lds[i][f], q[i]);
   __syncthreads();
   if (threadIdx.x < 128) {
-    if (deep_lds[threadIdx.x]) atomicAdd(deep_cnt + f0 + threadIdx.x, deep_lds[threadIdx.x]);
-    if (nz_lds[threadIdx.x]) atomicAdd(nz_cnt + f0 + threadIdx.x, nz_lds[threadIdx.x]);
+    unsigned long long* o = stats + f0 + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < STAT_COUNTS; i++) {   // (the sum of d_0 d_1 is signed: sign-extended, the 64-bit sum wraps correctly)
+      const int val = st_lds[i][threadIdx.x];
+      if (val) atomicAdd(o + (int64_t)i * n, (unsigned long long)(long long)val);
+    }
+    const unsigned long long counts = (unsigned long long)(unsigned)st_lds[NSTAT - 1][threadIdx.x] |
+                                      ((unsigned long long)(unsigned)st_lds[NSTAT][threadIdx.x] << 32);
+    if (counts) atomicAdd(o + (int64_t)STAT_COUNTS * n, counts);
   }
 }
 
-// flag bit 0: in some column more than 1 / 64 of the nonzero elements are deep (five planes are not enough); bit 1: more
-// than 1 / 4 (six are not either), or the column holds an Inf / NaN, which only the fp64 kernel propagates the way the
-// reference does.  The share is taken over the NONZERO elements: zeros add nothing to sigma, so a sparse column's accuracy is
-// set by the few elements it has.
-__global__ __launch_bounds__(256) void i8_depth_kernel(const int* deep_cnt, const int* nz_cnt, const int* emax, int n, int* flag) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
-  const int64_t c = deep_cnt[j], nz = nz_cnt[j];
-  const int bits = (c * 64 > nz ? 1 : 0) | ((c * 4 > nz || emax[j] == 255) ? 2 : 0);
-  if (bits) atomicOr(flag, bits);
+// ---- the route of a statistic (host model with the derivation: tests/i8_model.py).
+// With alpha_s(j) = 256^(5 - s) ||d_s(., j)|| / ||N_j|| (plane energies over the column norm) and rho_j = sqrt(rounded_j) / (2 ||N_j||),
+// Cauchy-Schwarz over the tokens bounds the error of the P-plane product entry-wise, for ANY input:
+//     |sigma_ij(P) - sigma_ij| / sqrt(sigma_ii sigma_jj)  <=  sum_{s + t >= P} alpha_s(i) alpha_t(j) + rho_i + rho_j + rho_i rho_j  <=  SQ_P + X_P
+//     SQ_P = sum_{2 s >= P} A_s^2 + 2 R + R^2   (attained on the diagonal)        X_P = sum_{s != t, s + t >= P} A_s A_t   (cross terms)
+// with A_s, R the maxima over the columns that stay on the int8 path.  The route is the smallest P in {5, 6} for which
+// SQ_P <= TAU_SQ and X_P <= tau_x(tokens) hold after at most ROUTE_JMAX columns have been handed to the fp64 column kernel -- greedily,
+// each time the column whose removal lowers the violation most (a column dominated by a few massive activations carries a bulk
+// that lives entirely in the deep planes: it alone sets A_2 .. A_4) -- else the whole statistic goes through mdg_cov_accum.  Columns
+// holding an Inf / NaN always leave (only the fp64 arithmetic propagates those the way the reference does).
+// ||N_j|| enters through the integer lower bound 2^32 (||256 d_0 + d_1|| - sqrt(nonzeros) / 2): every decision is a function of
+// integer sums, hence run-to-run bit-identical.  One workgroup per statistic; ~20 us when nothing has to leave.
+// TAU_SQ bounds the attained part.  The cross part is attained only by columns whose digit sequences are proportional over the
+// tokens; for uncorrelated columns the sums behind it grow like sqrt(tokens) where Cauchy-Schwarz allows tokens, so the measured
+// error sits ~4.5 / sqrt(tokens) below X_P (0.02 - 0.035 at 32768 tokens on every family of scripts/probes/i8_error_bound.py).
+// Short calls have no such averaging (33 tokens: measured / X_P ~ 0.3), hence the threshold on X_P grows with the token count:
+// guaranteed <= TAU_SQ + tau_x(tokens) <= 1.1e-11 for any input, and <= 1e-12 measured also on the uncorrelated data of a short call.
+constexpr double TAU_SQ = 1e-12, TAU_X_MIN = 1e-12, TAU_X_MAX = 1e-11, TAU_X_TOKENS = 1024.0;
+__host__ __device__ inline double tau_x_of(int64_t tokens) {
+  return fmin(TAU_X_MAX, fmax(TAU_X_MIN, TAU_X_MIN * ((double)tokens / TAU_X_TOKENS)));
+}
+constexpr int ROUTE_JMAX = MDG_I8_MAX_COLUMNS;   // columns per statistic and call the fp64 column kernel takes (32)
+constexpr int NVAL = 7;                     // alpha_0 .. alpha_5, rho
+constexpr int ROUTE_THREADS = 1024;
+constexpr int HIST_BINS = 160, HIST_KEY0 = 2 * (1023 - 70);   // half-binade bins from 2^-70 up (values below: bin 0, floor 0)
+
+struct RouteOut {                           // per statistic, in the workspace (mdg_cov_accum_i8_route reads it back)
+  int planes;                               // 5, 6, or 0: the whole statistic goes through the fp64 kernel
+  int n_out;                                // columns handed to the fp64 column kernel
+  int out[ROUTE_JMAX];                      // ... in the order they were taken
+  double sq, x;                             // SQ_P, X_P of the columns that stay (the guaranteed bound is their sum)
+};
+
+__device__ __forceinline__ void route_terms(const double (&A)[NVAL], int P, double& sq, double& x) {
+  sq = 2.0 * A[6] + A[6] * A[6];
+  x = 0.0;
+#pragma unroll
+  for (int s = 0; s < NP; s++)
+#pragma unroll
+    for (int t = 0; t < NP; t++)
+      if (s + t >= P) {
+        if (s == t) sq += A[s] * A[t];
+        else x += A[s] * A[t];
+      }
+}
+__device__ __forceinline__ double route_violation(const double (&A)[NVAL], int P, double tau_x) {
+  double sq, x;
+  route_terms(A, P, sq, x);
+  return fmax(sq / TAU_SQ, x / tau_x);
+}
+
+struct Top2 { double m1; int a1; double m2; };
+__device__ __forceinline__ void top2_merge(Top2& a, const Top2& b) {   // (lowest index wins among equals: the model's argmax)
+  if (b.m1 > a.m1 || (b.m1 == a.m1 && b.a1 < a.a1)) {
+    a.m2 = fmax(a.m1, b.m2);
+    a.m1 = b.m1;
+    a.a1 = b.a1;
+  } else {
+    a.m2 = fmax(a.m2, b.m1);
+  }
+}
+
+__global__ __launch_bounds__(ROUTE_THREADS) void i8_route_kernel(const unsigned long long* stats, int* emax, int n, double tau_x, double* vals,
+                                                                 int* flag, RouteOut* out, int* route_counts) {
+  __shared__ int hist[NVAL][HIST_BINS];
+  __shared__ Top2 wave_top[ROUTE_THREADS / 64][NVAL];
+  __shared__ Top2 top[NVAL];
+  __shared__ int decision;   // -1: keep going; 0: this P is done (accepted or given up)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < NVAL * HIST_BINS; i += ROUTE_THREADS) (&hist[0][0])[i] = 0;
+  __syncthreads();
+  // alpha_s(j), rho_j from the integers; columns with an Inf / NaN (emax 255) leave at once
+  int forced = 0;
+  for (int j = tid; j < n; j += ROUTE_THREADS) {
+    double q[NSTAT];
+#pragma unroll
+    for (int i = 0; i < NSTAT - 1; i++) q[i] = i == STAT_D0D1 ? (double)(long long)stats[(int64_t)i * n + j] : (double)stats[(int64_t)i * n + j];
+    const unsigned long long counts = stats[(int64_t)STAT_COUNTS * n + j];
+    const double nnz = (double)(unsigned)counts, rounded = (double)(unsigned)(counts >> 32);
+    const double hi2 = 65536.0 * q[0] + 512.0 * q[STAT_D0D1] + q[1];
+    const double norm = (sqrt(fmax(hi2, 0.0)) - 0.5 * sqrt(nnz)) * 4294967296.0;
+    // (norm <= 0 can only happen for a column of denormals, which has nothing below plane 1; 1e300 keeps the test conservative)
+    const double inv = nnz > 0 ? (norm > 0 ? 1.0 / norm : 1e300) : 0.0;
+    double a[NVAL];
+#pragma unroll
+    for (int s = 0; s < NP; s++) a[s] = q[s] > 0 ? sqrt(q[s]) * ldexp(1.0, 8 * (NP - 1 - s)) * inv : 0.0;
+    a[6] = rounded > 0 ? 0.5 * sqrt(rounded) * inv : 0.0;
+    const bool nonfinite = (emax[j] & 255) == 255;
+#pragma unroll
+    for (int i = 0; i < NVAL; i++) {
+      vals[(int64_t)i * n + j] = a[i];
+      if (!nonfinite) {
+        const int key = (int)(__double_as_longlong(a[i]) >> 51) - HIST_KEY0;   // 2 x exponent + top mantissa bit
+        atomicAdd(&hist[i][min(max(key, 0), HIST_BINS - 1)], 1);
+      }
+    }
+    if (nonfinite) {
+      emax[j] |= EMAX_COLUMN_OUT;
+      forced++;
+    }
+  }
+  // forced columns, in index order (deterministic): count them, then list them
+  __shared__ int forced_total;
+  if (tid == 0) forced_total = 0;
+  __syncthreads();
+  if (forced) atomicAdd(&forced_total, forced);
+  __syncthreads();
+  int n_out = 0;
+  if (forced_total > ROUTE_JMAX) {      // too many: the whole statistic goes through the fp64 kernel
+    if (tid == 0) {
+      out->planes = 0; out->n_out = 0; out->sq = out->x = 0.0;
+      atomicOr(flag, 2);
+    }
+    for (int j = tid; j < n; j += ROUTE_THREADS) emax[j] &= 255;
+    return;
+  }
+  if (forced_total) {
+    if (tid == 0)
+      for (int j = 0; j < n; j++)
+        if (emax[j] & EMAX_COLUMN_OUT) out->out[n_out++] = j;
+    n_out = forced_total;
+    __syncthreads();
+  }
+  const int n_forced = n_out;
+  for (int P = 5; P <= 6; P++) {
+    // prefilter: whatever ROUTE_JMAX columns leave, the (ROUTE_JMAX + 1)-th largest value of every quantity stays; its
+    // histogram bin's lower edge is a lower bound on it
+    {
+      __shared__ double floor_of[NVAL];
+      if (tid < NVAL) {
+        int seen = 0, b = HIST_BINS - 1;
+        for (; b > 0; b--) {
+          seen += hist[tid][b];
+          if (seen > ROUTE_JMAX - n_forced) break;
+        }
+        floor_of[tid] = b > 0 ? __longlong_as_double((long long)(b + HIST_KEY0) << 51) : 0.0;
+      }
+      __syncthreads();
+      double fl[NVAL];
+#pragma unroll
+      for (int i = 0; i < NVAL; i++) fl[i] = floor_of[i];
+      __syncthreads();
+      if (n > ROUTE_JMAX && route_violation(fl, P, tau_x) > 1.0) continue;   // (uniform: every thread computes the same)
+    }
+    n_out = n_forced;
+    for (;;) {
+      // top two of every quantity over the columns still on the int8 path
+      Top2 t[NVAL];
+#pragma unroll
+      for (int i = 0; i < NVAL; i++) t[i] = Top2{-1.0, 0x7fffffff, -1.0};
+      for (int j = tid; j < n; j += ROUTE_THREADS) {
+        if (emax[j] & EMAX_COLUMN_OUT) continue;
+#pragma unroll
+        for (int i = 0; i < NVAL; i++) top2_merge(t[i], Top2{vals[(int64_t)i * n + j], j, -1.0});
+      }
+#pragma unroll
+      for (int i = 0; i < NVAL; i++) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+          Top2 o;
+          o.m1 = __shfl_xor(t[i].m1, off);
+          o.a1 = __shfl_xor(t[i].a1, off);
+          o.m2 = __shfl_xor(t[i].m2, off);
+          top2_merge(t[i], o);
+        }
+        if (lane == 0) wave_top[wave][i] = t[i];
+      }
+      __syncthreads();
+      if (tid < NVAL) {
+        Top2 r = wave_top[0][tid];
+        for (int w = 1; w < ROUTE_THREADS / 64; w++) top2_merge(r, wave_top[w][tid]);
+        r.m1 = fmax(r.m1, 0.0);
+        r.m2 = fmax(r.m2, 0.0);
+        top[tid] = r;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        double A[NVAL];
+#pragma unroll
+        for (int i = 0; i < NVAL; i++) A[i] = top[i].m1;
+        decision = -1;
+        if (route_violation(A, P, tau_x) <= 1.0) {
+          out->planes = P;
+          out->n_out = n_out;
+          route_terms(A, P, out->sq, out->x);
+          if (P == 6) atomicOr(flag, 1);
+          if (route_counts && n_out) atomicAdd(route_counts + 3, n_out);
+          decision = 0;
+        } else if (n_out == ROUTE_JMAX) {
+          decision = 1;
+        } else {
+          int best = -1;
+          double best_v = 1e308;
+          for (int qi = 0; qi < NVAL; qi++) {      // candidates: the columns that hold a maximum, in quantity order
+            const int c = top[qi].a1;
+            if (c == 0x7fffffff) continue;
+            double A2[NVAL];
+#pragma unroll
+            for (int i = 0; i < NVAL; i++) A2[i] = top[i].a1 == c ? top[i].m2 : top[i].m1;
+            const double v = route_violation(A2, P, tau_x);
+            if (v < best_v) { best_v = v; best = c; }
+          }
+          if (best < 0) decision = 1;              // (no column left)
+          else {
+            emax[best] |= EMAX_COLUMN_OUT;
+            out->out[n_out] = best;
+          }
+        }
+      }
+      __syncthreads();
+      const int dec = decision;
+      __syncthreads();
+      if (dec == 0) return;
+      if (dec == 1) break;
+      n_out++;
+    }
+    // this P cannot be reached: take the greedy picks back (the forced columns stay out)
+    for (int j = tid; j < n; j += ROUTE_THREADS)
+      if ((emax[j] & EMAX_COLUMN_OUT) && (emax[j] & 255) != 255) emax[j] &= 255;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    out->planes = 0; out->n_out = 0; out->sq = out->x = 0.0;
+    atomicOr(flag, 2);
+  }
+  for (int j = tid; j < n; j += ROUTE_THREADS) emax[j] &= 255;
 }
 
 template <int V> struct ic { static constexpr int value = V; };
@@ -497,7 +757,8 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
     // accumulators fill the register file there), and reloaded here behind one s_waitcnt vmcnt(0) each -- which turns the 16
     // sigma loads of a block into 16 serialised memory round trips (26 us per flush and tile, 2 x 0.65 ms per launch)
     asm volatile("" : "+v"(row0));
-    const double sc_j = ldexp(1.0, pr.emax[col] - 172);
+    const int e_col = pr.emax[col];      // bits 0-7: the column's maximum exponent; EMAX_COLUMN_OUT: the fp64 column kernel computes this column
+    const double sc_j = ldexp(1.0, (e_col & 255) - 172);
     // all read-modify-writes of a lane: loads first (independent, in flight together), then the arithmetic and the stores;
     // written as `*p += v` one by one the compiler must keep them in order and every element pays a full memory round trip
 #pragma unroll
@@ -518,7 +779,9 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
         double v = 0.;
 #pragma unroll
         for (int k = P - 1; k >= 0; k--) v += ldexp((double)acc[k][b][reg], 80 - 8 * k);
-        if (col <= row0 + b * 32 + off) p[(int64_t)off * fold_ld] = old[reg] + v * sc_j * ldexp(1.0, er[reg] - 172);
+        // rows and columns the route handed to the fp64 column kernel are not ours: their digit products are computed and dropped
+        if (col <= row0 + b * 32 + off && !((e_col | er[reg]) & EMAX_COLUMN_OUT))
+          p[(int64_t)off * fold_ld] = old[reg] + v * sc_j * ldexp(1.0, (er[reg] & 255) - 172);
       }
     }
 #pragma unroll
@@ -863,6 +1126,112 @@ __global__ __launch_bounds__(256) void i8_tail_combine_kernel(SyrkArgs a, int n_
   }
 }
 
+// ---- the fp64 column kernel: the rows / columns of sigma that belong to the columns the route took off the int8 path
+// (RouteOut::out, at most ROUTE_JMAX per statistic): v_k[c] = sum over tokens of x[t, out[k]] x[t, c] in plain fp64 -- the
+// reference's arithmetic (LlamaAdapter.py:127-147) -- for every column c.  One pass over X serves COLK_GROUP such columns: a lane
+// owns 8 consecutive columns c (one 16-byte load per token) x the group's columns (64 accumulators), a one-wave workgroup 512
+// columns x one of COLK_CHUNKS token chunks; 8 tokens' loads are in flight together, and the group's own values for the next 64
+// tokens are fetched while the current 64 are multiplied.  The chunk partials are reduced in chunk order by
+// i8_columns_reduce_kernel (run-to-run bit-identical), which adds v_k[c] to sigma[max(c, j)][min(c, j)].  Both launches are
+// enqueued with every call and exit at once when the route left every column on the int8 path.  2 x tokens x n flop per column:
+// 0.94 GFLOP at the sigma_mlp shape; one pass reads X once (0.94 GB).
+constexpr int COLK_GROUP = 8, COLK_CHUNKS = 64, COLK_WG_COLS = 512, COLK_STAGE = 64, COLK_BATCH = 8;
+struct ColArgs {
+  const bf16_t* x;
+  int64_t ld, T;
+  int n, vec;                 // vec: rows are 16-byte addressable
+  const RouteOut* route;
+  const int* flag;            // the statistic's route bits (bit 1: the whole statistic went to the fp64 kernel)
+  double* part;               // [ROUTE_JMAX][COLK_CHUNKS][n]
+};
+__device__ __forceinline__ double bf16_bits_to_f64(unsigned b) { return (double)__uint_as_float(b << 16); }
+
+__global__ __launch_bounds__(64) void i8_columns_kernel(ColArgs a) {
+  const int pass = blockIdx.z;
+  const int n_out = a.route->n_out;
+  if ((*a.flag & 2) || pass * COLK_GROUP >= n_out) return;
+  const int nj = min(COLK_GROUP, n_out - pass * COLK_GROUP);
+  __shared__ __attribute__((aligned(16))) double xj[COLK_STAGE][COLK_GROUP];
+  const int lane = threadIdx.x;
+  const int my_k = lane % COLK_GROUP;                       // staging: lane l fetches column l % 8 of the group for tokens l / 8 + 8 i
+  const int my_col = my_k < nj ? a.route->out[pass * COLK_GROUP + my_k] : -1;
+  const int c0 = blockIdx.x * COLK_WG_COLS + lane * 8;
+  const bool active = c0 < a.n;
+  const int64_t chunk_len = (a.T + COLK_CHUNKS - 1) / COLK_CHUNKS;
+  const int64_t t0 = blockIdx.y * chunk_len, t1 = min(a.T, t0 + chunk_len);
+  const unsigned short* xs = (const unsigned short*)a.x;
+  auto fetch_group = [&](int64_t t, unsigned short (&g)[COLK_STAGE / 8]) {
+#pragma unroll
+    for (int i = 0; i < COLK_STAGE / 8; i++) {
+      const int64_t tok = t + lane / COLK_GROUP + 8 * i;
+      g[i] = (my_col >= 0 && tok < t1) ? xs[tok * a.ld + my_col] : (unsigned short)0;
+    }
+  };
+  double acc[COLK_GROUP][8] = {};
+  unsigned short g[COLK_STAGE / 8];
+  if (t0 < t1) fetch_group(t0, g);
+  for (int64_t t = t0; t < t1; t += COLK_STAGE) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < COLK_STAGE / 8; i++) xj[lane / COLK_GROUP + 8 * i][my_k] = bf16_bits_to_f64(g[i]);
+    __syncthreads();
+    if (t + COLK_STAGE < t1) fetch_group(t + COLK_STAGE, g);
+    if (!active) continue;
+    const int steps = (int)min((int64_t)COLK_STAGE, t1 - t);
+    for (int tb = 0; tb < steps; tb += COLK_BATCH) {
+      unsigned w[COLK_BATCH][4];
+#pragma unroll
+      for (int i = 0; i < COLK_BATCH; i++) {
+        const int64_t tok = min(t + tb + i, t1 - 1);          // (clamped: the group's staged values beyond the chunk are zero)
+        if (a.vec) {
+          const i32x4 v = *(const i32x4*)(xs + tok * a.ld + c0);
+          w[i][0] = v[0]; w[i][1] = v[1]; w[i][2] = v[2]; w[i][3] = v[3];
+        } else {
+#pragma unroll
+          for (int h = 0; h < 4; h++) w[i][h] = xs[tok * a.ld + c0 + 2 * h] | ((unsigned)xs[tok * a.ld + c0 + 2 * h + 1] << 16);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < COLK_BATCH; i++) {
+        double xc[8];
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+          xc[2 * h] = bf16_bits_to_f64(w[i][h] & 0xFFFFu);
+          xc[2 * h + 1] = bf16_bits_to_f64(w[i][h] >> 16);
+        }
+#pragma unroll
+        for (int k = 0; k < COLK_GROUP; k++) {
+          const double xk = xj[tb + i][k];
+#pragma unroll
+          for (int c = 0; c < 8; c++) acc[k][c] += xk * xc[c];
+        }
+      }
+    }
+  }
+  if (!active) return;
+#pragma unroll
+  for (int k = 0; k < COLK_GROUP; k++)
+    if (k < nj) {
+      double* o = a.part + ((int64_t)(pass * COLK_GROUP + k) * COLK_CHUNKS + blockIdx.y) * a.n + c0;
+#pragma unroll
+      for (int c = 0; c < 8; c++) o[c] = acc[k][c];
+    }
+}
+
+__global__ __launch_bounds__(256) void i8_columns_reduce_kernel(ColArgs a, const int* emax, double* sigma, int64_t ld_sigma, int block) {
+  const int k = blockIdx.y;
+  if ((*a.flag & 2) || k >= a.route->n_out) return;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= a.n) return;
+  const int j = a.route->out[k];
+  if (block && c / block != j / block) return;                 // per-head statistics: only the head's own 128 x 128 block exists
+  if ((emax[c] & EMAX_COLUMN_OUT) && c < j) return;            // a pair of two such columns belongs to the pass of the smaller index
+  double v = 0.0;
+  for (int q = 0; q < COLK_CHUNKS; q++) v += a.part[((int64_t)k * COLK_CHUNKS + q) * a.n + c];   // chunk order: reproducible
+  const int row = max(c, j), col = min(c, j);
+  sigma[(int64_t)row * ld_sigma + col - (block ? row / block * block : 0)] += v;
+}
+
 size_t planes_bytes(int64_t T, int64_t n) { return (size_t)NP * (size_t)n * (size_t)ceil_div(T, KS) * KS; }
 size_t zmask_bytes(int64_t T, int64_t n) { return align_up((size_t)ceil_div(T, KS) * (size_t)(n / 32), 256); }
 
@@ -883,12 +1252,17 @@ constexpr int TAIL_MAX_PIECES = 1024;  // partial tiles (chunks of all split til
 constexpr size_t PARTIAL_BYTES = (size_t)TAIL_MAX_PIECES * TI * 128 * sizeof(double);   // partial tiles of at most 128 x 128
 
 // shapes: per statistic {row blocks of 128 features, block (0 = full lower triangle, 128 = per-head diagonal tiles)}
+// The one thing the library keeps across calls: device copies of the schedules, a few KB each, keyed by (device, tile shape,
+// statistic shapes).  Plain device memory -- no streams, no events (those are the caller's) -- released by mdg_shutdown(); the
+// containers' destructors at process exit free host memory only and make no HIP call (the runtime may be gone by then).
+std::mutex g_sched_mutex;
+std::map<std::vector<int>, Schedule> g_sched_cache;
+
 const Schedule* schedule_for(const std::vector<std::pair<int, int>>& shapes, int cw) {   // cw: tile columns per 128 features (1: 128 x 128 tiles, 2: 128 x 64)
-  static std::mutex mu;
-  static std::map<std::vector<int>, Schedule> cache;
+  auto& cache = g_sched_cache;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
+  std::lock_guard<std::mutex> lock(g_sched_mutex);
   std::vector<int> key = {dev, cw};
   for (auto& sh : shapes) {
     key.push_back(sh.first);
@@ -990,10 +1364,11 @@ const Schedule* schedule_for(const std::vector<std::pair<int, int>>& shapes, int
 }
 
 // Workspace layout of a call: [shared block: route flag, executed-MFMA counter, XCD arrival counters][partial tiles]
-// then per statistic [digit planes][column maxima, deep / nonzero counters][piece masks], then the fp64 fallback's split-K space.
+// then per statistic [digit planes][column maxima, route statistics][alpha / rho][RouteOut][column-kernel partials][piece masks],
+// then the fp64 fallback's split-K space.
 constexpr size_t SHARED_BYTES = 256;
 struct ProblemWs {
-  size_t planes, ints, zmask;   // byte offsets
+  size_t planes, ints, vals, route, colpart, zmask;   // byte offsets
 };
 size_t layout(int count, const mdg_cov_problem* pr, ProblemWs* out, size_t* fallback_off) {
   size_t off = SHARED_BYTES + PARTIAL_BYTES, fb = 0;
@@ -1002,8 +1377,14 @@ size_t layout(int count, const mdg_cov_problem* pr, ProblemWs* out, size_t* fall
     ProblemWs w;
     w.planes = off;
     off += align_up(planes_bytes(pr[i].n_tokens, cols), 256);
-    w.ints = off;
-    off += align_up((size_t)(3 * cols) * sizeof(int), 256);
+    w.ints = off;                                   // column maxima (n ints, padded to 8 bytes), then the [NSTAT][n] route statistics
+    off += align_up((size_t)((cols + 1) / 2 * 2) * sizeof(int) + (size_t)(NSTAT * cols) * sizeof(unsigned long long), 256);
+    w.vals = off;                                   // alpha_s / rho per column
+    off += align_up((size_t)(NVAL * cols) * sizeof(double), 256);
+    w.route = off;
+    off += align_up(sizeof(RouteOut), 256);
+    w.colpart = off;                                // chunk partials of the fp64 column kernel
+    off += align_up((size_t)ROUTE_JMAX * COLK_CHUNKS * (size_t)cols * sizeof(double), 256);
     w.zmask = off;
     off += zmask_bytes(pr[i].n_tokens, cols);
     if (out) out[i] = w;
@@ -1016,7 +1397,7 @@ size_t layout(int count, const mdg_cov_problem* pr, ProblemWs* out, size_t* fall
 bool problems_ok(int count, const mdg_cov_problem* pr) {
   if (count < 1 || count > MAX_PROBLEMS || !pr) return false;
   for (int i = 0; i < count; i++) {
-    if (pr[i].n_tokens != pr[0].n_tokens || pr[i].n_tokens < 0 || pr[i].n_feat <= 0 || pr[i].batch < 1) return false;
+    if (pr[i].n_tokens != pr[0].n_tokens || pr[i].n_tokens < 0 || pr[i].n_tokens >= (1ll << 28) || pr[i].n_feat <= 0 || pr[i].batch < 1) return false;
     if (pr[i].batch == 1 ? pr[i].n_feat % TI != 0 : pr[i].n_feat != TI) return false;   // per-head statistics: head_dim 128 only
     if (pr[i].n_feat * pr[i].batch >= (1 << 21)) return false;
     if (pr[i].ld < pr[i].n_feat * pr[i].batch || pr[i].ld_sigma < pr[i].n_feat) return false;
@@ -1026,6 +1407,23 @@ bool problems_ok(int count, const mdg_cov_problem* pr) {
 }
 
 }  // namespace
+
+// mdg_shutdown(): give the cached schedules back.  The caller guarantees no int8 covariance call is in flight.
+int release_i8_schedules() {
+  std::lock_guard<std::mutex> lock(g_sched_mutex);
+  int dev0 = 0;
+  const bool have_dev = hipGetDevice(&dev0) == hipSuccess;
+  int rc = MDG_OK;
+  for (auto& kv : g_sched_cache) {
+    if (hipSetDevice(kv.first[0]) != hipSuccess) { rc = MDG_ERR_HIP; continue; }
+    if (kv.second.dev && hipFree(kv.second.dev) != hipSuccess) rc = MDG_ERR_HIP;
+    if (kv.second.tail && hipFree(kv.second.tail) != hipSuccess) rc = MDG_ERR_HIP;
+  }
+  g_sched_cache.clear();
+  if (have_dev) (void)hipSetDevice(dev0);
+  (void)hipGetLastError();
+  return rc;
+}
 }  // namespace mdg
 
 using namespace mdg;
@@ -1067,25 +1465,25 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
     const int n = (int)(q.n_feat * q.batch);    // columns of the activation matrix
     signed char* planes = (signed char*)ws + pw[i].planes;
     int* emax = (int*)((char*)ws + pw[i].ints);
-    int* deep_cnt = emax + n;
-    int* nz_cnt = deep_cnt + n;
+    unsigned long long* stats = (unsigned long long*)(emax + (n + 1) / 2 * 2);
     unsigned char* zmask = (unsigned char*)ws + pw[i].zmask;
-    MDG_HIP(hipMemsetAsync(emax, 0, (size_t)(3 * n) * sizeof(int), st));
+    MDG_HIP(hipMemsetAsync(emax, 0, (size_t)((n + 1) / 2 * 2) * sizeof(int) + (size_t)(NSTAT * n) * sizeof(unsigned long long), st));
     const bool vec = ((uintptr_t)q.x % 16 == 0) && (q.ld % 8 == 0);
     const int64_t rows_per_block = 2048;
     if (vec) {
       hipLaunchKernelGGL(i8_colmax_vec_kernel, dim3((unsigned)(n / 128), (unsigned)ceil_div(n_tokens, rows_per_block)), dim3(256), 0,
                          st, (const bf16_t*)q.x, q.ld, n_tokens, rows_per_block, emax);
-      hipLaunchKernelGGL(i8_split_vec_kernel, dim3((unsigned)(n / 128), (unsigned)ceil_div(nk, 2)), dim3(256), 0, st,
-                         (const bf16_t*)q.x, q.ld, n_tokens, n, nk, emax, planes, deep_cnt, nz_cnt, zmask);
+      hipLaunchKernelGGL(i8_split_vec_kernel, dim3((unsigned)(n / 128), (unsigned)ceil_div(nk, 2 * SPLIT_TILES)), dim3(256), 0, st,
+                         (const bf16_t*)q.x, q.ld, n_tokens, n, nk, emax, planes, stats, zmask);
     } else {
       hipLaunchKernelGGL(i8_colmax_kernel, dim3((unsigned)ceil_div(n, 64), (unsigned)ceil_div(n_tokens, rows_per_block)), dim3(256),
                          0, st, (const bf16_t*)q.x, q.ld, n_tokens, n, rows_per_block, emax);
       hipLaunchKernelGGL(i8_split_kernel, dim3((unsigned)(n / 32), (unsigned)ceil_div(nk, SPLIT_STEPS)), dim3(256), 0, st,
-                         (const bf16_t*)q.x, q.ld, n_tokens, n, nk, emax, planes, deep_cnt, nz_cnt, zmask);
+                         (const bf16_t*)q.x, q.ld, n_tokens, n, nk, emax, planes, stats, zmask);
     }
     // a flag per statistic: the launch takes the deepest route any statistic still on the int8 path asks for (launch_route)
-    hipLaunchKernelGGL(i8_depth_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, deep_cnt, nz_cnt, emax, n, pflag + i);
+    hipLaunchKernelGGL(i8_route_kernel, dim3(1), dim3(ROUTE_THREADS), 0, st, stats, emax, n, tau_x_of(n_tokens), (double*)((char*)ws + pw[i].vals), pflag + i,
+                       (RouteOut*)((char*)ws + pw[i].route), route_counts);
     MDG_LAUNCH_CHECK();
     a.prob[i] = SyrkProblem{planes, emax, zmask, q.sigma, q.ld_sigma, n, q.batch > 1 ? TI : 0};
     shapes.emplace_back(n / TI, q.batch > 1 ? TI : 0);
@@ -1161,8 +1559,24 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
     MDG_LAUNCH_CHECK();
   }
   if (ev_stop) MDG_HIP(hipEventRecord((hipEvent_t)ev_stop, st));
-  // some column of a statistic is mostly far below its maximum (its flag's bit 1): six planes do not carry fp64-level accuracy
-  // there -- that statistic, and only that one, goes through the fp64 kernel
+  // the columns the route took off the int8 path: their rows / columns of sigma from the fp64 column kernel (both launches exit at
+  // once when there are none)
+  for (int i = 0; i < count; i++) {
+    const mdg_cov_problem& q = problems[i];
+    const int n = (int)(q.n_feat * q.batch);
+    ColArgs c;
+    c.x = (const bf16_t*)q.x; c.ld = q.ld; c.T = n_tokens; c.n = n;
+    c.vec = ((uintptr_t)q.x % 16 == 0) && (q.ld % 8 == 0);
+    c.route = (const RouteOut*)((char*)ws + pw[i].route);
+    c.flag = pflag + i;
+    c.part = (double*)((char*)ws + pw[i].colpart);
+    hipLaunchKernelGGL(i8_columns_kernel, dim3((unsigned)ceil_div(n, COLK_WG_COLS), COLK_CHUNKS, ROUTE_JMAX / COLK_GROUP), dim3(64), 0, st, c);
+    hipLaunchKernelGGL(i8_columns_reduce_kernel, dim3((unsigned)ceil_div(n, 256), ROUTE_JMAX), dim3(256), 0, st, c, a.prob[i].emax, q.sigma,
+                       q.ld_sigma, q.batch > 1 ? TI : 0);
+    MDG_LAUNCH_CHECK();
+  }
+  // a statistic the bound cannot certify on six planes even without its ROUTE_JMAX worst columns (its flag's bit 1) -- that
+  // statistic, and only that one -- goes through the fp64 kernel
   for (int i = 0; i < count; i++) {
     const mdg_cov_problem& q = problems[i];
     const int fb = cov_accum_gated(q.x, MDG_BF16, n_tokens, q.n_feat, q.batch, q.ld, 0, q.sigma, q.ld_sigma, q.sigma_batch_stride, fb_ws,
@@ -1258,6 +1672,27 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
                 (long long)n_feat, TI);
   const mdg_cov_problem q = single_problem(x, n_tokens, n_feat, ld, sigma, ld_sigma);
   return mdg_cov_accum_i8_multi(1, &q, ws, ws_bytes, used_i8, route_counts, ev_start, ev_stop, stream);
+}
+
+extern "C" int mdg_cov_accum_i8_route(int count, const mdg_cov_problem* problems, int stat, const void* ws, int* planes, int* n_columns,
+                                      int* columns, double* bound, void* stream) {
+  MDG_CLEAR();
+  MDG_CHECK_ARG(problems_ok(count, problems) && stat >= 0 && stat < count && ws, "mdg_cov_accum_i8_route: bad arguments");
+  ProblemWs pw[MAX_PROBLEMS];
+  layout(count, problems, pw, nullptr);
+  RouteOut r;
+  hipStream_t st = (hipStream_t)stream;
+  MDG_HIP(hipMemcpyAsync(&r, (const char*)ws + pw[stat].route, sizeof(r), hipMemcpyDeviceToHost, st));
+  MDG_HIP(hipStreamSynchronize(st));
+  if (planes) *planes = r.planes;
+  if (n_columns) *n_columns = r.n_out;
+  if (columns)
+    for (int i = 0; i < MDG_I8_MAX_COLUMNS; i++) columns[i] = i < r.n_out ? r.out[i] : -1;
+  if (bound) {
+    bound[0] = r.sq;
+    bound[1] = r.x;
+  }
+  return MDG_OK;
 }
 
 extern "C" int mdg_cov_accum_i8_stats(const void* ws, int64_t n_tokens, int64_t n_feat, unsigned long long* executed_mfma,

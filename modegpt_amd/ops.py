@@ -74,13 +74,17 @@ def cov_accum(sigma: torch.Tensor, x: torch.Tensor, n_heads: int = 1, relu: bool
 
 
 def cov_accum_i8(sigma: torch.Tensor, x: torch.Tensor, events=None, mfma_stats: Optional[dict] = None,
-                 report: bool = True) -> Optional[int]:
-    """sigma (lower triangle) += X^T X for one bf16 matrix through the int8 digit-plane kernel (csrc/cov_i8.hip).
-    The route -- five planes, six planes, or the fp64 kernel for batches whose per-column depth statistic is too heavy-tailed
-    -- is chosen on the device; the result is valid either way.  report=True (tests, measurements) returns the route of this
+                 report: bool = True, route_info: Optional[dict] = None) -> Optional[int]:
+    """sigma (lower triangle) += X^T X for one bf16 matrix through the int8 digit-plane kernel (csrc/cov_i8.hip): error-free
+    split into digit planes, truncated plane-pair product.  The route -- five planes or six, which columns leave the int8 path
+    for the fp64 column kernel (at most 32), or the fp64 kernel for the whole statistic -- is derived on the device from a
+    per-call error bound (guaranteed <= 1.1e-11 of sqrt(sigma_ii sigma_jj) entry-wise, measured <= 1e-12; include/modegpt_hip.h);
+    the result is valid either way.  report=True (tests, measurements) returns the route of this
     call (5, 6, or 0 for the fp64 kernel) at the price of one stream synchronisation and books it in I8_STATS;
     report=False (the hooks: cov_accum_multi) only enqueues and returns None -- the per-device counters behind
     i8_route_counts() are updated by the kernels themselves in both modes.  Feature count must be a multiple of 128.
+    route_info: optional dict, filled with {"planes", "columns" (those the fp64 column kernel computed), "sq", "x" (the two parts
+    of the bound for the columns that stayed), "bound" (their sum)} -- implies report.
     events: optional pair of torch.cuda.Event(enable_timing=True), each recorded once already, re-recorded around the product
     launches alone.  mfma_stats: optional dict; its "executed" entry is increased by the number of v_mfma instructions the
     product kernel issued (it skips digit planes that are all-zero over a tile panel) and "dense" by what a kernel without
@@ -99,7 +103,7 @@ def cov_accum_i8(sigma: torch.Tensor, x: torch.Tensor, events=None, mfma_stats: 
         raise ValueError(f"shape mismatch: sigma {tuple(sigma.shape)}, x {tuple(x2.shape)}")
     nbytes = lib.mdg_cov_accum_i8_ws_bytes(x2.shape[0], n)
     ws, wsp = _ws(nbytes, x.device)
-    report = report or mfma_stats is not None
+    report = report or mfma_stats is not None or route_info is not None
     used = C.c_int(0)
     with torch.cuda.device(x.device):
         check(lib.mdg_cov_accum_i8(x2.data_ptr(), x2.shape[0], n, x2.stride(0), sigma.data_ptr(), sigma.stride(0), wsp, nbytes,
@@ -111,13 +115,28 @@ def cov_accum_i8(sigma: torch.Tensor, x: torch.Tensor, events=None, mfma_stats: 
             check(lib.mdg_cov_accum_i8_stats(wsp, x2.shape[0], n, C.byref(done), _stream(x)), "mdg_cov_accum_i8_stats")
             mfma_stats["executed"] = mfma_stats.get("executed", 0) + done.value
             mfma_stats["dense"] = mfma_stats.get("dense", 0) + i8_dense_mfma_count(x2.shape[0], n, used.value)
+        if route_info is not None:
+            arr = (_lib.CovProblem * 1)(_lib.CovProblem(x2.data_ptr(), x2.shape[0], n, 1, x2.stride(0), sigma.data_ptr(),
+                                                        sigma.stride(0), 0))
+            route_info.update(_read_route(lib, 1, arr, 0, wsp, _stream(x)))
     if not report:
         return None
     I8_STATS[{5: "i8_5", 6: "i8_6"}.get(used.value, "fallback_f64")] += 1
     return used.value
 
 
-def cov_accum_i8_multi(items, events=None, mfma_stats: Optional[dict] = None, report: bool = False) -> Optional[int]:
+def _read_route(lib, count, arr, stat, wsp, stream) -> dict:
+    planes, ncol = C.c_int(0), C.c_int(0)
+    cols = (C.c_int * 32)()
+    bound = (C.c_double * 2)()
+    check(lib.mdg_cov_accum_i8_route(count, arr, stat, wsp, C.byref(planes), C.byref(ncol), cols, bound, stream),
+          "mdg_cov_accum_i8_route")
+    return {"planes": planes.value, "columns": [cols[i] for i in range(ncol.value)], "sq": bound[0], "x": bound[1],
+            "bound": bound[0] + bound[1]}
+
+
+def cov_accum_i8_multi(items, events=None, mfma_stats: Optional[dict] = None, report: bool = False,
+                       route_info: Optional[list] = None) -> Optional[int]:
     """Several statistics of ONE calibration batch through the int8 digit-plane kernels in one persistent product launch
     (mdg_cov_accum_i8_multi): items = sequence of (sigma, x, n_heads), largest first, at most 4, all bf16 with the same token
     count.  n_heads == 1: sigma [n, n], n a multiple of 128; n_heads > 1: per-head Grams, sigma [n_heads, 128, 128] of an
@@ -125,7 +144,7 @@ def cov_accum_i8_multi(items, events=None, mfma_stats: Optional[dict] = None, re
     large one's last round leaves idle -- and one route: the deepest any column of any of them asks for (more planes are
     never less exact); a statistic too heavy-tailed for six planes leaves the launch alone (fp64 kernel).  events / mfma_stats /
     report as in cov_accum_i8 (report: the planes of the statistics that stayed, 0 if none did; the executed / dense counts cover
-    all statistics and assume none fell back)."""
+    all statistics and assume none fell back).  route_info: optional list, extended by one dict per statistic (see cov_accum_i8)."""
     lib = _lib.load()
     items = list(items)
     arr = (_lib.CovProblem * len(items))()
@@ -152,7 +171,7 @@ def cov_accum_i8_multi(items, events=None, mfma_stats: Optional[dict] = None, re
         raise ValueError("these statistics cannot share an int8 launch (token counts differ, widths not multiples of 128, or "
                          "per-head statistics with head_dim != 128)")
     ws, wsp = _ws(nbytes, dev)
-    report = report or mfma_stats is not None
+    report = report or mfma_stats is not None or route_info is not None
     used = C.c_int(0)
     with torch.cuda.device(dev):
         check(lib.mdg_cov_accum_i8_multi(len(items), arr, wsp, nbytes, C.byref(used) if report else None,
@@ -164,6 +183,8 @@ def cov_accum_i8_multi(items, events=None, mfma_stats: Optional[dict] = None, re
             check(lib.mdg_cov_accum_i8_stats(wsp, 0, 0, C.byref(done), _stream(keep[0])), "mdg_cov_accum_i8_stats")
             mfma_stats["executed"] = mfma_stats.get("executed", 0) + done.value
             mfma_stats["dense"] = mfma_stats.get("dense", 0) + sum(i8_dense_mfma_count(t, f, used.value, h) for t, f, h in dense_shapes)
+        if route_info is not None:
+            route_info.extend(_read_route(lib, len(items), arr, i, wsp, _stream(keep[0])) for i in range(len(items)))
     if not report:
         return None
     I8_STATS[{5: "i8_5", 6: "i8_6"}.get(used.value, "fallback_f64")] += len(items)
@@ -174,23 +195,25 @@ _ROUTE_COUNTERS = {}
 
 
 def _route_counters(device) -> torch.Tensor:
-    """Per-device int32[3] the product kernels bump: [five planes, six planes, fp64 fallback] (mdg_cov_accum_i8 route_counts)."""
+    """Per-device int32[4] the kernels bump: [five planes, six planes, fp64 fallback of a whole statistic, columns handed to the
+    fp64 column kernel] (mdg_cov_accum_i8 route_counts)."""
     dev = torch.device(device)
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     if key not in _ROUTE_COUNTERS:
-        _ROUTE_COUNTERS[key] = torch.zeros(3, dtype=torch.int32, device=torch.device("cuda", key))
+        _ROUTE_COUNTERS[key] = torch.zeros(4, dtype=torch.int32, device=torch.device("cuda", key))
     return _ROUTE_COUNTERS[key]
 
 
 def i8_route_counts(device=None, reset: bool = False) -> dict:
     """How the int8-route requests on `device` (default: the current one) were served so far, counted on the device by the
-    kernels that ran: {"i8_5", "i8_6", "fallback_f64"}.  One small device -> host copy; calibration reads it once, at the end."""
+    kernels that ran: {"i8_5", "i8_6", "fallback_f64"} count statistics, "fp64_columns" the single columns the route handed to
+    the fp64 column kernel.  One small device -> host copy; calibration reads it once, at the end."""
     key = torch.cuda.current_device() if device is None else (torch.device(device).index or 0)
     t = _route_counters(torch.device("cuda", key))
     v = t.cpu().tolist()
     if reset:
         t.zero_()
-    return {"i8_5": v[0], "i8_6": v[1], "fallback_f64": v[2]}
+    return {"i8_5": v[0], "i8_6": v[1], "fallback_f64": v[2], "fp64_columns": v[3]}
 
 
 def i8_dense_mfma_count(n_tokens: int, n: int, planes: int, n_heads: int = 1) -> int:
@@ -207,8 +230,9 @@ def i8_dense_mfma_count(n_tokens: int, n: int, planes: int, n_heads: int = 1) ->
 
 
 # Which matrix cores accumulate the large covariances of a layer: "f64" (v_mfma_f64, the accumulation order of the
-# reference's fp64 matmul) or "i8" (exact digit-plane split on the int8 cores, csrc/cov_i8.hip; per-head statistics and
-# anything it cannot take stay on the fp64 kernel, and every call falls back by itself on outlier-dominated columns).
+# reference's fp64 matmul) or "i8" (error-free digit-plane split, truncated product on the int8 cores, csrc/cov_i8.hip; what it
+# cannot take stays on the fp64 kernel, and every call derives its route -- planes, columns for the fp64 column kernel, or the
+# fp64 kernel -- from its own error bound).
 COV_MODE = os.environ.get("MODEGPT_COV_MODE", "i8")
 I8_MIN_FEATURES = 2048
 I8_STATS = {"i8_5": 0, "i8_6": 0, "fallback_f64": 0}      # routes of the REPORTING cov_accum_i8 calls (tests, bench); all calls: i8_route_counts()

@@ -207,9 +207,9 @@ def _check_against(S, R):
 
 
 @pytest.mark.parametrize("widths,heads,T,kind,planes", [
-    ([4096, 2048], [8, 2], 5000, "gaussian", 5),            # 528 + 136 + 8 + 2 tiles of 128 x 128, k-split tail across statistics
-    ([4096, 2048], [8, 2], 5000, "silu_gated", 6),          # the gated statistic takes every other one to six planes
-    ([2048], [32], 700, "gaussian", None),                  # (few tokens: some column's deep share may pass 1 / 64 -> either route)
+    ([4096, 2048], [8, 2], 12000, "gaussian", 5),           # 528 + 136 + 8 + 2 tiles of 128 x 128, k-split tail across statistics
+    ([4096, 2048], [8, 2], 12000, "silu_gated", 6),         # the gated statistic takes every other one to six planes
+    ([2048], [32], 700, "gaussian", None),                  # (few tokens: the bound of some column may ask for six planes -> either route)
     ([14336, 4096], [32, 8], 32768, "gaussian", 5),         # the four hooks of a Llama-3-8B layer, one calibration batch
     ([14336, 4096], [32, 8], 32768, "silu_gated", 6),
     ([3328], [3], 2 * 65504 + 100, "gaussian", 5),          # across two int32 folds
@@ -229,43 +229,124 @@ def test_fused_int8_launch_of_a_layers_statistics(ops, dev, widths, heads, T, ki
     for (S, _, _), R in zip(items, refs):
         _check_against(S, 2 * R)
     counts = ops.i8_route_counts(dev, reset=True)
-    assert counts[{5: "i8_5", 6: "i8_6"}[planes]] == 2 * len(items) and sum(counts.values()) == 2 * len(items)
+    assert counts[{5: "i8_5", 6: "i8_6"}[planes]] == 2 * len(items) and counts["i8_5"] + counts["i8_6"] + counts["fallback_f64"] == 2 * len(items)
+    assert counts["fp64_columns"] == 0 or T < 10240        # (short calls: the cross-term threshold is tighter, columns may leave)
 
 
-def test_fused_int8_launch_lets_one_statistic_fall_back_alone(ops, dev):
-    """One column dominated by a single massive activation sends THAT statistic to the fp64 kernel (its result then equals
-    ops.cov_accum's bit for bit); the other statistics of the launch stay on their digit planes."""
-    T = 3000
+def test_fused_int8_launch_lets_columns_and_statistics_leave_alone(ops, dev):
+    """One column dominated by a single massive activation leaves the int8 path -- that COLUMN, through the fp64 column kernel;
+    its statistic and the others of the launch stay on their digit planes.  A statistic whose every column is beyond six
+    planes goes to the fp64 kernel alone (its result then equals ops.cov_accum's bit for bit)."""
+    T = 12000
     Xa = gaussian(dev, T, 2048, 5)
     Xb = gaussian(dev, T, 2048, 6).clone()
     Xb[:, 17] = (Xb[:, 17].float() * 1e-6).to(torch.bfloat16)
     Xb[5, 17] = 300.0
-    Xq = gaussian(dev, T, 4 * 128, 7)
+    Xq = gaussian(dev, T, 4 * 128, 7).clone()
+    Xq[:, 2 * 128 + 5] = (Xq[:, 2 * 128 + 5].float() * 1e-5).to(torch.bfloat16)      # head 2, feature 5
+    Xq[100, 2 * 128 + 5] = -77.0
     items = [(torch.zeros(2048, 2048, dtype=F64, device=dev), Xa, 1), (torch.zeros(2048, 2048, dtype=F64, device=dev), Xb, 1),
              (torch.zeros(4, 128, 128, dtype=F64, device=dev), Xq, 4)]
     ops.i8_route_counts(dev, reset=True)
-    assert ops.cov_accum_i8_multi(items, report=True) == 5
-    assert ops.i8_route_counts(dev, reset=True) == {"i8_5": 2, "i8_6": 0, "fallback_f64": 1}
+    info = []
+    assert ops.cov_accum_i8_multi(items, report=True, route_info=info) == 5
+    assert [i["columns"] for i in info] == [[], [17], [2 * 128 + 5]] and all(i["planes"] == 5 for i in info)
+    assert ops.i8_route_counts(dev, reset=True) == {"i8_5": 3, "i8_6": 0, "fallback_f64": 0, "fp64_columns": 2}
     refs = []
     for S, X, nh in items:
         R = torch.zeros_like(S)
         ops.cov_accum(R, X, n_heads=nh)
         refs.append(R)
-    assert torch.equal(items[1][0], refs[1])
+    for (S, _, _), R in zip(items, refs):
+        _check_against(S, R)
     assert not torch.equal(items[0][0], refs[0])           # (an int8 result: equal to 1e-12, not to the bit)
-    _check_against(items[0][0], refs[0])
-    _check_against(items[2][0], refs[2])
-    # all of them heavy-tailed: nothing is left on the int8 path
-    both = [(torch.zeros(2048, 2048, dtype=F64, device=dev), Xb, 1), (torch.zeros(2048, 2048, dtype=F64, device=dev), Xb, 1)]
+    # a statistic with nothing the int8 path can certify goes to the fp64 kernel, alone
+    Xh = (torch.randn(T, 2048, device=dev) ** 5 * torch.randn(T, 2048, device=dev) ** 3).to(torch.bfloat16)
+    Rh = torch.zeros(2048, 2048, dtype=F64, device=dev)
+    ops.cov_accum(Rh, Xh)
+    mixed = [(torch.zeros(2048, 2048, dtype=F64, device=dev), Xa, 1), (torch.zeros(2048, 2048, dtype=F64, device=dev), Xh, 1)]
+    assert ops.cov_accum_i8_multi(mixed, report=True) == 5
+    assert ops.i8_route_counts(dev, reset=True) == {"i8_5": 1, "i8_6": 0, "fallback_f64": 1, "fp64_columns": 0}
+    assert torch.equal(mixed[1][0], Rh)
+    _check_against(mixed[0][0], refs[0])
+    both = [(torch.zeros(2048, 2048, dtype=F64, device=dev), Xh, 1), (torch.zeros(2048, 2048, dtype=F64, device=dev), Xh, 1)]
     assert ops.cov_accum_i8_multi(both, report=True) == 0
-    assert torch.equal(both[0][0], refs[1]) and torch.equal(both[1][0], refs[1])
+    assert torch.equal(both[0][0], Rh) and torch.equal(both[1][0], Rh)
+
+
+def massive(X, cols, spikes=3, gap=12, seed=0):
+    """BOS-like columns: the bulk of column c pushed `gap`+ binades under `spikes` massive activations."""
+    g = torch.Generator(device=X.device).manual_seed(seed)
+    X = X.clone()
+    for i, c in enumerate(cols):
+        top = X[:, c].float().abs().max()
+        X[:, c] = (X[:, c].float() * 2.0 ** -(gap + i)).to(torch.bfloat16)
+        rows = torch.randperm(X.shape[0], device=X.device, generator=g)[:spikes]
+        X[rows, c] = (top * (1.0 + torch.rand(spikes, device=X.device, generator=g))).to(torch.bfloat16)
+    return X
+
+
+@pytest.mark.parametrize("n,kind,planes", [(4096, "gaussian", 5), (14336, "gaussian", 5), (14336, "silu_gated", 6)])
+def test_massive_activation_columns_leave_alone_at_product_widths(ops, dev, n, kind, planes):
+    """four BOS-like columns (bulk 12-15 binades under 3 spikes) at the widths of sigma_x and sigma_mlp.  The
+    launch stays on its digit planes, exactly those four columns go to the fp64 column kernel, every entry equals the fp64
+    kernel's to 1e-12, and the call costs less than 5 % more than the clean one."""
+    cols = [5, 129, n // 2 + 77, n - 1]
+    X0 = (gaussian if kind == "gaussian" else silu_gated)(dev, T_BATCH, n, 300 + n)
+    X = massive(X0, cols)
+    S8 = torch.zeros(n, n, dtype=F64, device=dev)
+    S64 = torch.zeros_like(S8)
+    info = {}
+    assert ops.cov_accum_i8(S8, X, route_info=info) == planes
+    assert sorted(info["columns"]) == cols and info["bound"] <= 1.1e-11, info
+    ops.cov_accum(S64, X)
+    err = entrywise_err(S8, S64)
+    assert err < 1e-12 and err <= info["bound"] + 1e-15, (err, info)
+    # the clean batch takes the same planes, no columns
+    info0 = {}
+    assert ops.cov_accum_i8(S8, X0, route_info=info0) == planes and info0["columns"] == []
+
+    def timed(Xin):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        S8.zero_()
+        ops.cov_accum_i8(S8, Xin, report=False)
+        best = 1e9
+        for _ in range(3):
+            e0.record()
+            ops.cov_accum_i8(S8, Xin, report=False)
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        return best
+    t_clean, t_massive = timed(X0), timed(X)
+    print(f"n={n} {kind}: clean {t_clean:.2f} ms, with 4 massive columns {t_massive:.2f} ms (+{100 * (t_massive / t_clean - 1):.1f} %)")
+    assert t_massive < 1.05 * t_clean + 0.3, (t_clean, t_massive)   # (+0.3 ms: at 4096 features the whole call is ~3 ms)
+
+
+def test_device_route_equals_the_host_model_at_sigma_x_width(ops, dev):
+    """The device's decision (planes, columns in greedy order, both parts of the bound) against tests/i8_model.py on the same data,
+    4096 features x 12288 tokens, clean and with massive columns; measured error <= computed bound."""
+    from tests import i8_model as M
+    for kind, cols in (("gaussian", []), ("gaussian", [7, 2000]), ("silu_gated", [4095])):
+        X = (gaussian if kind == "gaussian" else silu_gated)(dev, 12288, 4096, 17)
+        X = massive(X, cols, gap=11) if cols else X
+        S8 = torch.zeros(4096, 4096, dtype=F64, device=dev)
+        S64 = torch.zeros_like(S8)
+        info = {}
+        ops.cov_accum_i8(S8, X, route_info=info)
+        want = M.route_of(X.cpu())
+        assert (info["planes"], info["columns"]) == (want["planes"], want["columns"]), (kind, cols, info, want["planes"], want["columns"])
+        assert abs(info["sq"] - want["sq"]) <= 1e-9 * want["sq"] and abs(info["x"] - want["x"]) <= 1e-9 * want["x"]
+        ops.cov_accum(S64, X)
+        err = entrywise_err(S8, S64)
+        assert err < 1e-12 and err <= info["bound"] + 1e-15, (kind, cols, err, info)
 
 
 def test_cov_accum_multi_routes_a_llama_layer(ops, dev, monkeypatch):
     """ops.cov_accum_multi in "i8" mode (what the adapter hooks call): sigma_mlp in a launch and on a route of its own (six
     planes on SiLU-gated data), sigma_x + sigma_q + sigma_k together in one cov_accum_i8_multi launch (five planes); with
     MODEGPT_I8_FUSE off the per-head statistics go through the fp64 kernel instead -- same results to 1e-12."""
-    T, f, d, nh, nkv = 4096, 4096, 2048, 8, 2
+    T, f, d, nh, nkv = 12288, 4096, 2048, 8, 2
     H, X, Q, K = silu_gated(dev, T, f, 1), gaussian(dev, T, d, 2), gaussian(dev, T, nh * 128, 3), gaussian(dev, T, nkv * 128, 4)
 
     def run(fuse):
@@ -278,7 +359,7 @@ def test_cov_accum_multi_routes_a_llama_layer(ops, dev, monkeypatch):
 
     fused, c1 = run(True)
     apart, c0 = run(False)
-    assert c1 == {"i8_5": 3, "i8_6": 1, "fallback_f64": 0}        # sigma_mlp alone on six planes; x, q, k share a five-plane launch
-    assert c0 == {"i8_5": 1, "i8_6": 1, "fallback_f64": 0}        # separate launches: sigma_mlp six planes, sigma_x five, heads fp64
+    assert c1 == {"i8_5": 3, "i8_6": 1, "fallback_f64": 0, "fp64_columns": 0}   # sigma_mlp alone on six planes; x, q, k share a five-plane launch
+    assert c0 == {"i8_5": 1, "i8_6": 1, "fallback_f64": 0, "fp64_columns": 0}   # separate launches: sigma_mlp six planes, sigma_x five, heads fp64
     for a, b in zip(fused, apart):
         _check_against(a, b)

@@ -529,25 +529,45 @@ def test_rope_strided_input_and_errors(ops, dev):
 
 
 # ---------------------------------------------------------------- int8 digit-plane covariance
+def entry_err(S, ref):
+    """max over the lower triangle of |S - ref|_ij / sqrt(ref_ii ref_jj)"""
+    S, ref = S.double().cpu(), ref.double().cpu()
+    d = torch.sqrt(torch.diagonal(ref))
+    d = torch.where(d > 0, d, torch.ones_like(d))
+    low = torch.tril(torch.ones_like(ref, dtype=torch.bool))
+    return (((S - ref).abs() / (d[:, None] * d[None]))[low]).max().item()
+
+
+def check_route(info, X):
+    """The device's route decision against the host model (tests/i8_model.py) on the same bf16 data: planes, the columns handed
+    to the fp64 column kernel IN THE ORDER the greedy took them, and both parts of the bound."""
+    from tests import i8_model as M
+    want = M.route_of(X.cpu())
+    assert (info["planes"], info["columns"]) == (want["planes"], want["columns"]), (info, {k: want[k] for k in ("planes", "columns", "sq", "x")})
+    if want["planes"]:
+        assert abs(info["sq"] - want["sq"]) <= 1e-9 * want["sq"] + 1e-300 and abs(info["x"] - want["x"]) <= 1e-9 * want["x"] + 1e-300
+    return want
+
+
 @pytest.mark.parametrize("tokens,feat", [(777, 256), (4096, 128), (33, 384), (20000, 256), (65504 + 3000, 128)])
 def test_cov_i8_matches_the_fp64_oracle(ops, dev, tokens, feat):
-    """The error-free int8 route against the oracle's fp64 X^T X: 1e-12 of |sigma| (the route's own bound on such data is
-    ~1e-13), lower triangle; a second call accumulates; 68504 tokens cross the int32 fold boundary (2047 k-steps = 65504
-    tokens, the exact bound enumerated by scripts/probes/i8_int32_bound.py)."""
+    """The int8 route (error-free split, truncated product) against the oracle's fp64 X^T X, entry-wise over sqrt(s_ii s_jj):
+    below 1e-12 AND below the bound the call itself computed; the route equals the host model's; a second call accumulates;
+    68504 tokens cross the int32 fold boundary (2047 k-steps = 65504 tokens, scripts/probes/i8_int32_bound.py)."""
     gen = torch.Generator().manual_seed(tokens + feat)
     X = acts(gen, tokens, feat)
     ref = torch.zeros(feat, feat, dtype=F64)
     O.cov_accum_tokens(ref, X)
     S = torch.zeros(feat, feat, dtype=F64, device=dev)
-    # Gaussian columns: five planes (with 33 tokens a single small element is already 3 % of a column: six)
-    assert ops.cov_accum_i8(S, X.to(dev)) == (5 if tokens > 100 else 6)
-    low = torch.tril(torch.ones(feat, feat, dtype=torch.bool))
-    err = ((S.cpu() - ref)[low].abs().max() / ref.abs().max()).item()
-    assert err < 1e-12, err
+    info = {}
+    assert ops.cov_accum_i8(S, X.to(dev), route_info=info) in (5, 6)
+    check_route(info, X)
+    err = entry_err(S, ref)
+    assert err < 1e-12 and err <= info["bound"] + 1e-15, (err, info)
     X2 = acts(gen, 200, feat)
     O.cov_accum_tokens(ref, X2)
     assert ops.cov_accum_i8(S, X2.to(dev)) in (5, 6)
-    assert ((S.cpu() - ref)[low].abs().max() / ref.abs().max()).item() < 1e-12
+    assert entry_err(S, ref) < 1e-12
 
 
 def test_cov_i8_agrees_with_the_fp64_kernel_and_is_deterministic(ops, dev):
@@ -559,43 +579,73 @@ def test_cov_i8_agrees_with_the_fp64_kernel_and_is_deterministic(ops, dev):
     assert ops.cov_accum_i8(S8, X) == 5 and ops.cov_accum_i8(S8b, X) == 5
     ops.cov_accum(S64, X)
     assert torch.equal(S8, S8b), "integer accumulation: bit-identical from run to run"
-    low = torch.tril(torch.ones(512, 512, dtype=torch.bool, device=dev))
-    assert ((S8 - S64)[low].abs().max() / S64.abs().max()).item() < 1e-12
+    assert entry_err(S8, torch.tril(S64) + torch.tril(S64, -1).T) < 1e-12
     ops.cov_finalize(S8, 1.0 / 5000)
     assert torch.equal(S8, S8.T)
 
 
-def test_cov_i8_hands_outlier_columns_to_the_fp64_kernel(ops, dev):
-    """A column whose maximum towers over its typical magnitude (the massive-activation pattern) fails the per-column test:
-    the call reports the fp64 route and the result is the fp64 kernel's."""
+def test_cov_i8_hands_outlier_columns_to_the_fp64_column_kernel(ops, dev):
+    """Columns whose bulk sits far below a few massive activations (the BOS-token dimensions of a Llama residual stream) leave
+    the int8 path ALONE: the launch stays on five planes, the fold skips their rows and columns, and the fp64 column kernel
+    computes those -- plain fp64 arithmetic, so they agree with the oracle to rounding."""
     gen = torch.Generator().manual_seed(6)
     X = acts(gen, 3000, 256)
     X[17, 40] = 3000.0
+    X[[5, 900, 2001], 131] = torch.tensor([-2.0e4, 1.5e4, 3.0e4]).to(torch.bfloat16)
+    ref = torch.zeros(256, 256, dtype=F64)
+    O.cov_accum_tokens(ref, X)
     S = torch.zeros(256, 256, dtype=F64, device=dev)
-    S64 = torch.zeros_like(S)
-    assert ops.cov_accum_i8(S, X.to(dev)) == 0
-    ops.cov_accum(S64, X.to(dev))
-    assert torch.equal(S, S64)
+    info = {}
+    ops.i8_route_counts(dev, reset=True)
+    assert ops.cov_accum_i8(S, X.to(dev), route_info=info) == 5
+    assert sorted(info["columns"]) == [40, 131]
+    check_route(info, X)
+    assert ops.i8_route_counts(dev, reset=True) == {"i8_5": 1, "i8_6": 0, "fallback_f64": 0, "fp64_columns": 2}
+    assert entry_err(S, ref) < 1e-12
+    low = torch.tril(S).cpu()
+    full = low + torch.tril(low, -1).T
+    for j in (40, 131):      # the column kernel's entries: fp64 sums of exact products
+        assert ((full[j] - ref[j]).abs() / (torch.sqrt(torch.diagonal(ref)) * torch.sqrt(ref[j, j]))).max().item() < 1e-13
+    ref_first = ref.clone()
+    # a second batch accumulates on top, again with its own columns
+    X2 = acts(gen, 1000, 256)
+    X2[3, 200] = -1.0e4
+    O.cov_accum_tokens(ref, X2)
+    info2 = {}
+    assert ops.cov_accum_i8(S, X2.to(dev), route_info=info2) == 5 and info2["columns"][0] == 200
+    check_route(info2, X2)      # (1000 tokens: the threshold on the cross terms is 1e-12, a few more columns leave to stay on five planes)
+    assert entry_err(S, ref) < 1e-12
+    # the same through the strided / unaligned element-wise passes
+    wide = torch.zeros(3000, 263, dtype=torch.bfloat16)
+    wide[:, 3:259] = X
+    S3 = torch.zeros(256, 256, dtype=F64, device=dev)
+    assert ops.cov_accum_i8(S3, wide.to(dev)[:, 3:259]) == 5
+    assert entry_err(S3, ref_first) < 1e-12
 
 
-@pytest.mark.parametrize("kind,route,tol", [("silu_gated", 6, 2e-13), ("laplace", 6, 2e-13), ("relu", 5, 1e-12), ("cubed", 0, 1e-13)])
-def test_cov_i8_route_follows_the_depth_of_the_columns(ops, dev, kind, route, tol):
-    """The per-column depth statistic picks the route: light tails -> 5 planes, SiLU-gated products (the MLP statistic of a
-    real Llama) -> 6 planes, heavier tails -> the fp64 kernel.  Error is measured against the oracle's fp64 product,
-    normalised entry-wise by sqrt(sigma_ii sigma_jj)."""
+@pytest.mark.parametrize("kind", ["silu_gated", "laplace", "relu", "cubed", "student_t"])
+def test_cov_i8_route_follows_the_error_bound(ops, dev, kind):
+    """The route is derived from the per-call bound (Cauchy-Schwarz on the plane energies): light tails -> five planes,
+    SiLU-gated products (the MLP statistic of a real Llama) -> six, heavier tails -> columns leave for the fp64 column kernel
+    or, when 32 are not enough, the whole statistic goes to the fp64 kernel.  Whatever is chosen must equal the host model's
+    choice and hold the measured error below 1e-12 and below the computed bound."""
     gen = torch.Generator().manual_seed(21)
     T, n = 6000, 256
     g, u = torch.randn(T, n, generator=gen), torch.randn(T, n, generator=gen)
     X = {"silu_gated": torch.nn.functional.silu(g) * u, "laplace": torch.sign(g) * torch.log(torch.rand(T, n, generator=gen)),
-         "relu": torch.relu(g), "cubed": g ** 3}[kind].to(torch.bfloat16)
+         "relu": torch.relu(g), "cubed": g ** 3, "student_t": g / torch.sqrt((torch.randn(3, T, n, generator=gen) ** 2).mean(0))}[kind].to(torch.bfloat16)
     ref = torch.zeros(n, n, dtype=F64)
     O.cov_accum_tokens(ref, X)
     S = torch.zeros(n, n, dtype=F64, device=dev)
-    assert ops.cov_accum_i8(S, X.to(dev)) == route
-    d = torch.sqrt(torch.diag(ref))
-    low = torch.tril(torch.ones(n, n, dtype=torch.bool))
-    err = (((S.cpu() - ref).abs() / (d[:, None] * d[None]))[low]).max().item()
-    assert err < tol, err
+    info = {}
+    planes = ops.cov_accum_i8(S, X.to(dev), route_info=info)
+    want = check_route(info, X)
+    assert planes == want["planes"]
+    assert planes == {"silu_gated": 6, "relu": 5}.get(kind, planes)
+    err = entry_err(S, ref)
+    assert err < 1e-12, err
+    if planes:
+        assert info["bound"] <= 1.1e-11 and err <= info["bound"] + 1e-15, (err, info)
 
 
 def test_cov_i8_special_values_and_errors(ops, dev):
@@ -615,9 +665,18 @@ def test_cov_i8_special_values_and_errors(ops, dev):
     assert S[9, 9].item() == ref[9, 9].item() != 0.0          # products of denormals are exact
     Xn = X.clone()
     Xn[3, 7] = float("inf")
+    Xn[40, 100] = float("nan")
     Sn = torch.zeros(128, 128, dtype=F64, device=dev)
-    assert ops.cov_accum_i8(Sn, Xn.to(dev)) == 0                  # Inf / NaN: the fp64 kernel's semantics
-    assert not bool(torch.isfinite(Sn[7, 7]))
+    info = {}
+    assert ops.cov_accum_i8(Sn, Xn.to(dev), route_info=info) in (5, 6)   # Inf / NaN columns go to the fp64 column kernel ...
+    assert info["columns"][:2] == [7, 100]
+    refn = torch.zeros(128, 128, dtype=F64)
+    O.cov_accum_tokens(refn, Xn)
+    lown = torch.tril(torch.ones(128, 128, dtype=torch.bool))
+    assert torch.equal(torch.isfinite(Sn.cpu())[lown], torch.isfinite(refn)[lown])   # ... which propagates them as the reference does
+    assert not bool(torch.isfinite(Sn[7, 7])) and not bool(torch.isfinite(Sn[100, 7]))
+    fin = torch.isfinite(refn) & lown
+    assert ((Sn.cpu() - refn)[fin].abs().max() / ref.abs().max()).item() < 1e-12
     with pytest.raises(RuntimeError, match="multiple of 128"):
         ops.cov_accum_i8(torch.zeros(200, 200, dtype=F64, device=dev), acts(gen, 64, 200).to(dev))
     with pytest.raises(ValueError):
@@ -790,12 +849,13 @@ def test_allgather_layers_through_the_c_abi(dev):
 
 def test_cov_i8_route_is_chosen_and_counted_on_the_device(ops, dev):
     """The hooks' path (report=False) never asks the host which route a call took: the five-plane product, the six-plane
-    product and the fp64 kernel are all enqueued and the device runs one.  The tallies live on the device
-    (ops.i8_route_counts) and the results equal those of the reporting calls bit for bit."""
+    product, the fp64 column kernel and the fp64 kernel are all enqueued and the device runs what the bound asks for.  The
+    tallies live on the device (ops.i8_route_counts) and the results equal those of the reporting calls bit for bit."""
     gen = torch.Generator().manual_seed(91)
     n, T = 256, 3000
     g, u = torch.randn(T, n, generator=gen), torch.randn(T, n, generator=gen)
-    data = {"i8_5": acts(gen, T, n), "i8_6": (torch.nn.functional.silu(g) * u).to(torch.bfloat16), "fallback_f64": (g ** 3).to(torch.bfloat16)}
+    heavy = (g ** 5 * u ** 3).to(torch.bfloat16)          # every column far beyond six planes: the whole statistic leaves
+    data = {"i8_5": acts(gen, T, n), "i8_6": (torch.nn.functional.silu(g) * u).to(torch.bfloat16), "fallback_f64": heavy}
     ops.i8_route_counts(dev, reset=True)
     for k, (route, X) in enumerate(data.items()):
         X = X.to(dev)
@@ -806,5 +866,8 @@ def test_cov_i8_route_is_chosen_and_counted_on_the_device(ops, dev):
         assert {5: "i8_5", 6: "i8_6", 0: "fallback_f64"}[planes] == route
         assert torch.equal(S0, S1)
         counts = ops.i8_route_counts(dev)
-        assert counts[route] == 2 and sum(counts.values()) == 2 * (k + 1), counts
+        assert counts[route] == 2 and sum(v for r, v in counts.items() if r != "fp64_columns") == 2 * (k + 1), counts
+    S64 = torch.zeros(n, n, dtype=F64, device=dev)
+    ops.cov_accum(S64, data["fallback_f64"].to(dev))
+    assert torch.equal(S1, S64)                                        # the whole-statistic fallback IS the fp64 kernel
     assert ops.i8_route_counts(dev, reset=True)["fallback_f64"] == 2 and sum(ops.i8_route_counts(dev).values()) == 0
