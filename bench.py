@@ -145,8 +145,8 @@ def accumulate_layer(shape, batches, n_texts, timer=None):
 def compress_layer(shape, adapter, layer_idx, covs, keep, timer=None):
     """Second half of a step: compress_nystrom + compress_qk + compress_vo on the layer's finished statistics."""
     if timer is None:
-        return engine.compress_layer(adapter, layer_idx, covs, keep)
-    return timer.run_decomposition(decomposition_flops(shape, keep), lambda: engine.compress_layer(adapter, layer_idx, covs, keep))
+        return engine.compress_layer(adapter, layer_idx, covs, keep, check=False)
+    return timer.run_decomposition(decomposition_flops(shape, keep), lambda: engine.compress_layer(adapter, layer_idx, covs, keep, check=False))
 
 
 def step(shape, adapter, layer_idx, batches, keep, n_texts, timer=None):
@@ -382,6 +382,7 @@ def timed_steps(shape, adapter, layer_ids, batches, keep, n_texts, timer=None, p
     for li in layer_ids:
         pipe.submit(li)
     outs = pipe.drain()
+    adapter.check_chains()          # the layers' Cholesky / eigensolver statuses, read once for all of them
     torch.cuda.synchronize()
     return time.perf_counter() - t0, outs
 
@@ -416,6 +417,7 @@ def main():
 
     for i in range(a.warmup):
         step(shape, adapter, first + i, batches, a.keep, n_texts)
+    adapter.check_chains()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -430,6 +432,7 @@ def main():
         records.append(sharding.pack_layer(li, {k: tensors.get(k) for k in sharding.TENSOR_ORDER}, mask))
         last = (li, tensors, mask, covs)
         done.append((li, tensors, mask, None))          # (compressed tensors of every timed layer: compared with the f64 leg's below)
+    adapter.check_chains()                               # the layers' Cholesky / eigensolver statuses, read once for all of them
     gathered = sharding.allgather_records(records, a.steps, world)  # the single RCCL all-gather (no-op copy at N=1)
     torch.cuda.synchronize()
     if world > 1:

@@ -33,7 +33,7 @@ extern "C" {
                              6: mdg_cov_accum_i8_multi added (several statistics in one int8 launch); the int8 workspace layout changed;
                              7: the int8 route is derived from a per-call error bound, single columns can leave the int8 path for an fp64
                                 column kernel (route_counts has 4 entries, mdg_cov_accum_i8_route added, workspace layout changed);
-                                mdg_shutdown added */
+                                mdg_shutdown and mdg_deferred_status_* added */
 
 enum mdg_status {
   MDG_OK = 0,
@@ -57,6 +57,19 @@ int mdg_abi_version(void);
 const char* mdg_last_error(void);
 /* Fills name (<= cap bytes) with the gcnArchName of `device`; MDG_ERR_NO_DEVICE if HIP sees no GPU. */
 int mdg_device_info(int device, char* name, int cap, int* n_cu, int64_t* hbm_bytes);
+/* Deferred status.  The decomposition entry points below that say "SYNCHRONISES" do so for one reason: a 4-byte device status
+ * word (the Cholesky's not-positive-definite pivot, the Jacobi solver's convergence flag) has to reach the host before they can
+ * return MDG_ERR_NOT_PD / MDG_ERR_NO_CONVERGE.  Between mdg_deferred_status_begin and mdg_deferred_status_end, on the calling
+ * thread, they merge that word into `status_dev` (DEVICE int[2], zeroed by _begin on `stream`: {kind of the FIRST failure, its
+ * detail}) with a one-thread kernel and return MDG_OK at once -- a whole layer's chain (ridge scores, Nystrom refit, QK selection,
+ * VO factors) then enqueues without a host round trip, and the caller reads the two ints whenever it next has to wait for the
+ * stream anyway.  mdg_deferred_status_decode turns the two ints (copied to the host by the caller) into the status code and
+ * mdg_last_error() text the synchronising call would have produced: MDG_ERR_NOT_PD -> torch.linalg.LinAlgError upstream
+ * (torch.linalg.cholesky, compress_mlp.py:20,56), MDG_ERR_NO_CONVERGE -> RuntimeError.  After a failure the remaining kernels of
+ * the chain still run (on garbage, within their buffers); their outputs must be discarded. */
+int mdg_deferred_status_begin(int* status_dev, void* stream);
+int mdg_deferred_status_end(void);
+int mdg_deferred_status_decode(const int* status_host);
 /* Releases what the library keeps across calls: the device copies of the int8 product's tile schedules (a few KB per shape,
  * built at first use).  The library owns no HIP streams or events -- those are the caller's -- and makes no HIP call from a static
  * destructor; call this before the process tears the HIP runtime down (modegpt_amd/_lib.py registers it with atexit), with no

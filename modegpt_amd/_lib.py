@@ -35,6 +35,9 @@ SIGNATURES = {
     "mdg_last_error": (C.c_char_p, []),
     "mdg_device_info": (_i32, [_i32, C.c_char_p, _i32, C.POINTER(_i32), C.POINTER(_i64)]),
     "mdg_shutdown": (_i32, []),
+    "mdg_deferred_status_begin": (_i32, [_ptr, _ptr]),
+    "mdg_deferred_status_end": (_i32, []),
+    "mdg_deferred_status_decode": (_i32, [C.POINTER(_i32)]),
     "mdg_cov_accum_ws_bytes": (_sz, [_i64, _i64, _i64]),
     "mdg_cov_accum": (_i32, [_ptr, _i32, _i64, _i64, _i64, _i64, _i32, _ptr, _i64, _i64, _ptr, _sz, _ptr]),
     "mdg_cov_accum_i8_ws_bytes": (_sz, [_i64, _i64]),

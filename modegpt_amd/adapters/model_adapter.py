@@ -72,6 +72,13 @@ class ModelAdapter(ABC):
     def save_metrics(self, path="./metrics/metrics.json", backup_dir="./metrics/backups/"):
         _metrics.save(path=path, backup_dir=backup_dir, run_metrics=self.metrics)
 
+    def chain_status(self, status) -> None:
+        """Called by compress_nystrom / compress_vo with the ops.DeferredStatus of a layer's kernel chain, right before the
+        layer's artefact is saved: the default reads it now -- the save waits for the stream anyway, so this is the chain's one
+        host round trip (upstream raises from inside torch.linalg.cholesky at the same point, compress_mlp.py:20,56).  An adapter
+        that keeps results on the device (engine.TensorAdapter) collects the statuses and checks them later."""
+        status.check()
+
     # ---- reconstruction: per-(layer, stage) artefacts and the final swap (model_adapter.py:184-237) ----
     def save_layer(self, output_dir: str, suffix: str, weights: dict, layer_idx):
         """torch.save({name: bf16 tensor}) to <output_dir>/layer_<i>_<suffix>; env vars in the path expand."""

@@ -52,8 +52,12 @@ def compress_nystrom(adapter: ModelAdapter, cov, keep_ratios, target_layers, rid
     adapter.config.nystrom_ridge; the `ridge_lambda` argument is ignored."""
     for layer_idx in target_layers:
         comps = adapter.get_mlp_components(layer_idx)
-        up_T, down_T, gate_T, rank = compress_weights(comps, cov[layer_idx], keep_ratios[layer_idx], layer_idx=layer_idx,
-                                                      ridge_lambda=adapter.config.nystrom_ridge)
+        # the layer's whole chain (two Cholesky factorisations, selection, gathers, Nystrom solve) enqueues without a host round
+        # trip; the not-positive-definite status of both factorisations is read once (adapter.chain_status)
+        with ops.DeferredStatus(local_device()) as status:
+            up_T, down_T, gate_T, rank = compress_weights(comps, cov[layer_idx], keep_ratios[layer_idx], layer_idx=layer_idx,
+                                                          ridge_lambda=adapter.config.nystrom_ridge)
+        (getattr(adapter, "chain_status", None) or (lambda st: st.check()))(status)     # (a duck-typed adapter: read it now)
         logger.info(f"[MLP] Layer {layer_idx}  compressed to rank {rank}")
         weights = {"up": up_T.T, "down": down_T.T}
         if gate_T is not None:

@@ -103,8 +103,10 @@ def compress_vo(adapter: ModelAdapter, cov: List[Tensor], keep_ratios=None, slic
         except Exception as e:  # same tolerance as compress_vo.py:47-53
             logger.warning(f"[VO] Layer {layer}: cannot access v_proj/o_proj: {e}")
             continue
-        V_heads, O_heads = ops.vo_compress(C, W_v.detach().to(local_device()), W_o.detach().to(local_device()), n_heads, n_kv, head_dim, rank_i,
-                                           adapter.config.ridge_vo)
+        with ops.DeferredStatus(local_device()) as status:      # (the eigensolver's convergence flag: read once, by the adapter)
+            V_heads, O_heads = ops.vo_compress(C, W_v.detach().to(local_device()), W_o.detach().to(local_device()), n_heads, n_kv, head_dim,
+                                               rank_i, adapter.config.ridge_vo)
+        (getattr(adapter, "chain_status", None) or (lambda st: st.check()))(status)     # (a duck-typed adapter: read it now)
         adapter.save_layer(output_dir=adapter.config.temp_storage_dir, suffix="vo",
                            weights={"v_proj": V_heads, "o_proj": O_heads}, layer_idx=layer)
         logger.info(f"[VO] Compressed layer {layer} to rank {rank_i} per head")

@@ -14,6 +14,41 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// ---- deferred status (see common.hpp finish_flag)
+static thread_local int* g_deferred_status = nullptr;   // DEVICE int[2]: {kind of the first failure (STATUS_*), its detail}
+
+__global__ void status_merge_kernel(const int* dflag, int* status, int kind) {
+  if (*dflag != 0 && status[0] == 0) {   // the first failure of the chain is the one reported
+    status[0] = kind;
+    status[1] = *dflag;
+  }
+}
+
+static int status_to_error(int kind, int detail, const char* what) {
+  if (kind == STATUS_NOT_PD) {
+    set_error("Cholesky: the factorization could not be completed because the input is not positive-definite "
+              "(the leading minor of order %d is not positive-definite)", detail);
+    return MDG_ERR_NOT_PD;
+  }
+  if (kind == STATUS_NO_CONVERGE) {
+    set_error("%s: Jacobi eigensolver did not converge in 40 sweeps", what ? what : "eigensolver");
+    return MDG_ERR_NO_CONVERGE;
+  }
+  return MDG_OK;
+}
+
+int finish_flag(int* dflag, hipStream_t st, int kind, const char* what) {
+  if (g_deferred_status) {
+    hipLaunchKernelGGL(status_merge_kernel, dim3(1), dim3(1), 0, st, dflag, g_deferred_status, kind);
+    MDG_LAUNCH_CHECK();
+    return MDG_OK;
+  }
+  int flag = 0;
+  MDG_HIP(hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, st));
+  MDG_HIP(hipStreamSynchronize(st));
+  return flag ? status_to_error(kind, flag, what) : MDG_OK;
+}
+
 // Each wave issues `iters` x 16 independent-accumulator v_mfma_f64_16x16x4_f64; operands never leave registers.
 __global__ __launch_bounds__(256, 2) void probe_mfma_f64_kernel(int iters, double* sink) {
   d4 acc[16];
@@ -85,6 +120,27 @@ extern "C" int mdg_device_info(int device, char* name, int cap, int* n_cu, int64
   if (n_cu) *n_cu = prop.multiProcessorCount;
   if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
   return MDG_OK;
+}
+
+extern "C" int mdg_deferred_status_begin(int* status_dev, void* stream) {
+  MDG_CLEAR();
+  MDG_CHECK_ARG(status_dev, "mdg_deferred_status_begin: null status pointer");
+  MDG_CHECK_ARG(!mdg::g_deferred_status, "mdg_deferred_status_begin: already in deferred mode on this thread");
+  MDG_HIP(hipMemsetAsync(status_dev, 0, 2 * sizeof(int), (hipStream_t)stream));
+  mdg::g_deferred_status = status_dev;
+  return MDG_OK;
+}
+
+extern "C" int mdg_deferred_status_end(void) {
+  MDG_CLEAR();
+  mdg::g_deferred_status = nullptr;
+  return MDG_OK;
+}
+
+extern "C" int mdg_deferred_status_decode(const int* status_host) {
+  MDG_CLEAR();
+  MDG_CHECK_ARG(status_host, "mdg_deferred_status_decode: null pointer");
+  return mdg::status_to_error(status_host[0], status_host[1], "decomposition chain");
 }
 
 extern "C" int mdg_shutdown(void) {

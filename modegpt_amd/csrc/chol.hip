@@ -296,11 +296,6 @@ __global__ __launch_bounds__(256) void lower_colnorm2_kernel(const double* X, in
   if (wave == 0 && j < n) out[j] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
 
-static int read_flag(int* dflag, hipStream_t st, int* host) {
-  MDG_HIP(hipMemcpyAsync(host, dflag, sizeof(int), hipMemcpyDeviceToHost, st));
-  MDG_HIP(hipStreamSynchronize(st));
-  return MDG_OK;
-}
 
 // Two-level right-looking Cholesky.  Inner level: 128-wide panels (diagonal block factorised + inverted in LDS,
 // panel solve = GEMM with the inverse), whose rank-128 updates touch only the rest of the current 512-wide OUTER
@@ -356,14 +351,7 @@ int potrf_lower(double* A, int64_t n, int64_t lda, double* inv_diag, hipStream_t
                        A + Jend * lda + Jend, MDG_F64, lda, 1, 0, 0, 0, MDG_GEMM_LOWER_ONLY, st));
     }
   }
-  int flag = 0;
-  MDG_TRY(read_flag(dflag, st, &flag));
-  if (flag != 0) {
-    set_error("Cholesky: the factorization could not be completed because the input is not positive-definite "
-              "(the leading minor of order %d is not positive-definite)", flag);
-    return MDG_ERR_NOT_PD;
-  }
-  return MDG_OK;
+  return finish_flag(dflag, st, STATUS_NOT_PD, "Cholesky");   // (one host round trip, or none in deferred-status mode)
 }
 
 // Triangular inverse by recursive doubling on the block size, starting from the inverted 128-wide diagonal blocks the

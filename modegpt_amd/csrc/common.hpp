@@ -26,6 +26,12 @@ typedef unsigned short f16_t;   // raw bits
 
 // ---------------------------------------------------------------- errors
 void set_error(const char* fmt, ...);
+// A device status word (Cholesky pivot / Jacobi convergence) at the end of a chain of launches.  Normally: one 4-byte copy to
+// the host + a stream synchronisation, then `fail` (MDG_ERR_NOT_PD / MDG_ERR_NO_CONVERGE) with the message `what` when it is
+// nonzero.  Between mdg_deferred_status_begin / _end the word is merged into the caller's device status instead and MDG_OK is
+// returned at once: the chain of a whole layer then enqueues without a single host round trip (api.hip).
+enum { STATUS_NOT_PD = 1, STATUS_NO_CONVERGE = 2 };
+int finish_flag(int* dflag, hipStream_t st, int kind, const char* what);
 
 // mdg_cov_accum with a device-side gate (cov.hip): the launches are enqueued unconditionally, and every workgroup exits at once
 // unless (*gate & gate_mask) == gate_want when it runs (gate == nullptr: always runs).  mdg_cov_accum_i8 enqueues its fp64

@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void i8_split_vec_kernel(const bf16_t* x, int6
 // that lives entirely in the deep planes: it alone sets A_2 .. A_4) -- else the whole statistic goes through mdg_cov_accum.  Columns
 // holding an Inf / NaN always leave (only the fp64 arithmetic propagates those the way the reference does).
 // ||N_j|| enters through the integer lower bound 2^32 (||256 d_0 + d_1|| - sqrt(nonzeros) / 2): every decision is a function of
-// integer sums, hence run-to-run bit-identical.  One workgroup per statistic; ~20 us when nothing has to leave.
+// integer sums, hence run-to-run bit-identical.  One workgroup per statistic.
 // TAU_SQ bounds the attained part.  The cross part is attained only by columns whose digit sequences are proportional over the
 // tokens; for uncorrelated columns the sums behind it grow like sqrt(tokens) where Cauchy-Schwarz allows tokens, so the measured
 // error sits ~4.5 / sqrt(tokens) below X_P (0.02 - 0.035 at 32768 tokens on every family of scripts/probes/i8_error_bound.py).
@@ -361,8 +361,7 @@ __host__ __device__ inline double tau_x_of(int64_t tokens) {
 }
 constexpr int ROUTE_JMAX = MDG_I8_MAX_COLUMNS;   // columns per statistic and call the fp64 column kernel takes (32)
 constexpr int NVAL = 7;                     // alpha_0 .. alpha_5, rho
-constexpr int ROUTE_THREADS = 1024;
-constexpr int HIST_BINS = 160, HIST_KEY0 = 2 * (1023 - 70);   // half-binade bins from 2^-70 up (values below: bin 0, floor 0)
+constexpr int ROUTE_THREADS = 512;
 
 struct RouteOut {                           // per statistic, in the workspace (mdg_cov_accum_i8_route reads it back)
   int planes;                               // 5, 6, or 0: the whole statistic goes through the fp64 kernel
@@ -400,22 +399,68 @@ __device__ __forceinline__ void top2_merge(Top2& a, const Top2& b) {   // (lowes
   }
 }
 
-__global__ __launch_bounds__(ROUTE_THREADS) void i8_route_kernel(const unsigned long long* stats, int* emax, int n, double tau_x, double* vals,
-                                                                 int* flag, RouteOut* out, int* route_counts) {
-  __shared__ int hist[NVAL][HIST_BINS];
+__global__ __launch_bounds__(ROUTE_THREADS) void i8_route_kernel(const unsigned long long* __restrict__ stats, int* emax, int n, double tau_x,
+                                                                 double* __restrict__ vals, int* flag, RouteOut* out, int* route_counts) {
+  __shared__ unsigned long long group_max[NVAL][64];   // per quantity: maxima of the 64 column classes j % 64 (bit patterns of doubles >= 0)
   __shared__ Top2 wave_top[ROUTE_THREADS / 64][NVAL];
   __shared__ Top2 top[NVAL];
-  __shared__ int decision;   // -1: keep going; 0: this P is done (accepted or given up)
+  __shared__ double floor_of[NVAL];
+  __shared__ int decision;   // -1: keep going; 0: accepted; 1: this P cannot be reached
+  __shared__ int forced_total;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < NVAL * HIST_BINS; i += ROUTE_THREADS) (&hist[0][0])[i] = 0;
+  for (int i = tid; i < NVAL * 64; i += ROUTE_THREADS) (&group_max[0][0])[i] = 0ull;
+  if (tid == 0) forced_total = 0;
   __syncthreads();
-  // alpha_s(j), rho_j from the integers; columns with an Inf / NaN (emax 255) leave at once
+  // top two of every quantity over the columns still on the int8 path: block reduction of per-thread results into top[]
+  auto reduce_top = [&](Top2 (&t)[NVAL]) {
+#pragma unroll
+    for (int i = 0; i < NVAL; i++) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        Top2 o;
+        o.m1 = __shfl_xor(t[i].m1, off);
+        o.a1 = __shfl_xor(t[i].a1, off);
+        o.m2 = __shfl_xor(t[i].m2, off);
+        top2_merge(t[i], o);
+      }
+      if (lane == 0) wave_top[wave][i] = t[i];
+    }
+    __syncthreads();
+    if (tid < NVAL) {
+      Top2 r = wave_top[0][tid];
+      for (int w = 1; w < ROUTE_THREADS / 64; w++) top2_merge(r, wave_top[w][tid]);
+      r.m1 = fmax(r.m1, 0.0);
+      r.m2 = fmax(r.m2, 0.0);
+      top[tid] = r;
+    }
+    __syncthreads();
+  };
+  // pass 1: alpha_s(j), rho_j from the integers (kept in `vals` for the greedy), the top two and the class maxima of every
+  // quantity; columns with an Inf / NaN (emax 255) leave at once
   int forced = 0;
-  for (int j = tid; j < n; j += ROUTE_THREADS) {
+  Top2 t[NVAL];
+#pragma unroll
+  for (int i = 0; i < NVAL; i++) t[i] = Top2{-1.0, 0x7fffffff, -1.0};
+  // (the integers of all of a thread's columns are requested before anything is computed: one memory round trip, not one per column)
+  constexpr int PASS1_COLS = 4;
+  for (int j0 = tid; j0 < n; j0 += ROUTE_THREADS * PASS1_COLS) {
+    unsigned long long raw[PASS1_COLS][NSTAT];
+    int ex[PASS1_COLS];
+#pragma unroll
+    for (int c = 0; c < PASS1_COLS; c++) {
+      const int j = j0 + c * ROUTE_THREADS;
+#pragma unroll
+      for (int i = 0; i < NSTAT; i++) raw[c][i] = j < n ? stats[(int64_t)i * n + j] : 0ull;
+      ex[c] = j < n ? emax[j] : 0;
+    }
+#pragma unroll
+    for (int c = 0; c < PASS1_COLS; c++) {
+    const int j = j0 + c * ROUTE_THREADS;
+    if (j >= n) break;
     double q[NSTAT];
 #pragma unroll
-    for (int i = 0; i < NSTAT - 1; i++) q[i] = i == STAT_D0D1 ? (double)(long long)stats[(int64_t)i * n + j] : (double)stats[(int64_t)i * n + j];
-    const unsigned long long counts = stats[(int64_t)STAT_COUNTS * n + j];
+    for (int i = 0; i < NSTAT - 1; i++) q[i] = i == STAT_D0D1 ? (double)(long long)raw[c][i] : (double)raw[c][i];
+    const unsigned long long counts = raw[c][STAT_COUNTS];
     const double nnz = (double)(unsigned)counts, rounded = (double)(unsigned)(counts >> 32);
     const double hi2 = 65536.0 * q[0] + 512.0 * q[STAT_D0D1] + q[1];
     const double norm = (sqrt(fmax(hi2, 0.0)) - 0.5 * sqrt(nnz)) * 4294967296.0;
@@ -425,26 +470,23 @@ __global__ __launch_bounds__(ROUTE_THREADS) void i8_route_kernel(const unsigned 
 #pragma unroll
     for (int s = 0; s < NP; s++) a[s] = q[s] > 0 ? sqrt(q[s]) * ldexp(1.0, 8 * (NP - 1 - s)) * inv : 0.0;
     a[6] = rounded > 0 ? 0.5 * sqrt(rounded) * inv : 0.0;
-    const bool nonfinite = (emax[j] & 255) == 255;
+    const bool nonfinite = (ex[c] & 255) == 255;
 #pragma unroll
     for (int i = 0; i < NVAL; i++) {
       vals[(int64_t)i * n + j] = a[i];
-      if (!nonfinite) {
-        const int key = (int)(__double_as_longlong(a[i]) >> 51) - HIST_KEY0;   // 2 x exponent + top mantissa bit
-        atomicAdd(&hist[i][min(max(key, 0), HIST_BINS - 1)], 1);
-      }
+      if (!nonfinite) top2_merge(t[i], Top2{a[i], j, -1.0});
     }
     if (nonfinite) {
-      emax[j] |= EMAX_COLUMN_OUT;
+      emax[j] = ex[c] | EMAX_COLUMN_OUT;
       forced++;
     }
+    }
   }
-  // forced columns, in index order (deterministic): count them, then list them
-  __shared__ int forced_total;
-  if (tid == 0) forced_total = 0;
-  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NVAL; i++)
+    if (t[i].m1 > 0.0) atomicMax(&group_max[i][lane], (unsigned long long)__double_as_longlong(t[i].m1));   // (thread tid's columns are all = lane mod 64)
   if (forced) atomicAdd(&forced_total, forced);
-  __syncthreads();
+  reduce_top(t);
   int n_out = 0;
   if (forced_total > ROUTE_JMAX) {      // too many: the whole statistic goes through the fp64 kernel
     if (tid == 0) {
@@ -454,66 +496,60 @@ __global__ __launch_bounds__(ROUTE_THREADS) void i8_route_kernel(const unsigned 
     for (int j = tid; j < n; j += ROUTE_THREADS) emax[j] &= 255;
     return;
   }
-  if (forced_total) {
+  if (forced_total) {                   // (rare: listed in index order by one thread)
     if (tid == 0)
       for (int j = 0; j < n; j++)
         if (emax[j] & EMAX_COLUMN_OUT) out->out[n_out++] = j;
-    n_out = forced_total;
     __syncthreads();
   }
-  const int n_forced = n_out;
-  for (int P = 5; P <= 6; P++) {
-    // prefilter: whatever ROUTE_JMAX columns leave, the (ROUTE_JMAX + 1)-th largest value of every quantity stays; its
-    // histogram bin's lower edge is a lower bound on it
-    {
-      __shared__ double floor_of[NVAL];
-      if (tid < NVAL) {
-        int seen = 0, b = HIST_BINS - 1;
-        for (; b > 0; b--) {
-          seen += hist[tid][b];
-          if (seen > ROUTE_JMAX - n_forced) break;
-        }
-        floor_of[tid] = b > 0 ? __longlong_as_double((long long)(b + HIST_KEY0) << 51) : 0.0;
+  const int n_forced = forced_total;
+  // Whatever ROUTE_JMAX columns leave, the (ROUTE_JMAX + 1)-th largest value of every quantity stays.  A lower bound on it without
+  // sorting: the (ROUTE_JMAX + 1 - forced)-th largest of the 64 class maxima (that many DISTINCT columns are at least as large).
+  if (wave == 0) {
+    const int want = ROUTE_JMAX - n_forced;        // 0-based rank among the class maxima
+#pragma unroll 1
+    for (int i = 0; i < NVAL; i++) {
+      const unsigned long long mine = group_max[i][lane];
+      int rank = 0;
+      for (int k = 0; k < 64; k++) {
+        const unsigned long long o = group_max[i][k];
+        rank += (o > mine || (o == mine && k < lane));
       }
-      __syncthreads();
-      double fl[NVAL];
-#pragma unroll
-      for (int i = 0; i < NVAL; i++) fl[i] = floor_of[i];
-      __syncthreads();
-      if (n > ROUTE_JMAX && route_violation(fl, P, tau_x) > 1.0) continue;   // (uniform: every thread computes the same)
+      if (rank == want) floor_of[i] = __longlong_as_double((long long)mine);
     }
+  }
+  __syncthreads();
+  double fl[NVAL];
+#pragma unroll
+  for (int i = 0; i < NVAL; i++) fl[i] = floor_of[i];
+  bool top_valid = true;
+  for (int P = 5; P <= 6; P++) {
+    if (n > 64 && route_violation(fl, P, tau_x) > 1.0) continue;   // hopeless for this P (uniform: every thread computes the same)
     n_out = n_forced;
     for (;;) {
-      // top two of every quantity over the columns still on the int8 path
-      Top2 t[NVAL];
+      if (!top_valid) {             // (the first look uses pass 1's result)
+        top_valid = true;
 #pragma unroll
-      for (int i = 0; i < NVAL; i++) t[i] = Top2{-1.0, 0x7fffffff, -1.0};
-      for (int j = tid; j < n; j += ROUTE_THREADS) {
-        if (emax[j] & EMAX_COLUMN_OUT) continue;
+        for (int i = 0; i < NVAL; i++) t[i] = Top2{-1.0, 0x7fffffff, -1.0};
+        for (int j0 = tid; j0 < n; j0 += ROUTE_THREADS * PASS1_COLS) {
+          double v[PASS1_COLS][NVAL];
+          int ex[PASS1_COLS];
 #pragma unroll
-        for (int i = 0; i < NVAL; i++) top2_merge(t[i], Top2{vals[(int64_t)i * n + j], j, -1.0});
-      }
+          for (int c = 0; c < PASS1_COLS; c++) {
+            const int j = j0 + c * ROUTE_THREADS;
+            ex[c] = j < n ? emax[j] : EMAX_COLUMN_OUT;
 #pragma unroll
-      for (int i = 0; i < NVAL; i++) {
+            for (int i = 0; i < NVAL; i++) v[c][i] = j < n ? vals[(int64_t)i * n + j] : 0.0;
+          }
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-          Top2 o;
-          o.m1 = __shfl_xor(t[i].m1, off);
-          o.a1 = __shfl_xor(t[i].a1, off);
-          o.m2 = __shfl_xor(t[i].m2, off);
-          top2_merge(t[i], o);
+          for (int c = 0; c < PASS1_COLS; c++)
+            if (!(ex[c] & EMAX_COLUMN_OUT)) {
+#pragma unroll
+              for (int i = 0; i < NVAL; i++) top2_merge(t[i], Top2{v[c][i], j0 + c * ROUTE_THREADS, -1.0});
+            }
         }
-        if (lane == 0) wave_top[wave][i] = t[i];
+        reduce_top(t);
       }
-      __syncthreads();
-      if (tid < NVAL) {
-        Top2 r = wave_top[0][tid];
-        for (int w = 1; w < ROUTE_THREADS / 64; w++) top2_merge(r, wave_top[w][tid]);
-        r.m1 = fmax(r.m1, 0.0);
-        r.m2 = fmax(r.m2, 0.0);
-        top[tid] = r;
-      }
-      __syncthreads();
       if (tid == 0) {
         double A[NVAL];
 #pragma unroll
@@ -553,17 +589,53 @@ __global__ __launch_bounds__(ROUTE_THREADS) void i8_route_kernel(const unsigned 
       if (dec == 0) return;
       if (dec == 1) break;
       n_out++;
+      top_valid = false;
     }
     // this P cannot be reached: take the greedy picks back (the forced columns stay out)
-    for (int j = tid; j < n; j += ROUTE_THREADS)
-      if ((emax[j] & EMAX_COLUMN_OUT) && (emax[j] & 255) != 255) emax[j] &= 255;
-    __syncthreads();
+    if (n_out > n_forced) {
+      for (int j = tid; j < n; j += ROUTE_THREADS)
+        if ((emax[j] & EMAX_COLUMN_OUT) && (emax[j] & 255) != 255) emax[j] &= 255;
+      top_valid = false;
+      __syncthreads();
+    }
   }
   if (tid == 0) {
     out->planes = 0; out->n_out = 0; out->sq = out->x = 0.0;
     atomicOr(flag, 2);
   }
   for (int j = tid; j < n; j += ROUTE_THREADS) emax[j] &= 255;
+}
+
+// Columns the route took off the int8 path no longer matter to the product -- but their digits would still cost it: a bulk 12
+// binades under its spikes puts a nonzero into plane 3 of every piece of its 32-row group, and the five-plane kernel then runs
+// that group's deep-plane blocks in every k-step of every tile of its row and column block (measured: +2 % on the whole launch
+// for four such columns, through the tiles' per-step barrier).  So their rows of the digit planes are zeroed and the piece masks
+// of their groups recomputed: one wave per (column, k-step), lane = (half, row) -- a piece is read as the product kernel reads
+// it, 1 KB per plane.  Enqueued with every call; every workgroup exits at once when no column left.
+__global__ __launch_bounds__(256) void i8_clear_columns_kernel(const RouteOut* route, const int* flag, const int* emax, signed char* planes,
+                                                               unsigned char* zmask, int n, int nk) {
+  if ((*flag & 2) || (int)blockIdx.x >= route->n_out) return;
+  const int j = route->out[blockIdx.x];
+  const int64_t groups = n / 32;
+  const int G = j >> 5, lane = threadIdx.x & 63, row = lane & 31;
+  const bool row_out = (emax[G * 32 + row] & EMAX_COLUMN_OUT) != 0;     // (every column of this group that left, not only j)
+  for (int kt = blockIdx.y * 4 + (threadIdx.x >> 6); kt < nk; kt += gridDim.y * 4) {
+    const unsigned old_mask = zmask[(int64_t)kt * groups + G];
+    unsigned new_mask = 0;
+#pragma unroll
+    for (int s = 0; s < NP; s++) {
+      // planes the split pass did not write here (all-zero pieces of planes 4, 5) are not touched: nothing reads them
+      if (s >= ALWAYS_WRITTEN_PLANES && (old_mask >> s) == 0) continue;
+      i32x4* p = (i32x4*)(planes + ((s * groups + G) * (int64_t)nk + kt) * 1024) + lane;
+      i32x4 v = *p;
+      if (row_out) {
+        v = (i32x4)0;
+        *p = v;
+      }
+      if (__ballot((v[0] | v[1] | v[2] | v[3]) != 0)) new_mask |= 1u << s;
+    }
+    if (lane == 0) zmask[(int64_t)kt * groups + G] = (unsigned char)new_mask;
+  }
 }
 
 template <int V> struct ic { static constexpr int value = V; };
@@ -1484,6 +1556,8 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
     // a flag per statistic: the launch takes the deepest route any statistic still on the int8 path asks for (launch_route)
     hipLaunchKernelGGL(i8_route_kernel, dim3(1), dim3(ROUTE_THREADS), 0, st, stats, emax, n, tau_x_of(n_tokens), (double*)((char*)ws + pw[i].vals), pflag + i,
                        (RouteOut*)((char*)ws + pw[i].route), route_counts);
+    hipLaunchKernelGGL(i8_clear_columns_kernel, dim3(ROUTE_JMAX, (unsigned)std::min(64, (nk + 3) / 4)), dim3(256), 0, st,
+                       (const RouteOut*)((char*)ws + pw[i].route), pflag + i, emax, planes, zmask, n, nk);
     MDG_LAUNCH_CHECK();
     a.prob[i] = SyrkProblem{planes, emax, zmask, q.sigma, q.ld_sigma, n, q.batch > 1 ? TI : 0};
     shapes.emplace_back(n / TI, q.batch > 1 ? TI : 0);

@@ -179,16 +179,7 @@ int syevj_batched(double* A, int64_t n, int64_t batch, double* evals, double* ev
   return MDG_OK;
 }
 
-int check_flag(int* dflag, hipStream_t st, const char* what) {
-  int flag = 0;
-  MDG_HIP(hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, st));
-  MDG_HIP(hipStreamSynchronize(st));
-  if (flag != 0) {
-    set_error("%s: Jacobi eigensolver did not converge in 40 sweeps", what);
-    return MDG_ERR_NO_CONVERGE;
-  }
-  return MDG_OK;
-}
+int check_flag(int* dflag, hipStream_t st, const char* what) { return finish_flag(dflag, st, STATUS_NO_CONVERGE, what); }
 
 
 // ---------------------------------------------------------------- large n: block Jacobi out of the pieces above

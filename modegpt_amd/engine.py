@@ -108,6 +108,7 @@ class TensorAdapter(ModelAdapter):
         self.config = config or CompressionConfig(**RECIPE_RIDGES)
         self.metrics = {}
         self.store: Dict[tuple, Dict[str, torch.Tensor]] = {}
+        self.pending_status = []
 
     @property
     def arch(self) -> str:
@@ -115,6 +116,16 @@ class TensorAdapter(ModelAdapter):
 
     def save_layer(self, output_dir, suffix, weights, layer_idx):
         self.store[(layer_idx, suffix)] = weights
+
+    def chain_status(self, status):
+        """Results stay on the device, so nothing here has to wait for the stream: the statuses of the layers' chains are
+        collected and read together by check_chains() (bench.py: after the last layer is enqueued)."""
+        self.pending_status.append(status)
+
+    def check_chains(self):
+        pending, self.pending_status = self.pending_status, []
+        for st in pending:
+            st.check()
 
     def get_transformer_blocks(self):
         raise NotImplementedError("TensorAdapter has no nn.Module blocks")
@@ -173,9 +184,11 @@ class TensorAdapter(ModelAdapter):
         raise NotImplementedError
 
 
-def compress_layer(adapter: TensorAdapter, layer_idx: int, covs: Dict[str, torch.Tensor], keep_ratio: float):
+def compress_layer(adapter: TensorAdapter, layer_idx: int, covs: Dict[str, torch.Tensor], keep_ratio: float, check: bool = True):
     """mlp -> qk -> vo for one layer through the drop-in functions (fixed order of run_modegpt.py:128-151).
-    Returns the layer's compressed tensors and rotary mask."""
+    Returns the layer's compressed tensors and rotary mask.  The chain enqueues without a host round trip; check=True reads
+    its status (not positive definite / eigensolver not converged -> exception) before returning, check=False leaves that to
+    a later adapter.check_chains() (bench.py: once, after the last layer)."""
     n = max(adapter.shape["n_layers"], layer_idx + 1)
     lst = lambda t: [t if i == layer_idx else None for i in range(n)]  # noqa: E731
     keep = [keep_ratio] * n
@@ -183,6 +196,8 @@ def compress_layer(adapter: TensorAdapter, layer_idx: int, covs: Dict[str, torch
     masks = compress_qk(adapter=adapter, cov=(lst(covs["q"]), lst(covs["k"])), keep_ratios=keep,
                         target_layers=[layer_idx])
     compress_vo(adapter=adapter, cov=lst(covs["x"]), keep_ratios=keep, target_layers=[layer_idx])
+    if check:
+        adapter.check_chains()
     out = {}
     for suffix in ("mlp", "qk", "vo"):
         out.update(adapter.store[(layer_idx, suffix)])

@@ -48,6 +48,36 @@ def _as_weight(W: torch.Tensor) -> torch.Tensor:
     return W if W.stride(-1) == 1 else W.contiguous()
 
 
+# ------------------------------------------------------------------ deferred status of a decomposition chain
+class DeferredStatus:
+    """`with ops.DeferredStatus(device) as st: <ridge_scores / nystrom_down / vo_compress / potrf_lower ...>` -- inside the block
+    the decomposition entry points do not wait for the host to read their status word (Cholesky pivot, Jacobi convergence):
+    they merge it into a device-side int[2] and return at once (mdg_deferred_status_begin / _end).  `st.check()` -- any time
+    later -- copies the two ints to the host (the one synchronisation of the chain) and raises what the synchronising call
+    would have raised: torch.linalg.LinAlgError for a matrix that is not positive definite, RuntimeError otherwise."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.status = torch.empty(2, dtype=torch.int32, device=self.device)
+        self.checked = False
+
+    def __enter__(self):
+        with torch.cuda.device(self.device):
+            check(_lib.load().mdg_deferred_status_begin(self.status.data_ptr(), _stream(self.status)), "mdg_deferred_status_begin")
+        return self
+
+    def __exit__(self, *exc):
+        _lib.load().mdg_deferred_status_end()
+        return False
+
+    def check(self) -> None:
+        if self.checked:
+            return
+        self.checked = True
+        host = (C.c_int * 2)(*self.status.cpu().tolist())
+        check(_lib.load().mdg_deferred_status_decode(host), "decomposition chain")
+
+
 # ------------------------------------------------------------------ covariance
 def cov_accum(sigma: torch.Tensor, x: torch.Tensor, n_heads: int = 1, relu: bool = False) -> None:
     """sigma (lower triangle) += X^T X in fp64.  x: [..., n_heads*feat] (bf16/f16/f32/f64, last dim

@@ -27,7 +27,8 @@ imports it relatively), the way the reference ships its self-contained modeling 
 depends on torch and transformers only.  The fused HIP kernel is used when the modegpt_amd package is importable and the
 tensors live on a GPU; anywhere else (another machine, a CPU) the same chain runs as plain torch ops, the reference's own
 expression op for op -- the checkpoint loads and evaluates wherever the reference's would.  Which path ran is counted in
-PATH_CALLS; MODEGPT_REQUIRE_HIP=1 turns the torch path into an error.
+PATH_CALLS; MODEGPT_REQUIRE_HIP=1 turns the torch path into an error, and a GPU tensor without an importable engine is an
+error by itself unless MODEGPT_ALLOW_TORCH=1 (CPU tensors always take the portable path).
 
 Inference only: the kernel has no backward.
 """
@@ -97,6 +98,13 @@ def _rope_gather(x, cos, sin, mask, n_heads, n_kv, head_dim, norm_weight=None, e
     if os.environ.get("MODEGPT_REQUIRE_HIP", "0") == "1":
         raise RuntimeError("compressed attention: MODEGPT_REQUIRE_HIP=1 but the HIP kernel cannot serve this call "
                            f"(tensor on {x.device}, modegpt_amd importable: {_hip_ops() is not None})")
+    if x.is_cuda and os.environ.get("MODEGPT_ALLOW_TORCH", "0") != "1":
+        # a GPU tensor and no engine: on a GPU box that is a broken installation, not portability -- say so instead of quietly
+        # running ten eager passes per layer.  A checkpoint taken to a machine without the engine sets MODEGPT_ALLOW_TORCH=1
+        # (CPU tensors always take the portable path).
+        raise RuntimeError("compressed attention: the tensors are on a GPU but modegpt_amd (libmodegpt_hip.so) cannot be imported "
+                           "in this process, so mdg_rope_gather is unavailable.  Install / build the engine, or set "
+                           "MODEGPT_ALLOW_TORCH=1 to run the reference's torch expression on the GPU instead.")
     PATH_CALLS["torch"] += 1
     return _rope_gather_torch(x, cos.to(x.dtype), sin.to(x.dtype), mask, n_heads, n_kv,
                               None if norm_weight is None else norm_weight.detach().to(x.dtype), eps)

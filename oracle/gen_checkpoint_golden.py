@@ -117,6 +117,10 @@ def transformers_4x_names():
             del mru.ROPE_INIT_FUNCTIONS["default"]
 
 
+class _OptDone(Exception):
+    """(control flow: the OPT branch has produced its logits inside the load context)"""
+
+
 def forward_logits(model, ids):
     with torch.no_grad():
         return model(input_ids=ids).logits.float()
@@ -138,6 +142,86 @@ def forward_through_layers(model, ids):
             out = layer(h, attention_mask=mask, position_ids=pos, position_embeddings=cos_sin)
             h = out[0] if isinstance(out, tuple) else out
         return model.lm_head(core.norm(h)).float()
+
+
+def opt_reference_logits(cls, rconf, refdir, ids, state):
+    """The reference's OPT modules driven on this writer's checkpoint.  OPTRebuild.OPTForCausalLM does not construct under
+    transformers 5 (its `_tied_weights_keys` is a 4.x-style list), so -- as for Llama / Qwen3 around their model-level forward --
+    the part that carries the compressed semantics is driven directly: the reference's OPTModel (OPTRebuild.py:371, 745) is
+    constructed from our config (per-layer qk_ranks / vo_ranks / gate_ranks), filled with our tensors, and its modules run in the
+    order its own OPTDecoder.forward runs them (OPTRebuild.py:560-760): embed_tokens + embed_positions(attention_mask, 0,
+    position_ids), every OPTDecoderLayer with an explicit additive causal mask, final_layer_norm; the tied lm_head of
+    OPTForCausalLM (OPTRebuild.py:809-813, 905) is the product with embed_tokens.weight.  The checkpoint carries no bias for
+    the six compressed Linears of a layer (model_adapter.py:199-208 rebuilds them bias-free) while OPTRebuild creates them with
+    config.enable_bias: those 6 x n_layers keys are the only ones missing, and they are zeroed -- what the reference's own
+    from_pretrained does with them (OPTPreTrainedModel._init_weights, OPTRebuild.py:356-361)."""
+    import sys
+
+    from safetensors.torch import load_file
+    mod = sys.modules[cls.__module__]
+    with torch.device("meta"):
+        ref = mod.OPTModel(rconf)
+    ref = ref.to_empty(device="cpu").to(torch.bfloat16).eval()
+    sd = {}
+    for f in os.listdir(refdir):
+        if f.endswith(".safetensors"):
+            sd.update(load_file(os.path.join(refdir, f)))
+        elif f.endswith(".bin"):
+            sd.update(torch.load(os.path.join(refdir, f), map_location="cpu"))
+    sub = {k[len("model."):]: v for k, v in sd.items() if k.startswith("model.")}
+    res = ref.load_state_dict(sub, strict=False)
+    compressed = ("self_attn.q_proj.bias", "self_attn.k_proj.bias", "self_attn.v_proj.bias", "self_attn.out_proj.bias", "fc1.bias", "fc2.bias")
+    assert not res.unexpected_keys, res.unexpected_keys[:4]
+    assert all(k.endswith(compressed) for k in res.missing_keys) and len(res.missing_keys) == 6 * rconf.num_hidden_layers, res.missing_keys[:8]
+    own = dict(ref.named_parameters())
+    for k in res.missing_keys:
+        own[k].data.zero_()
+    rs = ref.state_dict()
+    for k, v in state.items():                     # every tensor of our checkpoint sits in the reference's module, bit for bit
+        kk = k[len("model."):] if k.startswith("model.") else None
+        if kk is not None:
+            assert rs[kk].shape == v.shape and torch.equal(rs[kk], v), k
+    ref.config._attn_implementation = "eager"
+    dec = ref.decoder
+    with torch.no_grad():
+        B, T = ids.shape
+        am = torch.ones(B, T, dtype=torch.long)
+        pos = (torch.cumsum(am, dim=1) * am - 1).long()
+        h = dec.embed_tokens(ids)
+        if dec.project_in is not None:
+            h = dec.project_in(h)
+        h = h + dec.embed_positions(am, 0, position_ids=pos)
+        mask = torch.full((T, T), torch.finfo(h.dtype).min, dtype=h.dtype).triu(1)[None, None]
+        for layer in dec.layers:
+            out = layer(h, attention_mask=mask)
+            h = out[0] if isinstance(out, tuple) else out
+        if dec.final_layer_norm is not None:
+            h = dec.final_layer_norm(h)
+        if dec.project_out is not None:
+            h = dec.project_out(h)
+        return torch.nn.functional.linear(h, dec.embed_tokens.weight).float(), ref
+
+
+def opt_drive_own(model, ids):
+    """The same drive through THIS engine's shipped modeling file (stock OPT modules with the compressed forward installed)."""
+    dec = model.model.decoder
+    with torch.no_grad():
+        B, T = ids.shape
+        am = torch.ones(B, T, dtype=torch.long)
+        pos = (torch.cumsum(am, dim=1) * am - 1).long()
+        h = dec.embed_tokens(ids)
+        if dec.project_in is not None:
+            h = dec.project_in(h)
+        h = h + dec.embed_positions(am, 0, position_ids=pos)
+        mask = torch.full((T, T), torch.finfo(h.dtype).min, dtype=h.dtype).triu(1)[None, None]
+        for layer in dec.layers:
+            out = layer(h, attention_mask=mask)
+            h = out[0] if isinstance(out, tuple) else out
+        if dec.final_layer_norm is not None:
+            h = dec.final_layer_norm(h)
+        if dec.project_out is not None:
+            h = dec.project_out(h)
+        return model.lm_head(h).float()
 
 
 def main():
@@ -185,6 +269,18 @@ def main():
                     from transformers.dynamic_module_utils import get_class_from_dynamic_module
                     rconf = transformers.AutoConfig.from_pretrained(refdir, trust_remote_code=True)
                     cls = get_class_from_dynamic_module(rconf.auto_map["AutoModelForCausalLM"], refdir)
+                    if kind == "opt":
+                        mine.config._attn_implementation = "eager"
+                        logits_ref, ref = opt_reference_logits(cls, rconf, refdir, ids, state)
+                        logits_mine_layers = opt_drive_own(mine, ids)
+                        shims = list(shims) + ["OPTForCausalLM does not construct under transformers 5: the reference's OPTModel is "
+                                               "constructed, filled and driven module by module; the 6 bias keys per layer the "
+                                               "checkpoint lacks are zeroed as the reference's _init_weights does"]
+                        d2 = (logits_mine_layers - logits_mine).abs().max().item()
+                        d3 = (logits_mine_layers - logits_ref).abs().max().item()
+                        print(f"[opt] this engine's model: module-by-module drive (eager attention) vs its model-level forward (sdpa): "
+                              f"max |diff| = {d2:.3e};  module-by-module drive, this engine's modules vs the reference's: {d3:.3e}")
+                        raise _OptDone()
                     # built on the meta device (transformers 5 runs no weight initialisers there -- its initialiser for
                     # rotary modules calls a 5.x-only method), materialised empty, filled from the checkpoint; the rotary
                     # module, whose inv_freq is a computed non-persistent buffer, is constructed again on the CPU
@@ -223,6 +319,8 @@ def main():
                     d3 = (logits_mine_layers - logits_ref).abs().max().item()
                     print(f"[{kind}] this engine's model: layer-by-layer drive (eager attention) vs its model-level forward (sdpa): "
                           f"max |diff| = {d2:.3e};  layer-by-layer drive, this engine's modules vs the reference's: {d3:.3e}")
+            except _OptDone:
+                pass
             except Exception as exc:  # recorded, not hidden: the fixture says what the reference's file did with the checkpoint
                 import traceback
                 traceback.print_exc()
@@ -244,7 +342,7 @@ def main():
         if logits_ref is not None:
             fx["logits_reference"] = logits_ref.numpy()
         fx["logits_engine_torch_path"] = logits_mine.numpy()          # model-level forward (sdpa), this engine's modeling file, CPU
-        if kind != "opt":
+        if logits_mine_layers is not None:
             fx["logits_engine_layers"] = logits_mine_layers.numpy()  # layer-by-layer drive (eager attention), same file
         np.savez_compressed(os.path.join(a.out, f"ckpt_{kind}.npz"), **fx)
 

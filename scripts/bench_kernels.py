@@ -161,3 +161,23 @@ if "covi8p6" in which:
     t8 = timeit(lambda: ops.cov_accum_i8(S8, H), n=3)
     t64 = timeit(lambda: ops.cov_accum(S64, H), n=3)
     print(f"cov mlp {T}x{d_ff} (SiLU-gated): int8 digit planes {t8*1e3:.1f} ms   fp64 MFMA {t64*1e3:.1f} ms")
+if "covi8massive" in which:
+    # four BOS-like columns (bulk 12-15 binades under three spikes) in sigma_mlp- and sigma_x-sized statistics: the route hands
+    # them to the fp64 column kernel; whole-call time against the clean batch, and the route the device reports
+    def massive(X, cols):
+        X = X.clone()
+        for i, c in enumerate(cols):
+            top = X[:, c].float().abs().max()
+            X[:, c] = (X[:, c].float() * 2.0 ** -(12 + i)).to(torch.bfloat16)
+            X[torch.randperm(X.shape[0], device=dev, generator=g)[:3], c] = (top * 1.5).to(torch.bfloat16)
+        return X
+    for n_, name in ((d_ff, "mlp"), (d, "x")):
+        H = acts(T, n_); Hm = massive(H, [5, 129, n_ // 2 + 77, n_ - 1])
+        S8 = torch.zeros(n_, n_, dtype=F64, device=dev)
+        info, info_m = {}, {}
+        ops.cov_accum_i8(S8, H, route_info=info); ops.cov_accum_i8(S8, Hm, route_info=info_m)
+        t0 = timeit(lambda: ops.cov_accum_i8(S8, H, report=False), n=5, warm=2)
+        t1 = timeit(lambda: ops.cov_accum_i8(S8, Hm, report=False), n=5, warm=2)
+        t0b = timeit(lambda: ops.cov_accum_i8(S8, H, report=False), n=5, warm=2)
+        print(f"cov {name} {T}x{n_}: clean {t0*1e3:.3f} / {t0b*1e3:.3f} ms (planes {info['planes']}, bound {info['bound']:.2e});  4 massive columns "
+              f"{t1*1e3:.3f} ms (+{100 * (t1 / min(t0, t0b) - 1):.1f} %), planes {info_m['planes']}, columns {info_m['columns']}, bound {info_m['bound']:.2e}")

@@ -88,3 +88,36 @@ if "gemm" in which:
         t = timeit(lambda: ops.gemm(a, b, c, alpha=-1.0, beta=1.0, flags=flags), n=5, warm=2)
         fl = 2.0 * M * N * K * (0.5 if flags & _lib.MDG_GEMM_LOWER_ONLY else 1.0)
         print(f"gemm {M}x{N}x{K} {what}: {t*1e6:.0f} us  {fl/t/1e12:.1f} TF")
+if "async" in which:
+    # one layer's whole compress_nystrom + compress_qk + compress_vo chain in deferred-status mode.  The host
+    # must come back long before the device is done (no synchronisation inside the layer), and a not-positive-definite
+    # input must still surface as LinAlgError -- when the status is read.
+    import time
+    from modegpt_amd import engine
+    shape = engine.SHAPES["llama-3-8b"]
+    w = engine.make_layer_weights(shape, 1234, dev)
+    batch = engine.make_activation_batch(shape, 8192, seed=5, device=dev)
+    covs = engine.new_covs(shape, dev)
+    engine.accumulate(covs, batch, shape)
+    engine.finalize(covs, 4)
+    ad = engine.TensorAdapter(shape, {0: w})
+    engine.compress_layer(ad, 0, covs, 0.7)                     # warm-up (checked)
+    for mode in ("deferred", "checked"):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter(); e0.record()
+        engine.compress_layer(ad, 0, covs, 0.7, check=(mode == "checked"))
+        e1.record(); t_host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        ad.check_chains()
+        print(f"layer chain, {mode}: host back after {t_host*1e3:.1f} ms, device busy {e0.elapsed_time(e1):.1f} ms "
+              f"({'no host synchronisation inside the layer' if t_host * 1e3 < 0.5 * e0.elapsed_time(e1) else 'the host waited'})")
+    bad = {k: v.clone() for k, v in covs.items()}
+    bad["mlp"][7, 7] = -1.0
+    try:
+        engine.compress_layer(ad, 0, bad, 0.7, check=False)
+        print("not-PD sigma_mlp: the chain enqueued without raising (deferred) ...")
+        ad.check_chains()
+        print("... and check_chains() did NOT raise: BUG")
+    except torch.linalg.LinAlgError as e:
+        print("... check_chains() raised LinAlgError:", str(e)[:110])

@@ -127,3 +127,29 @@ def layer_drive(model, ids):
         return model.lm_head(core.norm(h)).float()
 '''
 exec(LAYER_DRIVE)
+
+OPT_DRIVE = '''
+def opt_drive(model, ids):
+    """OPT: the decoder's own modules in the order OPTDecoder.forward runs them, explicit additive causal mask, tied lm_head
+    (what ckpt_opt.npz's reference logits were produced with: oracle/gen_checkpoint_golden.py opt_reference_logits)."""
+    import torch
+    dec = model.model.decoder
+    with torch.no_grad():
+        B, T = ids.shape
+        am = torch.ones(B, T, dtype=torch.long, device=ids.device)
+        pos = (torch.cumsum(am, dim=1) * am - 1).long()
+        h = dec.embed_tokens(ids)
+        if dec.project_in is not None:
+            h = dec.project_in(h)
+        h = h + dec.embed_positions(am, 0, position_ids=pos)
+        mask = torch.full((T, T), torch.finfo(h.dtype).min, dtype=h.dtype, device=ids.device).triu(1)[None, None]
+        for layer in dec.layers:
+            out = layer(h, attention_mask=mask)
+            h = out[0] if isinstance(out, tuple) else out
+        if dec.final_layer_norm is not None:
+            h = dec.final_layer_norm(h)
+        if dec.project_out is not None:
+            h = dec.project_out(h)
+        return model.lm_head(h).float()
+'''
+exec(OPT_DRIVE)

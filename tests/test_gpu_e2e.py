@@ -757,3 +757,22 @@ def test_fixture_checkpoint_through_the_hip_kernel_matches_the_reference_modelin
     assert mod.PATH_CALLS["hip"] >= 2 * m.config.num_hidden_layers and mod.PATH_CALLS["torch"] == 0, mod.PATH_CALLS
     want = z["logits_reference"]
     assert np.abs(got - want).max() <= 3e-2 * np.abs(want).max(), float(np.abs(got - want).max())
+
+
+def test_opt_fixture_checkpoint_on_the_gpu_matches_the_reference_modeling(dev, tmp_path, monkeypatch):
+    """tests/golden/ckpt_opt.npz: this writer's compressed OPT checkpoint, whose `logits_reference` came out of the REFERENCE's
+    OPTRebuild modules (OPTModel constructed from our config ranks, filled with our tensors, driven module by module:
+    oracle/gen_checkpoint_golden.py opt_reference_logits).  Loaded through the shipped modeling file on the GPU and driven the
+    same way, the logits agree within bf16 GEMM noise (OPT has no rotary chain: per-layer q/k and v/o head widths and the
+    q pre-scale by the compressed width are what is being pinned, OPTRebuild.py:126-163)."""
+    transformers = pytest.importorskip("transformers")
+    from tests.golden_util import materialise_checkpoint, opt_drive
+    monkeypatch.setenv("HF_MODULES_CACHE", str(tmp_path / "hf_modules"))
+    monkeypatch.setenv("MODEGPT_REQUIRE_HIP", "1")
+    out, ids, z = materialise_checkpoint("opt", str(tmp_path / "model"))
+    assert str(z["meta_status"]) == "loaded"
+    m = transformers.AutoModelForCausalLM.from_pretrained(out, trust_remote_code=True, dtype=torch.bfloat16).to(dev).eval()
+    m.config._attn_implementation = "eager"
+    got = opt_drive(m, ids.to(dev)).cpu().numpy()
+    want = z["logits_reference"]
+    assert np.abs(got - want).max() <= 3e-2 * np.abs(want).max(), float(np.abs(got - want).max())

@@ -190,6 +190,35 @@ def test_potrf_not_pd(ops, dev):
         ops.potrf_lower(A.to(dev))
 
 
+def test_deferred_status_reports_what_the_synchronising_call_would_have_raised(ops, dev):
+    """ops.DeferredStatus: inside the block the decomposition entry points enqueue and return (no host round trip for the
+    Cholesky pivot / Jacobi flag); check() afterwards raises LinAlgError with the pivot of the FIRST failure, good chains pass,
+    and outside the block the calls raise at once as before."""
+    good = torch.eye(300, dtype=F64, device=dev) * 2.0
+    bad = torch.eye(200, dtype=F64)
+    bad[150, 150] = -1.0
+    bad2 = torch.eye(200, dtype=F64)
+    bad2[20, 20] = -3.0
+    with ops.DeferredStatus(dev) as st:
+        ops.potrf_lower(good.clone())
+        ops.ridge_scores(good, 1e-4)
+    st.check()
+    st.check()                                        # idempotent
+    with ops.DeferredStatus(dev) as st:
+        ops.potrf_lower(good.clone())
+        ops.potrf_lower(bad.to(dev))                  # does not raise here
+        ops.potrf_lower(bad2.to(dev))
+    with pytest.raises(torch.linalg.LinAlgError, match="order 151"):
+        st.check()
+    with pytest.raises(torch.linalg.LinAlgError):     # deferred mode has ended with the block
+        ops.potrf_lower(bad.to(dev))
+    with pytest.raises(RuntimeError, match="already in deferred mode"):
+        with ops.DeferredStatus(dev):
+            with ops.DeferredStatus(dev):
+                pass
+    ops.potrf_lower(good.clone())                     # and the thread is back in the normal mode
+
+
 @pytest.mark.parametrize("n", [64, 160, 384, 704, 1100])
 def test_ridge_scores(ops, dev, n):
     gen = torch.Generator().manual_seed(n + 1)
