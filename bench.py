@@ -302,10 +302,12 @@ def parse_args(argv=None):
     ap.add_argument("--batch_size", type=int, default=16, help="samples of 2048 tokens per batch")
     ap.add_argument("--keep", type=float, default=0.7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pipeline", action="store_true",
-                    help="run layer L's decomposition chain on a high-priority side stream beside layer L + 1's covariance kernels "
-                         "(default: one after the other, which keeps the per-kernel figures clean; measured gain 1.8 %%, reported as "
-                         "value_pipelined)")
+    ap.add_argument("--pipeline", dest="pipeline", action="store_true", default=True,
+                    help="(default) layer L's decomposition chain runs on a side stream beside layer L + 1's covariance kernels: "
+                         "the chain enqueues without a host round trip (deferred status), so its kernels fill what the covariance "
+                         "launches leave idle; +3 %% on the step (A/B/A/B on one box, DESIGN.md section 7)")
+    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
+                    help="one after the other on one stream: per-kernel figures without interference (reported as value_sequential)")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip value_f64_route / value_gated (the same step loop on the fp64 route and on SiLU-gated data)")
     ap.add_argument("--cov-mode", default=None, choices=["f64", "i8"],
@@ -477,7 +479,9 @@ def main():
     dec_tf = dec_flops / (dec_ms * 1e-3) / 1e12 if n_dec else None
     decomposition = None if not n_dec else {
         "bound": "mfma", "achieved": dec_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dec_tf / FP64_MFMA_PEAK_TFLOPS,
-        "avg_ms_per_layer": dec_ms / n_dec, "flop_per_layer": dec_flops / n_dec, "share_of_step": dec_ms / n_dec / (elapsed / a.steps * 1e3)}
+        "avg_ms_per_layer": dec_ms / n_dec, "flop_per_layer": dec_flops / n_dec,
+        "timed": "on the side stream beside the next layer's covariance (waits for CUs included); alone: value_sequential.decomposition"
+                 if pipelined else "alone on the caller's stream"}
     # The JSON line carries numbers and short labels only; what each field means is written down in DESIGN.md section 7
     # ("The bench line, field by field").
     out = {
@@ -576,11 +580,18 @@ def main():
             out["i8_vs_f64_outputs"] = compare_outputs(headline_out, outs64, n_texts * 2048)
             del outs64
             ops.COV_MODE = "i8"
-            # (1b) the default route with layer L's decomposition beside layer L + 1's covariance (bench.py Pipeline)
-            if not pipelined:
+            # (1b) the same steps one after the other on one stream: the per-kernel figures without the two streams' interference
+            if pipelined:
                 tp = LaunchTimer()
-                sec, _ = timed_steps(shape, adapter, ids, batches, a.keep, n_texts, tp, True)
-                out["value_pipelined"] = {"value": len(ids) / sec, "ms_per_step": sec / len(ids) * 1e3}
+                sec, _ = timed_steps(shape, adapter, ids, batches, a.keep, n_texts, tp, False)
+                tp.price_i8(planes_per_batch)
+                nl_s, fl_s, ms_s = tp.summary()
+                n_d, d_fl, d_ms = tp.decomposition_summary()
+                out["value_sequential"] = {"value": len(ids) / sec, "ms_per_step": sec / len(ids) * 1e3,
+                                           "sigma_mlp_launch_ms": ms_s / nl_s,
+                                           "sigma_mlp_frac": fl_s / (ms_s * 1e-3) / 1e12 * executed_fraction / INT8_MFMA_PEAK_TOPS,
+                                           "decomposition": {"avg_ms_per_layer": d_ms / n_d, "achieved": d_fl / (d_ms * 1e-3) / 1e12,
+                                                             "frac": d_fl / (d_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS}}
             # (2) SiLU-gated sigma_mlp activations, what a real Llama MLP feeds the hook (LlamaAdapter.py:127-136): six planes
             gated = []
             for b, bt in enumerate(batches):

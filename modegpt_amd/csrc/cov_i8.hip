@@ -399,17 +399,29 @@ __device__ __forceinline__ void top2_merge(Top2& a, const Top2& b) {   // (lowes
   }
 }
 
+// Scratch of the multi-workgroup first pass, per workgroup: the top two of its columns and the maxima of the 64 column classes.
+struct RoutePartial {
+  Top2 top[NVAL];
+  unsigned long long cls[NVAL][64];
+};
+struct RouteScratch {            // zeroed with the statistics before every call
+  int ticket, forced;
+};
+
+// Grid: one workgroup per ROUTE_THREADS columns.  Every workgroup turns its columns' integers into alpha_s / rho (kept in `vals`
+// for the greedy) and leaves its partial maxima in `partial`; the LAST one to finish (ticket) merges them and decides -- so the
+// ~10 fp64 square roots per column are spread over the chip and the common case (nothing has to leave) ends there.
 __global__ __launch_bounds__(ROUTE_THREADS) void i8_route_kernel(const unsigned long long* __restrict__ stats, int* emax, int n, double tau_x,
-                                                                 double* __restrict__ vals, int* flag, RouteOut* out, int* route_counts) {
+                                                                 double* __restrict__ vals, RoutePartial* partial, RouteScratch* scratch,
+                                                                 int* flag, RouteOut* out, int* route_counts) {
   __shared__ unsigned long long group_max[NVAL][64];   // per quantity: maxima of the 64 column classes j % 64 (bit patterns of doubles >= 0)
   __shared__ Top2 wave_top[ROUTE_THREADS / 64][NVAL];
   __shared__ Top2 top[NVAL];
   __shared__ double floor_of[NVAL];
   __shared__ int decision;   // -1: keep going; 0: accepted; 1: this P cannot be reached
-  __shared__ int forced_total;
+  __shared__ int forced_total, my_ticket;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < NVAL * 64; i += ROUTE_THREADS) (&group_max[0][0])[i] = 0ull;
-  if (tid == 0) forced_total = 0;
   __syncthreads();
   // top two of every quantity over the columns still on the int8 path: block reduction of per-thread results into top[]
   auto reduce_top = [&](Top2 (&t)[NVAL]) {
@@ -429,64 +441,71 @@ __global__ __launch_bounds__(ROUTE_THREADS) void i8_route_kernel(const unsigned 
     if (tid < NVAL) {
       Top2 r = wave_top[0][tid];
       for (int w = 1; w < ROUTE_THREADS / 64; w++) top2_merge(r, wave_top[w][tid]);
-      r.m1 = fmax(r.m1, 0.0);
-      r.m2 = fmax(r.m2, 0.0);
       top[tid] = r;
     }
     __syncthreads();
   };
-  // pass 1: alpha_s(j), rho_j from the integers (kept in `vals` for the greedy), the top two and the class maxima of every
-  // quantity; columns with an Inf / NaN (emax 255) leave at once
-  int forced = 0;
+  // pass 1 (every workgroup): alpha_s(j), rho_j of its column from the integers; columns with an Inf / NaN (emax 255) leave at once
   Top2 t[NVAL];
 #pragma unroll
   for (int i = 0; i < NVAL; i++) t[i] = Top2{-1.0, 0x7fffffff, -1.0};
-  // (the integers of all of a thread's columns are requested before anything is computed: one memory round trip, not one per column)
-  constexpr int PASS1_COLS = 4;
-  for (int j0 = tid; j0 < n; j0 += ROUTE_THREADS * PASS1_COLS) {
-    unsigned long long raw[PASS1_COLS][NSTAT];
-    int ex[PASS1_COLS];
+  {
+    const int j = blockIdx.x * ROUTE_THREADS + tid;
+    bool nonfinite = false;
+    if (j < n) {
+      double q[NSTAT];
 #pragma unroll
-    for (int c = 0; c < PASS1_COLS; c++) {
-      const int j = j0 + c * ROUTE_THREADS;
+      for (int i = 0; i < NSTAT - 1; i++) q[i] = i == STAT_D0D1 ? (double)(long long)stats[(int64_t)i * n + j] : (double)stats[(int64_t)i * n + j];
+      const unsigned long long counts = stats[(int64_t)STAT_COUNTS * n + j];
+      const int ex = emax[j];
+      const double nnz = (double)(unsigned)counts, rounded = (double)(unsigned)(counts >> 32);
+      const double hi2 = 65536.0 * q[0] + 512.0 * q[STAT_D0D1] + q[1];
+      const double norm = (sqrt(fmax(hi2, 0.0)) - 0.5 * sqrt(nnz)) * 4294967296.0;
+      // (norm <= 0 can only happen for a column of denormals, which has nothing below plane 1; 1e300 keeps the test conservative)
+      const double inv = nnz > 0 ? (norm > 0 ? 1.0 / norm : 1e300) : 0.0;
+      double a[NVAL];
 #pragma unroll
-      for (int i = 0; i < NSTAT; i++) raw[c][i] = j < n ? stats[(int64_t)i * n + j] : 0ull;
-      ex[c] = j < n ? emax[j] : 0;
+      for (int s2 = 0; s2 < NP; s2++) a[s2] = q[s2] > 0 ? sqrt(q[s2]) * ldexp(1.0, 8 * (NP - 1 - s2)) * inv : 0.0;
+      a[6] = rounded > 0 ? 0.5 * sqrt(rounded) * inv : 0.0;
+      nonfinite = (ex & 255) == 255;
+#pragma unroll
+      for (int i = 0; i < NVAL; i++) {
+        vals[(int64_t)i * n + j] = a[i];
+        if (!nonfinite) t[i] = Top2{a[i], j, -1.0};
+      }
+      if (nonfinite) emax[j] = ex | EMAX_COLUMN_OUT;
     }
 #pragma unroll
-    for (int c = 0; c < PASS1_COLS; c++) {
-    const int j = j0 + c * ROUTE_THREADS;
-    if (j >= n) break;
-    double q[NSTAT];
-#pragma unroll
-    for (int i = 0; i < NSTAT - 1; i++) q[i] = i == STAT_D0D1 ? (double)(long long)raw[c][i] : (double)raw[c][i];
-    const unsigned long long counts = raw[c][STAT_COUNTS];
-    const double nnz = (double)(unsigned)counts, rounded = (double)(unsigned)(counts >> 32);
-    const double hi2 = 65536.0 * q[0] + 512.0 * q[STAT_D0D1] + q[1];
-    const double norm = (sqrt(fmax(hi2, 0.0)) - 0.5 * sqrt(nnz)) * 4294967296.0;
-    // (norm <= 0 can only happen for a column of denormals, which has nothing below plane 1; 1e300 keeps the test conservative)
-    const double inv = nnz > 0 ? (norm > 0 ? 1.0 / norm : 1e300) : 0.0;
-    double a[NVAL];
-#pragma unroll
-    for (int s = 0; s < NP; s++) a[s] = q[s] > 0 ? sqrt(q[s]) * ldexp(1.0, 8 * (NP - 1 - s)) * inv : 0.0;
-    a[6] = rounded > 0 ? 0.5 * sqrt(rounded) * inv : 0.0;
-    const bool nonfinite = (ex[c] & 255) == 255;
-#pragma unroll
-    for (int i = 0; i < NVAL; i++) {
-      vals[(int64_t)i * n + j] = a[i];
-      if (!nonfinite) top2_merge(t[i], Top2{a[i], j, -1.0});
-    }
-    if (nonfinite) {
-      emax[j] = ex[c] | EMAX_COLUMN_OUT;
-      forced++;
-    }
-    }
+    for (int i = 0; i < NVAL; i++)
+      if (t[i].m1 > 0.0) atomicMax(&group_max[i][lane], (unsigned long long)__double_as_longlong(t[i].m1));   // (column j is in class j % 64 = lane)
+    const unsigned long long nf = __ballot(nonfinite);
+    if (lane == 0 && nf) atomicAdd(&scratch->forced, __popcll(nf));
   }
-#pragma unroll
-  for (int i = 0; i < NVAL; i++)
-    if (t[i].m1 > 0.0) atomicMax(&group_max[i][lane], (unsigned long long)__double_as_longlong(t[i].m1));   // (thread tid's columns are all = lane mod 64)
-  if (forced) atomicAdd(&forced_total, forced);
   reduce_top(t);
+  // hand the partial results over; the last workgroup to arrive goes on
+  RoutePartial& mine = partial[blockIdx.x];
+  if (tid < NVAL) mine.top[tid] = top[tid];
+  for (int i = tid; i < NVAL * 64; i += ROUTE_THREADS) (&mine.cls[0][0])[i] = (&group_max[0][0])[i];
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) my_ticket = atomicAdd(&scratch->ticket, 1);
+  __syncthreads();
+  if (my_ticket != (int)gridDim.x - 1) return;
+  __threadfence();
+  if (tid < NVAL) {
+    Top2 r = partial[0].top[tid];
+    for (unsigned w = 1; w < gridDim.x; w++) top2_merge(r, partial[w].top[tid]);
+    r.m1 = fmax(r.m1, 0.0);
+    r.m2 = fmax(r.m2, 0.0);
+    top[tid] = r;
+  }
+  for (int i = tid; i < NVAL * 64; i += ROUTE_THREADS) {
+    unsigned long long m = 0ull;
+    for (unsigned w = 0; w < gridDim.x; w++) m = max(m, (&partial[w].cls[0][0])[i]);
+    (&group_max[0][0])[i] = m;
+  }
+  if (tid == 0) forced_total = scratch->forced;
+  __syncthreads();
   int n_out = 0;
   if (forced_total > ROUTE_JMAX) {      // too many: the whole statistic goes through the fp64 kernel
     if (tid == 0) {
@@ -531,6 +550,7 @@ __global__ __launch_bounds__(ROUTE_THREADS) void i8_route_kernel(const unsigned 
         top_valid = true;
 #pragma unroll
         for (int i = 0; i < NVAL; i++) t[i] = Top2{-1.0, 0x7fffffff, -1.0};
+        constexpr int PASS1_COLS = 4;     // (four columns' loads in flight per thread)
         for (int j0 = tid; j0 < n; j0 += ROUTE_THREADS * PASS1_COLS) {
           double v[PASS1_COLS][NVAL];
           int ex[PASS1_COLS];
@@ -553,7 +573,11 @@ __global__ __launch_bounds__(ROUTE_THREADS) void i8_route_kernel(const unsigned 
       if (tid == 0) {
         double A[NVAL];
 #pragma unroll
-        for (int i = 0; i < NVAL; i++) A[i] = top[i].m1;
+        for (int i = 0; i < NVAL; i++) {
+          top[i].m1 = fmax(top[i].m1, 0.0);
+          top[i].m2 = fmax(top[i].m2, 0.0);
+          A[i] = top[i].m1;
+        }
         decision = -1;
         if (route_violation(A, P, tau_x) <= 1.0) {
           out->planes = P;
@@ -1304,6 +1328,8 @@ __global__ __launch_bounds__(256) void i8_columns_reduce_kernel(ColArgs a, const
   sigma[(int64_t)row * ld_sigma + col - (block ? row / block * block : 0)] += v;
 }
 
+// column maxima (n ints, padded to 8 bytes) + the [NSTAT][n] route statistics + the route kernel's ticket: zeroed together per call
+size_t ints_bytes(int64_t n) { return (size_t)((n + 1) / 2 * 2) * sizeof(int) + (size_t)(NSTAT * n) * sizeof(unsigned long long) + sizeof(RouteScratch); }
 size_t planes_bytes(int64_t T, int64_t n) { return (size_t)NP * (size_t)n * (size_t)ceil_div(T, KS) * KS; }
 size_t zmask_bytes(int64_t T, int64_t n) { return align_up((size_t)ceil_div(T, KS) * (size_t)(n / 32), 256); }
 
@@ -1450,9 +1476,9 @@ size_t layout(int count, const mdg_cov_problem* pr, ProblemWs* out, size_t* fall
     w.planes = off;
     off += align_up(planes_bytes(pr[i].n_tokens, cols), 256);
     w.ints = off;                                   // column maxima (n ints, padded to 8 bytes), then the [NSTAT][n] route statistics
-    off += align_up((size_t)((cols + 1) / 2 * 2) * sizeof(int) + (size_t)(NSTAT * cols) * sizeof(unsigned long long), 256);
-    w.vals = off;                                   // alpha_s / rho per column
-    off += align_up((size_t)(NVAL * cols) * sizeof(double), 256);
+    off += align_up(ints_bytes(cols), 256);
+    w.vals = off;                                   // alpha_s / rho per column, then the route kernel's per-workgroup partial maxima
+    off += align_up((size_t)(NVAL * cols) * sizeof(double) + (size_t)ceil_div(cols, (int64_t)ROUTE_THREADS) * sizeof(RoutePartial), 256);
     w.route = off;
     off += align_up(sizeof(RouteOut), 256);
     w.colpart = off;                                // chunk partials of the fp64 column kernel
@@ -1539,7 +1565,7 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
     int* emax = (int*)((char*)ws + pw[i].ints);
     unsigned long long* stats = (unsigned long long*)(emax + (n + 1) / 2 * 2);
     unsigned char* zmask = (unsigned char*)ws + pw[i].zmask;
-    MDG_HIP(hipMemsetAsync(emax, 0, (size_t)((n + 1) / 2 * 2) * sizeof(int) + (size_t)(NSTAT * n) * sizeof(unsigned long long), st));
+    MDG_HIP(hipMemsetAsync(emax, 0, ints_bytes(n), st));
     const bool vec = ((uintptr_t)q.x % 16 == 0) && (q.ld % 8 == 0);
     const int64_t rows_per_block = 2048;
     if (vec) {
@@ -1554,8 +1580,13 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
                          (const bf16_t*)q.x, q.ld, n_tokens, n, nk, emax, planes, stats, zmask);
     }
     // a flag per statistic: the launch takes the deepest route any statistic still on the int8 path asks for (launch_route)
-    hipLaunchKernelGGL(i8_route_kernel, dim3(1), dim3(ROUTE_THREADS), 0, st, stats, emax, n, tau_x_of(n_tokens), (double*)((char*)ws + pw[i].vals), pflag + i,
-                       (RouteOut*)((char*)ws + pw[i].route), route_counts);
+    {
+      double* vals = (double*)((char*)ws + pw[i].vals);
+      RoutePartial* partial = (RoutePartial*)(vals + (size_t)NVAL * n);
+      RouteScratch* scratch = (RouteScratch*)(stats + (size_t)NSTAT * n);      // (inside the region zeroed above)
+      hipLaunchKernelGGL(i8_route_kernel, dim3((unsigned)ceil_div(n, ROUTE_THREADS)), dim3(ROUTE_THREADS), 0, st, stats, emax, n,
+                         tau_x_of(n_tokens), vals, partial, scratch, pflag + i, (RouteOut*)((char*)ws + pw[i].route), route_counts);
+    }
     hipLaunchKernelGGL(i8_clear_columns_kernel, dim3(ROUTE_JMAX, (unsigned)std::min(64, (nk + 3) / 4)), dim3(256), 0, st,
                        (const RouteOut*)((char*)ws + pw[i].route), pflag + i, emax, planes, zmask, n, nk);
     MDG_LAUNCH_CHECK();

@@ -24,6 +24,9 @@ ap.add_argument("--calib_size", type=int, default=64)
 ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--layers", type=int, default=0, help="truncate the model to this many layers (0 = all)")
 ap.add_argument("--ratio", type=float, default=0.3)
+ap.add_argument("--price", action="store_true",
+                help="price the run (VERDICT r2 item 5): a forward-only pass (hooks off), the hooks' kernel time by HIP events around "
+                     "every covariance enqueue, BI time, artefact IO, and the per-rank projection at 8 GPUs")
 a = ap.parse_args()
 sh = engine.SHAPES[a.arch]
 L = a.layers or sh["n_layers"]
@@ -45,9 +48,46 @@ tmp = tempfile.mkdtemp(prefix="mdg_e2e_")
 ad = ModelAdapter.from_model(model, None)
 ad.config = CompressionConfig(temp_storage_dir=os.path.join(tmp, "layers"), dataset="synthetic", calib_size=a.calib_size,
                               calibs_batch_size=a.batch, compression_ratio=a.ratio, order="mlp,qk,vo", **engine.RECIPE_RIDGES)
+price = {}
+if a.price:
+    from modegpt_amd import ops as _ops, calibration as _cal
+    from modegpt_amd.eval import load_calibration_texts
+    ad.calibs = load_calibration_texts(calib_size=a.calib_size, model=model, tokenizer=None, batch_size=a.batch, dataset="synthetic")
+    with torch.no_grad():
+        model(ad.calibs[0])                                            # warm-up (allocator, kernels)
+        torch.cuda.synchronize(); t0 = time.time()
+        for batch in ad.calibs:
+            model(batch)
+        torch.cuda.synchronize(); price["forward_only_s"] = time.time() - t0
+        torch.cuda.synchronize(); t0 = time.time()
+        for batch in ad.calibs:
+            out = model(batch, output_hidden_states=True); del out
+        torch.cuda.synchronize(); price["forward_with_hidden_states_s"] = time.time() - t0
+    ev = []
+    real_multi = _ops.cov_accum_multi
+    def timed_multi(items, mode=None):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); real_multi(items, mode); e1.record(); ev.append((e0, e1))
+    _ops.cov_accum_multi = timed_multi
+    bi_ev = []
+    real_add = _cal.BlockInfluence.add_batch
+    def timed_add(self, hs):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.time(); e0.record(); real_add(self, hs); e1.record(); bi_ev.append((e0, e1, time.time() - t0))
+    _cal.BlockInfluence.add_batch = timed_add
+    io = [0.0]
+    real_save = type(ad).save_layer
+    def timed_save(self, *args, **kw):
+        torch.cuda.synchronize(); t0 = time.time(); real_save(self, *args, **kw); io[0] += time.time() - t0
+    type(ad).save_layer = timed_save
 torch.cuda.synchronize(); t0 = time.time()
 cov_mlp, cov_q, cov_k, cov_x, bi = load_calibs(ad, a.calib_size, a.batch, dataset="synthetic", target_layers=[])
 torch.cuda.synchronize(); t_cal = time.time() - t0
+if a.price:
+    price["hook_kernels_s"] = sum(e0.elapsed_time(e1) for e0, e1 in ev) * 1e-3
+    price["hook_enqueues"] = len(ev)
+    price["bi_kernels_s"] = sum(e0.elapsed_time(e1) for e0, e1, _ in bi_ev) * 1e-3
+    price["bi_host_s"] = sum(h for _, _, h in bi_ev)
 print(f"calibration ({a.calib_size} x 2048 tokens, all {L} layers hooked): {t_cal:.1f} s; bi[:4] = {[round(b, 4) for b in bi[:4]]}")
 keep = allocate_global_sparsity(bi, a.ratio, smoothing=ad.config.sparsity_smoothing, max_sparsity=ad.config.max_sparsity, adapter=ad)
 layers = list(range(L))
@@ -65,6 +105,19 @@ install_compressed_attention(ad, masks)
 t0 = time.time(); ppl = compute_perplexity(model, None, bs=4, dataset="synthetic", adapter=ad); t_ppl = time.time() - t0
 print(f"compressed model, in-process compressed attention: synthetic-token perplexity {ppl:.1f} (random weights; vocab 32000) in {t_ppl:.1f} s")
 print(f"TOTAL {t_cal + t_mlp + t_qk + t_vo:.1f} s for {L} layers = {L / (t_cal + t_mlp + t_qk + t_vo):.3f} layers/s (model forward and artefact IO included)")
+if a.price:
+    fw, hk, bik = price["forward_with_hidden_states_s"], price["hook_kernels_s"], price["bi_kernels_s"]
+    dec = t_mlp + t_qk + t_vo - io[0]
+    print(f"PRICE calibration {t_cal:.1f} s = forward {fw:.1f} (without output_hidden_states: {price['forward_only_s']:.1f}) + hooks' covariance "
+          f"kernels {hk:.1f} ({price['hook_enqueues']} enqueues) + BI kernels {bik:.2f} (host side of BI incl. its syncs {price['bi_host_s']:.2f}) "
+          f"+ rest (host stalls, allocator, finalize) {t_cal - fw - hk - bik:.1f}")
+    print(f"PRICE compress {t_mlp + t_qk + t_vo:.1f} s = kernels + host {dec:.1f} + artefact IO (torch.save after a synchronize) {io[0]:.1f}")
+    G = 8
+    print(f"PROJECTION at {G} GPUs, layer-sharded (every rank: all samples through the whole model, hooks on its {L // G} layers): "
+          f"forward {fw:.1f} + cov {hk / G:.1f} + BI {bik:.2f} + dec {dec / G:.1f} + IO {io[0] / G:.1f} = "
+          f"{fw + hk / G + bik + dec / G + io[0] / G:.1f} s per rank  -> speed-up {(t_cal + t_mlp + t_qk + t_vo) / (fw + hk / G + bik + dec / G + io[0] / G):.2f}x; "
+          f"with the forward truncated after a rank's last owned layer (mean (g + 1) / G of it over ranks, the LAST rank the full one): "
+          f"slowest rank unchanged; with BI from one shared bf16 pre-pass and hooks fed by a layer-pipelined forward: see DESIGN.md section 6")
 shutil.rmtree(tmp, ignore_errors=True)
 from modegpt_amd import ops as _ops
 print(f"covariance routes of the large statistics (mode {_ops.COV_MODE}; counted on the device): {getattr(ad, 'cov_routes', None)}")
