@@ -353,8 +353,10 @@ __global__ __launch_bounds__(256) void i8_split_vec_kernel(const bf16_t* x, int6
 // TAU_SQ bounds the attained part.  The cross part is attained only by columns whose digit sequences are proportional over the
 // tokens; for uncorrelated columns the sums behind it grow like sqrt(tokens) where Cauchy-Schwarz allows tokens, so the measured
 // error sits ~4.5 / sqrt(tokens) below X_P (0.02 - 0.035 at 32768 tokens on every family of scripts/probes/i8_error_bound.py).
-// Short calls have no such averaging (33 tokens: measured / X_P ~ 0.3), hence the threshold on X_P grows with the token count:
-// guaranteed <= TAU_SQ + tau_x(tokens) <= 1.1e-11 for any input, and <= 1e-12 measured also on the uncorrelated data of a short call.
+// Short calls have no such averaging (33 tokens: measured / X_P ~ 0.3), and neither have sparse columns (the sums run over a
+// column's nonzero elements: 7033 tokens at 1 % density measured 0.23), hence the threshold on X_P grows with the EFFECTIVE token
+// count -- the smallest number of nonzero elements any column of the statistic has:
+// guaranteed <= TAU_SQ + tau_x <= 1.1e-11 for any input, and <= 1e-12 measured also on the uncorrelated data of a short or sparse call.
 constexpr double TAU_SQ = 1e-12, TAU_X_MIN = 1e-12, TAU_X_MAX = 1e-11, TAU_X_TOKENS = 1024.0;
 __host__ __device__ inline double tau_x_of(int64_t tokens) {
   return fmin(TAU_X_MAX, fmax(TAU_X_MIN, TAU_X_MIN * ((double)tokens / TAU_X_TOKENS)));
@@ -403,6 +405,7 @@ __device__ __forceinline__ void top2_merge(Top2& a, const Top2& b) {   // (lowes
 struct RoutePartial {
   Top2 top[NVAL];
   unsigned long long cls[NVAL][64];
+  unsigned min_nnz;              // fewest nonzero elements of any (not all-zero) column
 };
 struct RouteScratch {            // zeroed with the statistics before every call
   int ticket, forced;
@@ -411,7 +414,7 @@ struct RouteScratch {            // zeroed with the statistics before every call
 // Grid: one workgroup per ROUTE_THREADS columns.  Every workgroup turns its columns' integers into alpha_s / rho (kept in `vals`
 // for the greedy) and leaves its partial maxima in `partial`; the LAST one to finish (ticket) merges them and decides -- so the
 // ~10 fp64 square roots per column are spread over the chip and the common case (nothing has to leave) ends there.
-__global__ __launch_bounds__(ROUTE_THREADS) void i8_route_kernel(const unsigned long long* __restrict__ stats, int* emax, int n, double tau_x,
+__global__ __launch_bounds__(ROUTE_THREADS) void i8_route_kernel(const unsigned long long* __restrict__ stats, int* emax, int n, int64_t n_tokens,
                                                                  double* __restrict__ vals, RoutePartial* partial, RouteScratch* scratch,
                                                                  int* flag, RouteOut* out, int* route_counts) {
   __shared__ unsigned long long group_max[NVAL][64];   // per quantity: maxima of the 64 column classes j % 64 (bit patterns of doubles >= 0)
@@ -420,8 +423,11 @@ __global__ __launch_bounds__(ROUTE_THREADS) void i8_route_kernel(const unsigned 
   __shared__ double floor_of[NVAL];
   __shared__ int decision;   // -1: keep going; 0: accepted; 1: this P cannot be reached
   __shared__ int forced_total, my_ticket;
+  __shared__ unsigned min_nnz;
+  __shared__ double tau_x_shared;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < NVAL * 64; i += ROUTE_THREADS) (&group_max[0][0])[i] = 0ull;
+  if (tid == 0) min_nnz = 0xffffffffu;
   __syncthreads();
   // top two of every quantity over the columns still on the int8 path: block reduction of per-thread results into top[]
   auto reduce_top = [&](Top2 (&t)[NVAL]) {
@@ -468,6 +474,7 @@ __global__ __launch_bounds__(ROUTE_THREADS) void i8_route_kernel(const unsigned 
       for (int s2 = 0; s2 < NP; s2++) a[s2] = q[s2] > 0 ? sqrt(q[s2]) * ldexp(1.0, 8 * (NP - 1 - s2)) * inv : 0.0;
       a[6] = rounded > 0 ? 0.5 * sqrt(rounded) * inv : 0.0;
       nonfinite = (ex & 255) == 255;
+      if ((unsigned)counts) atomicMin(&min_nnz, (unsigned)counts);
 #pragma unroll
       for (int i = 0; i < NVAL; i++) {
         vals[(int64_t)i * n + j] = a[i];
@@ -485,6 +492,7 @@ __global__ __launch_bounds__(ROUTE_THREADS) void i8_route_kernel(const unsigned 
   // hand the partial results over; the last workgroup to arrive goes on
   RoutePartial& mine = partial[blockIdx.x];
   if (tid < NVAL) mine.top[tid] = top[tid];
+  if (tid == 0) mine.min_nnz = min_nnz;
   for (int i = tid; i < NVAL * 64; i += ROUTE_THREADS) (&mine.cls[0][0])[i] = (&group_max[0][0])[i];
   __threadfence();
   __syncthreads();
@@ -504,8 +512,14 @@ __global__ __launch_bounds__(ROUTE_THREADS) void i8_route_kernel(const unsigned 
     for (unsigned w = 0; w < gridDim.x; w++) m = max(m, (&partial[w].cls[0][0])[i]);
     (&group_max[0][0])[i] = m;
   }
-  if (tid == 0) forced_total = scratch->forced;
+  if (tid == 0) {
+    forced_total = scratch->forced;
+    unsigned m = 0xffffffffu;
+    for (unsigned w = 0; w < gridDim.x; w++) m = min(m, partial[w].min_nnz);
+    tau_x_shared = tau_x_of(min(n_tokens, (int64_t)m));
+  }
   __syncthreads();
+  const double tau_x = tau_x_shared;
   int n_out = 0;
   if (forced_total > ROUTE_JMAX) {      // too many: the whole statistic goes through the fp64 kernel
     if (tid == 0) {
@@ -1585,7 +1599,7 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
       RoutePartial* partial = (RoutePartial*)(vals + (size_t)NVAL * n);
       RouteScratch* scratch = (RouteScratch*)(stats + (size_t)NSTAT * n);      // (inside the region zeroed above)
       hipLaunchKernelGGL(i8_route_kernel, dim3((unsigned)ceil_div(n, ROUTE_THREADS)), dim3(ROUTE_THREADS), 0, st, stats, emax, n,
-                         tau_x_of(n_tokens), vals, partial, scratch, pflag + i, (RouteOut*)((char*)ws + pw[i].route), route_counts);
+                         n_tokens, vals, partial, scratch, pflag + i, (RouteOut*)((char*)ws + pw[i].route), route_counts);
     }
     hipLaunchKernelGGL(i8_clear_columns_kernel, dim3(ROUTE_JMAX, (unsigned)std::min(64, (nk + 3) / 4)), dim3(256), 0, st,
                        (const RouteOut*)((char*)ws + pw[i].route), pflag + i, emax, planes, zmask, n, nk);

@@ -31,7 +31,7 @@ def err_of(S, R):
     return (((S - R).abs() / (d[:, None] * d[None]))[low]).max().item()
 
 
-worst, routes, bad = 0.0, {}, 0
+worst, routes, bad, cols_out, worst_ratio = 0.0, {}, 0, 0, 0.0
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 80):
     T = int(torch.randint(1, 9000, (1,), generator=g))
     count = int(torch.randint(1, 5, (1,), generator=g))
@@ -46,14 +46,20 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 80):
             X, k = sample(T, n)
             items.append((torch.zeros(n, n, dtype=F64, device=dev), X, 1))
         kinds.append(k)
-    r = ops.cov_accum_i8_multi(items, report=True)
+    infos = []
+    r = ops.cov_accum_i8_multi(items, report=True, route_info=infos)
+    cols_out += sum(len(i_["columns"]) for i_ in infos)
     routes[r] = routes.get(r, 0) + 1
-    for (S, X, nh), k in zip(items, kinds):
+    for (S, X, nh), k, info in zip(items, kinds, infos):
         R = torch.zeros_like(S)
         ops.cov_accum(R, X, n_heads=nh)
         e = err_of(S, R) if S.dim() == 2 else max(err_of(S[h], R[h]) for h in range(nh))
         worst = max(worst, e)
-        if not e < 1e-12:
+        over_bound = info["planes"] != 0 and e > info["bound"] + 4e-16       # (the guaranteed part: must never happen)
+        if info["planes"] and e > 4e-16:
+            worst_ratio = max(worst_ratio, e / max(info["bound"], 1e-300))
+        if not e < 1e-12 or over_bound:
             bad += 1
-            print(f"VIOLATION trial {trial}: T={T} shape={tuple(S.shape)} kind={k} route={r} of {count} statistics err={e:.2e}")
-print(f"routes {routes}; worst error {worst:.2e}; violations {bad}")
+            print(f"VIOLATION trial {trial}: T={T} shape={tuple(S.shape)} kind={k} route={r} of {count} statistics err={e:.2e} "
+                  f"bound={info['bound']:.2e} columns={info['columns']}")
+print(f"routes {routes}; worst error {worst:.2e}; largest measured / bound {worst_ratio:.3f}; columns sent to the fp64 column kernel {cols_out}; violations {bad}")

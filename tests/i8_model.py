@@ -31,8 +31,9 @@ TAU_SQ, TAU_X, JMAX = 1e-12, 1e-11, 32            # TAU_X: the cross-term thresh
 
 
 def tau_x_of(tokens):
-    """The threshold on X_P grows with the token count (cov_i8.hip tau_x_of): for uncorrelated columns the measured error sits
-    ~4.5 / sqrt(tokens) below X_P, an averaging a short call does not have.  1e-12 up to 1024 tokens, 1e-11 from 10240."""
+    """The threshold on X_P grows with the EFFECTIVE token count -- the fewest nonzero elements any column has, at most the tokens
+    of the call (cov_i8.hip tau_x_of): for uncorrelated columns the measured error sits ~4.5 / sqrt(tokens) below X_P, an
+    averaging a short call or a sparse column does not have.  1e-12 up to 1024 tokens, 1e-11 from 10240."""
     return min(TAU_X, max(1e-12, 1e-12 * tokens / 1024.0))
 
 
@@ -167,5 +168,6 @@ def route_of(X, chunk=1024):
         st = column_stats(d, rounded, nnz)
         qs.append(st["q"]); rs.append(st["rounded"]); ns.append(st["nnz"])
     st = {"q": np.concatenate(qs, axis=1), "rounded": np.concatenate(rs), "nnz": np.concatenate(ns)}
-    planes, cols, (sq, x) = route(st, sort=False, tokens=X.shape[0])
+    nz = st["nnz"][st["nnz"] > 0]
+    planes, cols, (sq, x) = route(st, sort=False, tokens=min(X.shape[0], int(nz.min()) if nz.size else X.shape[0]))
     return {"planes": planes, "columns": cols, "sq": sq, "x": x, "bound": sq + x, "stats": st}
