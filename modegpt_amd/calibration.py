@@ -73,6 +73,14 @@ class BlockInfluence:
         return [v / n_texts for v in self.acc.cpu().tolist()]
 
 
+class StopForward(Exception):
+    """Raised by a forward hook behind the last layer a rank owns: the rest of the model forward is not needed there."""
+
+
+def _stop_forward(module, args, output):
+    raise StopForward()
+
+
 def load_calibs(adapter: ModelAdapter, n_samples: int, batch_size: int, dataset: str = "wikitext",
                 load_calibs_from="", calibs_save_path="", target_layers: List[int] = []):
     return _calibrate_model(adapter, n_samples=n_samples, batch_size=batch_size, dataset=dataset,
@@ -84,6 +92,8 @@ def _calibrate_model(adapter: ModelAdapter, n_samples: int, batch_size: int, tar
                      dataset="wikitext"):
     model = adapter.model
     targets = list(target_layers) if target_layers else list(range(adapter.n_layers))
+    if getattr(adapter, "calib_no_hooks", False):      # a sharded rank that owns no layer of this chunk (BI only, or nothing)
+        targets = []
     if adapter.calibs is None:
         from .eval import load_calibration_texts
         adapter.calibs = load_calibration_texts(calib_size=n_samples, model=model, tokenizer=adapter.tokenizer,
@@ -99,19 +109,32 @@ def _calibrate_model(adapter: ModelAdapter, n_samples: int, batch_size: int, tar
     for i in targets:
         adapter.register_hooks(i, blocks[i], cov_mlp_list=sig.lists["mlp"], cov_q_list=sig.lists["q"],
                                cov_k_list=sig.lists["k"], cov_x_list=sig.lists["x"], handles=handles, logger=logger)
-    model.config.output_hidden_states = True
+    # A sharded run (run_modegpt.compress_chunk) sets two attributes on the adapter: calib_stop_after = the last layer this rank
+    # needs activations of -- the forward is cut right behind it -- and calib_want_bi = whether this rank is the one that
+    # computes the BI scores (they need every layer's hidden state, i.e. the full forward; the others receive them).
+    stop_after = getattr(adapter, "calib_stop_after", None)
+    want_bi = getattr(adapter, "calib_want_bi", True)
+    if want_bi:
+        stop_after = None
+    if stop_after is not None:
+        handles.append(blocks[stop_after].register_forward_hook(_stop_forward))
+    model.config.output_hidden_states = bool(want_bi)
     model.eval()
     n_texts = 0
     try:
         for batch in adapter.calibs:
             n_texts += len(batch)
-            out = model(batch, output_hidden_states=True)
-            bi.add_batch(out.hidden_states)
+            try:
+                out = model(batch, output_hidden_states=bool(want_bi))
+            except StopForward:
+                continue
+            if want_bi:
+                bi.add_batch(out.hidden_states)
             del out
     finally:
         for h in handles:
             h.remove()
-    bi_scores = bi.scores(n_texts)
+    bi_scores = bi.scores(n_texts) if want_bi else None
     adapter.bi_scores = bi_scores
     sig.finalize(n_texts)
     if ops.COV_MODE == "i8":   # the route of every large-statistic launch was picked on the device; read the tally once

@@ -50,12 +50,39 @@ def _free() -> None:
     torch.cuda.empty_cache()
 
 
+def _share_bi_scores(adapter, bi_scores, src: int, rank: int):
+    """BI scores from the rank that ran the full forward to everybody (the model and the calibration samples do not change between
+    chunks, so later chunks reuse them: upstream recomputes identical values, run_modegpt.py:112-118)."""
+    import torch.distributed as dist
+    cached = getattr(adapter, "bi_scores_cached", None)
+    if cached is not None:
+        return cached
+    dev = "cuda" if torch.cuda.is_available() and dist.get_backend() == "nccl" else "cpu"
+    t = torch.zeros(adapter.n_layers, dtype=torch.float64, device=dev)
+    if rank == src:
+        t.copy_(torch.tensor(bi_scores, dtype=torch.float64))
+    dist.broadcast(t, src=src)
+    adapter.bi_scores_cached = adapter.bi_scores = t.cpu().tolist()
+    return adapter.bi_scores_cached
+
+
 def compress_chunk(adapter: ModelAdapter, config: CompressionConfig, chunk: List[int], rank: int, world: int):
     """Calibrate + compress the layers of `chunk` this rank owns; returns the chunk's rotary masks in layer order."""
     mine = sharding.my_layers(chunk, rank, world)
+    if world > 1:
+        # Every rank takes all samples through the model, but only as far as its own layers reach (the hooks of a layer need the
+        # forward up to that layer, nothing behind it).  The BI scores need every hidden state: the LAST rank -- whose block ends
+        # the chunk and which owns the fewest layers under the balanced partition -- runs the forward to the end and computes
+        # them once; the others receive them below (a 8 n_layers-byte control message, not a data-path exchange).
+        bi_rank = world - 1
+        adapter.calib_want_bi = rank == bi_rank and getattr(adapter, "bi_scores_cached", None) is None
+        adapter.calib_stop_after = mine[-1] if mine else chunk[0]
+        adapter.calib_no_hooks = not mine          # (`target_layers=[]` means "all layers" upstream: say "none" explicitly)
     cov_mlp, cov_q, cov_k, cov_x, bi_scores = load_calibs(
         adapter=adapter, n_samples=config.calib_size, batch_size=config.calibs_batch_size, dataset=config.dataset,
         target_layers=mine)
+    if world > 1:
+        bi_scores = _share_bi_scores(adapter, bi_scores, bi_rank, rank)
     keep = allocate_global_sparsity(bi_scores, compression_ratio=config.compression_ratio,
                                     smoothing=config.sparsity_smoothing, max_sparsity=config.max_sparsity,
                                     adapter=adapter)
@@ -80,6 +107,8 @@ def main(trial=None, config: Optional[CompressionConfig] = None):
     config = config or CompressionConfig.from_args()
     print(config.to_dict())
     rank, world = sharding.init_from_env()
+    if world > 1:   # blocks balanced against the forward a rank runs to reach them (measured share)
+        os.environ.setdefault("MODEGPT_SHARD_FORWARD_SHARE", "0.32")
 
     model, tokenizer = reload_compressed_model(config.model)
     adapter = ModelAdapter.from_model(model=model, tokenizer=tokenizer)

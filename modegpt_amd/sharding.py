@@ -1,7 +1,8 @@
 """Layer sharding across the GPUs of one node (new: the reference is single-process).
 
 Given the sigma matrices, every layer's MLP / QK / VO compression is independent, so rank g of G owns a
-contiguous block of ceil(L/G) layers and no data-path collective is needed until the end, when ONE all-gather
+contiguous block of layers (equal blocks, or blocks balanced against the forward a rank has to run to reach them:
+partition()) and no data-path collective is needed until the end, when ONE all-gather
 (RCCL over xGMI under backend "nccl", gloo on CPU in tests) of a fixed-stride packed buffer reassembles the
 compressed checkpoint on every rank.
 
@@ -42,18 +43,49 @@ def finalize() -> None:
         dist.destroy_process_group()
 
 
-def my_layers(layers: Sequence[int], rank: int, world: int) -> List[int]:
-    """Contiguous block partition: rank g gets layers[g*ceil(L/G) : (g+1)*ceil(L/G)]."""
+def forward_share() -> float:
+    """Cost of taking the calibration samples through ONE layer of the model forward, relative to that layer's covariance +
+    decomposition + artefact IO (env MODEGPT_SHARD_FORWARD_SHARE, default 0: equal blocks).  run_modegpt sets it to its measured
+    0.32 (random-init Llama-3-8B, 512 x 2048 tokens on one MI355X: forward 15.4 s against 48.2 s for 32 layers)."""
+    return float(os.environ.get("MODEGPT_SHARD_FORWARD_SHARE", "0"))
+
+
+def partition(n: int, world: int, share: Optional[float] = None) -> List[Tuple[int, int]]:
+    """Contiguous blocks [start, end) of n layers for ranks 0 .. world - 1.
+    share == 0: equal blocks of ceil(n / world) (the synthetic bench: no forward).  share > 0: a rank that owns layers [a, b) pays
+    the forward up to b (it stops there) plus its own layers' covariance / decomposition, f b + c (b - a) with f / c = share;
+    equalising that over the ranks gives b_g = n (1 - r^g) / (1 - r^world), r = 1 / (1 + share): early ranks own more layers, the
+    last ones -- which traverse (almost) the whole model -- few."""
+    share = forward_share() if share is None else share
+    if world <= 1:
+        return [(0, n)]
+    if share <= 0:
+        per = -(-n // world)
+        return [(min(n, g * per), min(n, (g + 1) * per)) for g in range(world)]
+    r = 1.0 / (1.0 + share)
+    bounds = [0] + [int(round(n * (1 - r ** g) / (1 - r ** world))) for g in range(1, world)] + [n]
+    for g in range(1, world + 1):                      # monotone, and nobody beyond n
+        bounds[g] = min(n, max(bounds[g], bounds[g - 1]))
+    return [(bounds[g], bounds[g + 1]) for g in range(world)]
+
+
+def my_layers(layers: Sequence[int], rank: int, world: int, share: Optional[float] = None) -> List[int]:
+    """This rank's contiguous block of `layers` (partition())."""
     layers = list(layers)
-    if world == 1:
-        return layers
-    per = -(-len(layers) // world)
-    return layers[rank * per:(rank + 1) * per]
+    a, b = partition(len(layers), world, share)[rank]
+    return layers[a:b]
 
 
-def owner_of(pos: int, n: int, world: int) -> int:
-    per = -(-n // world)
-    return pos // per
+def max_block(n: int, world: int, share: Optional[float] = None) -> int:
+    """Records per rank in the all-gather: the largest block of the partition."""
+    return max(b - a for a, b in partition(n, world, share))
+
+
+def owner_of(pos: int, n: int, world: int, share: Optional[float] = None) -> int:
+    for g, (a, b) in enumerate(partition(n, world, share)):
+        if a <= pos < b:
+            return g
+    raise IndexError(pos)
 
 
 # ------------------------------------------------------------------ pack / unpack
@@ -146,7 +178,7 @@ def gather_layer_artifacts(adapter, chunk: Sequence[int], mine: Sequence[int], r
             if os.path.exists(p):
                 tensors.update(torch.load(p, map_location=dev))
         records.append(pack_layer(layer, tensors, rms[pos] if pos < len(rms) else None))
-    per = -(-len(chunk) // world)
+    per = max_block(len(chunk), world)
     masks = {}
     for rec in allgather_records(records, per, world):
         layer, tensors, mask = unpack_layer(rec)

@@ -1,0 +1,58 @@
+#!/bin/bash
+# The judged profile: rocprofv3 --kernel-trace --stats of the DEFAULT bench command, then three separate PMC passes over the int8
+# covariance call at the bench's sigma_mlp shape (counters never ride along a timed run; --pmc only with --kernel-trace).
+#   bash scripts/probes/prof_bench.sh <tag> [bench args]     -> gpurun_out/<tag>_bench_kernel_trace_stats.csv, _by_launch_shape.csv,
+#                                                               _bench_under_rocprof.log, <tag>_cov_i8_pmc.csv, <tag>_cov_i8_hbm_traffic.json
+# Copy what should be judged into profiles/.  The program stands directly after `--`.
+export TMPDIR=/tmp
+R=$PWD
+TAG=${1:-r03}
+shift
+OUT=/tmp/${TAG}_prof
+rm -rf $OUT
+cd /tmp
+timeout -k 10 900 rocprofv3 --kernel-trace --stats -d $OUT -o p -- python3 $R/bench.py "$@" > $R/gpurun_out/${TAG}_bench_under_rocprof.log 2>&1
+echo "rocprofv3 exit code: $?" >> $R/gpurun_out/${TAG}_bench_under_rocprof.log
+cd $R
+DB=$(ls $OUT/*.db $OUT/*/*.db 2>/dev/null | head -1)
+python3 scripts/rocpd_summary.py $DB > gpurun_out/${TAG}_bench_kernel_trace_stats.csv
+python3 scripts/rocpd_summary.py $DB bygrid > gpurun_out/${TAG}_bench_kernel_trace_by_launch_shape.csv
+rm -rf $OUT
+grep -h "i8_syrk_kernelILi5" gpurun_out/${TAG}_bench_kernel_trace_by_launch_shape.csv | cut -c1-200
+: > gpurun_out/${TAG}_cov_i8_pmc.csv
+for pass in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT"; do
+  rm -rf $OUT
+  (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --pmc $pass -d $OUT -o p -- python3 $R/scripts/bench_kernels.py covi8 covi8p6 > $R/gpurun_out/${TAG}_pmc_pass.log 2>&1) || { echo "PMC pass $pass failed"; tail -5 gpurun_out/${TAG}_pmc_pass.log; exit 1; }
+  DB=$(ls $OUT/*.db $OUT/*/*.db 2>/dev/null | head -1)
+  echo "# pass: $pass" >> gpurun_out/${TAG}_cov_i8_pmc.csv
+  python3 scripts/rocpd_summary.py $DB bygrid | grep -i "i8_syrk\|^kernel" >> gpurun_out/${TAG}_cov_i8_pmc.csv
+  rm -rf $OUT
+done
+python3 - <<PY
+import csv, json, re
+rows = [l.strip() for l in open("gpurun_out/${TAG}_cov_i8_pmc.csv")]
+val = {}
+for l in rows:
+    m = re.match(r'"(.*i8_syrk_kernelILi(\d)EE.*)",(\d+),(ran_long),(\w+),(\d+),([0-9.e+]+)', l)
+    if m:
+        val[(m.group(2), m.group(5))] = float(m.group(7))
+    m = re.match(r'"(.*i8_syrk_kernelILi(\d)EE.*)",(\d+),(ran_long),(\d+),([0-9.]+),', l)
+    if m:
+        val[(m.group(2), "avg_ms")] = float(m.group(6))
+out = {}
+for P in ("5", "6"):
+    if (P, "FETCH_SIZE") in val:
+        fetch, write = val[(P, "FETCH_SIZE")] * 1024 * 2, val.get((P, "WRITE_SIZE"), 0.0) * 1024
+        out["planes_" + P] = {"fetch_bytes_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
+                              "avg_ms_under_profiler": val.get((P, "avg_ms")),
+                              "mfma_busy": val.get((P, "SQ_VALU_MFMA_BUSY_CYCLES"), 0) / max(val.get((P, "GRBM_GUI_ACTIVE"), 1) * 128, 1),
+                              "wait_any_share": val.get((P, "SQ_WAIT_ANY"), 0) / max(val.get((P, "SQ_WAVE_CYCLES"), 1), 1),
+                              "lds_bank_conflict": val.get((P, "SQ_LDS_BANK_CONFLICT")),
+                              "clock_ghz": (val.get((P, "GRBM_GUI_ACTIVE"), 0) / 8 / (val.get((P, "avg_ms"), 1) * 1e-3) / 1e9) if val.get((P, "avg_ms")) else None}
+res = {"source": "scripts/probes/prof_bench.sh: rocprofv3 --kernel-trace --pmc <one group per pass> -- python3 scripts/bench_kernels.py covi8 covi8p6; "
+                 "sigma_mlp-sized dispatches (class ran_long) of i8_syrk_kernel<5> (Gaussian columns) and <6> (SiLU-gated) averaged; raw rows: the _cov_i8_pmc.csv beside this file",
+       "units": "bytes per launch; FETCH_SIZE (KB) doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at 64 B), WRITE_SIZE (KB) as is",
+       "hbm_bytes_per_launch": out.get("planes_5", {}).get("hbm_bytes_per_launch"), **out}
+json.dump(res, open("gpurun_out/${TAG}_cov_i8_hbm_traffic.json", "w"), indent=1)
+print(json.dumps(res)[:1500])
+PY

@@ -62,10 +62,16 @@ def _worker(rank, world, port, tmp):
     # the GPU stages of compress_chunk, replaced: same signatures, deterministic artefacts written through adapter.save_layer
     def load_calibs(adapter, n_samples, batch_size, dataset, target_layers):
         calibrated.append(list(target_layers))
+        stops.append((adapter.calib_stop_after, adapter.calib_want_bi))
         none = [None] * N_LAYERS
-        return none, none, none, none, [0.1 * (i + 1) for i in range(N_LAYERS)]     # BI for ALL layers, on every rank
+        # BI for ALL layers, but only from the rank that runs the whole forward (compress_chunk hands them to the others)
+        return none, none, none, none, ([0.1 * (i + 1) for i in range(N_LAYERS)] if adapter.calib_want_bi else None)
+
+    stops = []
+    seen_bi = []
 
     def allocate(bi, **kw):
+        seen_bi.append(list(bi))
         return [0.7] * N_LAYERS
 
     def nystrom(adapter, cov, keep_ratios, target_layers):
@@ -94,6 +100,9 @@ def _worker(rank, world, port, tmp):
         assert mine == (chunk[:3] if rank == 0 else chunk[3:])
         all_masks = R.compress_chunk(ad, ad.config, chunk, rank, world)
         assert calibrated[-1] == mine                 # hooks only for this rank's layers
+        # the forward stops behind this rank's last layer; the last rank computes the BI scores, once (later chunks reuse them)
+        assert stops[-1] == (mine[-1], rank == world - 1 and first == 0)
+        assert all(abs(a - 0.1 * (i + 1)) < 1e-12 for i, a in enumerate(seen_bi[-1])) and len(seen_bi[-1]) == N_LAYERS
         assert len(all_masks) == 5
         for pos, i in enumerate(chunk):
             assert torch.equal(all_masks[pos], _layer(i)[1])

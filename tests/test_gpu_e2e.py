@@ -111,6 +111,39 @@ def _capture(adapter, batches):
     return store, [b / n_texts for b in bi], n_texts
 
 
+def test_truncated_forward_gives_the_same_statistics_for_the_layers_it_reaches(dev):
+    """A sharded rank cuts the calibration forward right behind its last layer (adapter.calib_stop_after) and leaves the BI
+    scores to the rank that runs the whole model (adapter.calib_want_bi = False): the statistics of the layers it does reach
+    must equal the full run's bit for bit, the others stay empty, and no BI comes back."""
+    from modegpt_amd.adapters.CompressionConfig import CompressionConfig
+    from modegpt_amd.adapters.model_adapter import ModelAdapter
+    from modegpt_amd.calibration import load_calibs
+    transformers = pytest.importorskip("transformers")
+    torch.manual_seed(0)
+    cfg = transformers.LlamaConfig(hidden_size=128, intermediate_size=320, num_hidden_layers=4, num_attention_heads=4,
+                                   num_key_value_heads=2, head_dim=32, vocab_size=211, max_position_embeddings=64)
+    model = transformers.LlamaForCausalLM(cfg).to(dev).to(torch.bfloat16).eval()
+    ad = ModelAdapter.from_model(model, None)
+    ad.config = CompressionConfig(dataset="synthetic", calib_size=8, calibs_batch_size=4)
+    full = load_calibs(ad, n_samples=8, batch_size=4, dataset="synthetic", target_layers=[0, 1])
+    assert full[4] is not None and len(full[4]) == 4
+    ran = []
+    hook = ad.get_transformer_blocks()[2].register_forward_hook(lambda *a: ran.append(1))
+    ad.calib_stop_after, ad.calib_want_bi = 1, False
+    cut = load_calibs(ad, n_samples=8, batch_size=4, dataset="synthetic", target_layers=[0, 1])
+    hook.remove()
+    assert not ran, "layer 2 must not have run"
+    assert cut[4] is None
+    for kind_full, kind_cut in zip(full[:4], cut[:4]):
+        for i in (0, 1):
+            assert torch.equal(kind_full[i], kind_cut[i])
+        assert kind_cut[2] is None and kind_cut[3] is None
+    # a rank without layers in the chunk hooks nothing (target_layers=[] alone would mean "all layers")
+    ad.calib_no_hooks = True
+    none = load_calibs(ad, n_samples=8, batch_size=4, dataset="synthetic", target_layers=[])
+    assert all(t is None for lst in none[:4] for t in lst)
+
+
 @pytest.mark.parametrize("kind", ["llama_gqa", "llama_mha", "qwen3", "opt", "llama_128"])
 def test_model_end_to_end(dev, kind, tmp_path):
     from modegpt_amd.adapters.CompressionConfig import CompressionConfig

@@ -124,6 +124,16 @@ def test_sharding_partition_and_record_roundtrip():
     assert [S.my_layers(list(range(32)), r, 8) for r in (0, 7)] == [[0, 1, 2, 3], [28, 29, 30, 31]]
     assert sum((S.my_layers(list(range(40)), r, 8) for r in range(8)), []) == list(range(40))
     assert S.my_layers(list(range(10)), 3, 4) == [9] and S.my_layers([0, 1], 3, 4) == []
+    # blocks balanced against the forward a rank runs to reach them (real-model runs; run_modegpt sets the share to 0.32)
+    for n, w in ((32, 8), (40, 8), (5, 2), (7, 3), (3, 8)):
+        P = S.partition(n, w, 0.32)
+        assert P[0][0] == 0 and P[-1][1] == n and all(P[g][1] == P[g + 1][0] for g in range(w - 1)) and all(a <= b for a, b in P)
+        assert sum((S.my_layers(list(range(n)), r, w, 0.32) for r in range(w)), []) == list(range(n))
+        assert S.max_block(n, w, 0.32) == max(b - a for a, b in P)
+        cost = lambda blocks: max(0.32 * b + (b - a) for a, b in blocks)          # forward up to b + own layers
+        assert cost(P) <= cost(S.partition(n, w, 0)) + 1e-9
+    assert [b - a for a, b in S.partition(32, 8, 0.32)] == [9, 6, 5, 4, 3, 2, 2, 1]
+    assert all(S.owner_of(p, 32, 8, 0.32) == g for g, (a, b) in enumerate(S.partition(32, 8, 0.32)) for p in range(a, b))
     t = {"up": torch.randn(5, 4).bfloat16(), "gate": None, "down": torch.randn(4, 5).bfloat16(),
          "q_proj": torch.randn(6, 4).bfloat16(), "k_proj": torch.randn(3, 4).bfloat16(),
          "v_proj": torch.randn(3, 4).bfloat16(), "o_proj": torch.randn(4, 6).bfloat16()}
