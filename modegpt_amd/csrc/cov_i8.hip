@@ -1,28 +1,32 @@
-// sigma += X^T X through the int8 matrix cores, exactly: an error-free split of the bf16 activations into digit planes.
+// sigma += X^T X through the int8 matrix cores: an ERROR-FREE SPLIT of the bf16 activations into digit planes and a TRUNCATED
+// plane-pair product whose error is bounded per call.
 //
 // A bf16 value is a signed 8-bit significand times a power of two.  Against a per-column scale 2^(E_j - 172), E_j the largest
 // exponent in column j of this call, it is a 48-bit fixed-point integer N = sig << (38 - (E_j - e)): six balanced base-256
-// digits d_0..d_5 in [-128, 127] (|d_0| <= 64).  Then
+// digits d_0..d_5 in [-128, 127] (|d_0| <= 64) -- exactly, for every element within 38 binades of its column maximum.  Then
 //     x_ti x_tj = 2^(E_i + E_j - 344) * sum_{s,t} d_s(t,i) d_t(t,j) 256^(10 - s - t)
-// and sum over tokens of d_s d_t is an int8 MFMA product with exact int32 accumulation.  Keeping the plane pairs with
-// s + t < P (P = 5: 15 pairs, P = 6: 21 pairs) drops terms below 2^-8P of (column maximum)^2 per token; what that costs
-// depends on how far below their column's maximum the elements sit, so every call measures it -- per column, the share of
-// its nonzero elements that lie more than 10 binades below the maximum ("deep") -- and picks the route (measured against the exact product,
-// scripts/probes/digit_plane_sim.py, 32768 tokens: Gaussian / ReLU columns, deep share < 1/64: P = 5 is within 2e-13 of
-// sigma's scale; Laplace / Student-t / SiLU- and GELU-gated products / products of two or three Gaussians, share 0.02 - 0.2:
-// P = 5 gives 5e-13 .. 8e-12, P = 6 gives 5e-15 .. 1e-13; cubed Gaussians, share ~0.5: P = 6 gives 3e-12; a column
-// dominated by a few massive activations, share ~1: beyond both):
-//     every column's deep share <= 1/64  ->  P = 5        <= 1/4  ->  P = 6        else  ->  the fp64 kernel (mdg_cov_accum)
+// and sum over tokens of d_s d_t is an int8 MFMA product with exact int32 accumulation.  The product keeps the plane pairs with
+// s + t < P (P = 5: 15 pairs, P = 6: 21 pairs) and DROPS the others.  What the dropped pairs can amount to is bounded from integer
+// plane energies the split pass accumulates per column (Cauchy-Schwarz over the tokens; i8_route_kernel below has the derivation):
+//     |sigma_ij(P) - sigma_ij| <= (SQ_P + X_P) sqrt(sigma_ii sigma_jj),   entry-wise, for any input,
+// and the route is the smallest P with SQ_P <= 1e-12 (the attained part) and X_P <= tau_x <= 1e-11 (cross terms), after at most 32
+// columns have been handed to an fp64 column kernel: GUARANTEED <= 1.1e-11, MEASURED <= 1e-12 (scripts/probes/i8_error_bound.py,
+// i8_fuzz.py; Gaussian / ReLU columns take five planes at 2e-14 .. 2e-13, SiLU- / GELU-gated products -- the MLP statistic of a
+// real Llama -- six at 6e-14; a column whose bulk sits 10+ binades under a few massive activations leaves alone).  Otherwise the
+// whole statistic goes through the fp64 kernel (mdg_cov_accum).
 // fp64 reference semantics: src/adapters/LlamaAdapter.py:127-147 (sigma += X^T X with X upcast to fp64).
 //
 // Kernels per call:
 //   i8_colmax_kernel   E_j = max exponent per column
 //   i8_split_kernel    six digit planes, written in the blocked layout the product kernel streams: [plane][32-row group]
 //                      [k-step][k-half][row][16 tokens] -- each 1 KB piece is one contiguous global_load_lds_dwordx4 per wave;
-//                      counts the deep elements per column on the way, and writes one mask byte per (k-step, 32-row group)
-//                      saying which planes hold a nonzero there (an element is two full digits and a carry digit, so whole
-//                      pieces of the deeper planes are zero on real activations)
-//   i8_depth_kernel    the route flag: 0 -> five planes, 1 -> six planes, bit 1 -> the fp64 kernel (read by the launches below)
+//                      accumulates the per-column integers of the route (sum of d_s^2 per plane, sum of d_0 d_1, nonzero / rounded
+//                      counts) on the way, and writes one mask byte per (k-step, 32-row group) saying which planes hold a nonzero
+//                      there (an element is two full digits and a carry digit, so whole pieces of the deeper planes are zero on
+//                      real activations)
+//   i8_route_kernel    the route: bit 0 of the statistic's flag -> six planes, bit 1 -> the fp64 kernel for the whole statistic;
+//                      bit 8 of emax[j] -> column j is computed by the fp64 column kernel (read by the launches below)
+//   i8_clear_columns_kernel   zeroes the digits of such columns and refreshes their groups' piece masks
 //   i8_syrk_kernel<P>  output tiles of the lower triangle, two waves per SIMD inside one workgroup of 8 waves:
 //                      P = 5: 128 x 128 tile, wave tile 64 x 32 (160 int32 accumulators; a 64 x 64 wave tile's 320 would not
 //                      fit); P = 6: 128 x 64 tile, wave tile 32 x 32 (96).  Per k-step of 32 tokens ONE set of fragment reads
@@ -32,12 +36,13 @@
 //                      stage; every 2047 k-steps (65504 tokens, the int32 bound) the classes are folded into sigma in fp64.  The
 //                      P = 5 variant reads the top five of the six planes (a balanced-digit truncation).  Planes beyond a
 //                      32-row group's depth in a k-step (piece masks) are neither written, nor loaded, nor read from LDS, nor
-//                      multiplied: exact, and 28 - 37 % of the MFMAs on SiLU-gated / Gaussian data.  Both instantiations
-//                      and the fp64 kernel are enqueued for every call; the device picks one (each workgroup of the others
-//                      exits on its first instruction).  Statistics of 2048 features and more (everything ops.py sends
-//                      here) run as a persistent launch: one workgroup per CU pulling tiles from per-XCD queues, the last, partly
-//                      filled round cut into k-chunks that fold into fp64 partial tiles
+//                      multiplied: no bit of the result changes, and 28 - 37 % of the MFMAs go on SiLU-gated / Gaussian data.
+//                      Both instantiations, the column kernel and the fp64 kernel are enqueued for every call; the device picks
+//                      (each workgroup of the others exits on its first instruction).  Statistics of 2048 features and more
+//                      (everything ops.py sends here) run as a persistent launch: one workgroup per CU pulling tiles from per-XCD
+//                      queues, the last, partly filled round cut into k-chunks that fold into fp64 partial tiles
 //   i8_tail_combine_kernel<P>  adds the partial tiles of that last round to sigma, in chunk order
+//   i8_columns_kernel, i8_columns_reduce_kernel   rows / columns of sigma of the columns that left, in plain fp64
 #include <algorithm>
 #include <map>
 #include <mutex>
