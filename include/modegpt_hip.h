@@ -231,6 +231,15 @@ size_t mdg_nystrom_down_ws_bytes(int64_t n, int64_t r, int64_t d);
 int mdg_nystrom_down(const double* C, int64_t n, int64_t ldc, const int64_t* idx, int64_t r, const void* Wd,
                      int64_t d, int64_t ld_wd, int w_dtype, double eps, void* down_out, int64_t ld_out, double* down_f64,
                      void* ws, size_t ws_bytes, void* stream);
+/* The same with the gathered cross product C[idx,:] W_d^T on `side_stream`, beside the factorisation of C_kk on `stream` (they do
+ * not depend on each other; the factorisation's 128-column steps leave most of the chip idle between their GEMMs).  Streams and the
+ * two events are the CALLER'S (any two hipEvent_t, timing disabled is fine): ev_fork is recorded on `stream` and waited for by
+ * `side_stream` before the product, ev_join is recorded behind the product and waited for by `stream` before the solve; when the
+ * call returns everything later on `stream` is ordered behind both.  Results are bit-identical to mdg_nystrom_down. */
+int mdg_nystrom_down_overlapped(const double* C, int64_t n, int64_t ldc, const int64_t* idx, int64_t r, const void* Wd,
+                                int64_t d, int64_t ld_wd, int w_dtype, double eps, void* down_out, int64_t ld_out,
+                                double* down_f64, void* ws, size_t ws_bytes, void* side_stream, void* ev_fork, void* ev_join,
+                                void* stream);
 
 /* ------------------------------------------------------------------ QK: CR selection
  * mask [n_kv, rank] (int64, score-descending, NOT sorted: compress_qk.py:366-367,418-419,464),

@@ -68,6 +68,8 @@ SIGNATURES = {
     "mdg_nystrom_down_ws_bytes": (_sz, [_i64, _i64, _i64]),
     "mdg_nystrom_down": (_i32, [_ptr, _i64, _i64, _ptr, _i64, _ptr, _i64, _i64, _i32, _f64, _ptr, _i64, _ptr, _ptr, _sz,
                                  _ptr]),
+    "mdg_nystrom_down_overlapped": (_i32, [_ptr, _i64, _i64, _ptr, _i64, _ptr, _i64, _i64, _i32, _f64, _ptr, _i64, _ptr, _ptr, _sz,
+                                            _ptr, _ptr, _ptr, _ptr]),
     "mdg_qk_select": (_i32, [_ptr, _ptr, _i32, _i32, _i32, _f64, _f64, _i32, _i32, _ptr, _ptr, _ptr, _ptr]),
     "mdg_vo_compress_ws_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "mdg_vo_compress": (_i32, [_ptr, _i64, _i64, _ptr, _i64, _ptr, _i64, _i32, _i32, _i32, _i32, _i32, _f64, _ptr, _i64,

@@ -22,9 +22,29 @@ extern "C" size_t mdg_nystrom_down_ws_bytes(int64_t n, int64_t r, int64_t d) {
   return ((size_t)r * r + mdg_potrf_inv_diag_elems(r) + (size_t)r * d + potrs_ws_elems(r, d)) * sizeof(double);
 }
 
+static int nystrom_down(const double* C, int64_t n, int64_t ldc, const int64_t* idx, int64_t r, const void* Wd, int64_t d, int64_t ld_wd,
+                        int w_dtype, double eps, void* down_out, int64_t ld_out, double* down_f64, void* ws, size_t ws_bytes,
+                        void* side_stream, void* ev_fork, void* ev_join, void* stream);
+
 extern "C" int mdg_nystrom_down(const double* C, int64_t n, int64_t ldc, const int64_t* idx, int64_t r, const void* Wd,
                                 int64_t d, int64_t ld_wd, int w_dtype, double eps, void* down_out, int64_t ld_out,
                                 double* down_f64, void* ws, size_t ws_bytes, void* stream) {
+  return nystrom_down(C, n, ldc, idx, r, Wd, d, ld_wd, w_dtype, eps, down_out, ld_out, down_f64, ws, ws_bytes, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int mdg_nystrom_down_overlapped(const double* C, int64_t n, int64_t ldc, const int64_t* idx, int64_t r, const void* Wd,
+                                           int64_t d, int64_t ld_wd, int w_dtype, double eps, void* down_out, int64_t ld_out,
+                                           double* down_f64, void* ws, size_t ws_bytes, void* side_stream, void* ev_fork, void* ev_join,
+                                           void* stream) {
+  MDG_CLEAR();
+  MDG_CHECK_ARG(side_stream && ev_fork && ev_join && side_stream != stream,
+                "mdg_nystrom_down_overlapped: needs a second stream and two events of the caller's");
+  return nystrom_down(C, n, ldc, idx, r, Wd, d, ld_wd, w_dtype, eps, down_out, ld_out, down_f64, ws, ws_bytes, side_stream, ev_fork, ev_join, stream);
+}
+
+static int nystrom_down(const double* C, int64_t n, int64_t ldc, const int64_t* idx, int64_t r, const void* Wd, int64_t d, int64_t ld_wd,
+                        int w_dtype, double eps, void* down_out, int64_t ld_out, double* down_f64, void* ws, size_t ws_bytes,
+                        void* side_stream, void* ev_fork, void* ev_join, void* stream) {
   MDG_CLEAR();
   MDG_CHECK_ARG(C && idx && Wd && down_out, "mdg_nystrom_down: null pointer");
   MDG_CHECK_ARG(w_dtype == MDG_BF16 || w_dtype == MDG_F64, "mdg_nystrom_down: W_d must be bf16 or f64 (got %d)", w_dtype);
@@ -40,8 +60,19 @@ extern "C" int mdg_nystrom_down(const double* C, int64_t n, int64_t ldc, const i
   // C_kk + eps I  (lower)                                           compress_mlp.py:52,56
   MDG_TRY(copy_lower(C, ldc, idx, Ckk, r, r, eps, st));
   // cross = C[idx,:] @ W_d^T  -> [r, d]                             compress_mlp.py:54
-  MDG_TRY(gemm_f64(r, d, n, 1.0, C, MDG_F64, ldc, 1, idx, Wd, w_dtype, 1, ld_wd, 0.0, X, MDG_F64, d, 1, 0, 0, 0, 0, st));
-  MDG_TRY(potrf_lower(Ckk, r, r, inv, st));                       // compress_mlp.py:56
+  // (with a second stream: beside the factorisation of C_kk, which does not need it -- the chain of 79 diagonal-block steps
+  // leaves most of the chip idle between its GEMMs, the 1.2 TFLOP product fills it: 36 -> 27 ms for the two)
+  hipStream_t cross_st = st;
+  if (side_stream) {
+    cross_st = (hipStream_t)side_stream;
+    MDG_HIP(hipEventRecord((hipEvent_t)ev_fork, st));
+    MDG_HIP(hipStreamWaitEvent(cross_st, (hipEvent_t)ev_fork, 0));
+  }
+  MDG_TRY(gemm_f64(r, d, n, 1.0, C, MDG_F64, ldc, 1, idx, Wd, w_dtype, 1, ld_wd, 0.0, X, MDG_F64, d, 1, 0, 0, 0, 0, cross_st));
+  if (side_stream) MDG_HIP(hipEventRecord((hipEvent_t)ev_join, cross_st));
+  const int rc_potrf = potrf_lower(Ckk, r, r, inv, st);           // compress_mlp.py:56
+  if (side_stream) MDG_HIP(hipStreamWaitEvent(st, (hipEvent_t)ev_join, 0));   // (also on failure: the workspace is the caller's to free)
+  if (rc_potrf != MDG_OK) return rc_potrf;
   MDG_TRY(potrs_lower(Ckk, r, r, inv, X, d, d, solve_ws, st));    // compress_mlp.py:57
   if (down_f64) MDG_HIP(hipMemcpyAsync(down_f64, X, (size_t)r * d * sizeof(double), hipMemcpyDeviceToDevice, st));
   // [r, d] fp64 -> [d, r] bf16                                      compress_mlp.py:61,97

@@ -6,6 +6,7 @@ the metric excludes."""
 from __future__ import annotations
 
 import math
+import os
 import types
 from typing import Dict, List, Optional
 
@@ -184,6 +185,10 @@ class TensorAdapter(ModelAdapter):
         raise NotImplementedError
 
 
+OVERLAP_VO = os.environ.get("MODEGPT_OVERLAP_VO", "1") != "0"
+_VO_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+
+
 def compress_layer(adapter: TensorAdapter, layer_idx: int, covs: Dict[str, torch.Tensor], keep_ratio: float, check: bool = True):
     """mlp -> qk -> vo for one layer through the drop-in functions (fixed order of run_modegpt.py:128-151).
     Returns the layer's compressed tensors and rotary mask.  The chain enqueues without a host round trip; check=True reads
@@ -192,10 +197,25 @@ def compress_layer(adapter: TensorAdapter, layer_idx: int, covs: Dict[str, torch
     n = max(adapter.shape["n_layers"], layer_idx + 1)
     lst = lambda t: [t if i == layer_idx else None for i in range(n)]  # noqa: E731
     keep = [keep_ratio] * n
+    # VO (one GEMM, a batched 128 x 128 eigensolve on 8 workgroups, skinny products: 8 ms of mostly latency) needs sigma_x only and
+    # runs on a stream of its own beside the MLP chain, whose Cholesky steps leave most of the chip idle between their GEMMs
+    dev = covs["x"].device
+    main = torch.cuda.current_stream(dev)
+    side = _VO_STREAMS.setdefault(dev.index, torch.cuda.Stream(device=dev)) if OVERLAP_VO else None
+    if side is not None:
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            compress_vo(adapter=adapter, cov=lst(covs["x"]), keep_ratios=keep, target_layers=[layer_idx])
+        covs["x"].record_stream(side)
     compress_nystrom(adapter=adapter, cov=lst(covs["mlp"]), keep_ratios=keep, target_layers=[layer_idx])
     masks = compress_qk(adapter=adapter, cov=(lst(covs["q"]), lst(covs["k"])), keep_ratios=keep,
                         target_layers=[layer_idx])
-    compress_vo(adapter=adapter, cov=lst(covs["x"]), keep_ratios=keep, target_layers=[layer_idx])
+    if side is None:
+        compress_vo(adapter=adapter, cov=lst(covs["x"]), keep_ratios=keep, target_layers=[layer_idx])
+    else:
+        main.wait_stream(side)
+        for t in adapter.store[(layer_idx, "vo")].values():
+            t.record_stream(main)        # allocated on the side stream, used on the caller's from here on
     if check:
         adapter.check_chains()
     out = {}

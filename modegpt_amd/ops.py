@@ -351,12 +351,14 @@ def _fusable_device(device) -> bool:
 
 
 COV_OVERLAP_SMALL = os.environ.get("MODEGPT_COV_OVERLAP", "1") != "0"
+NYSTROM_OVERLAP = os.environ.get("MODEGPT_NYSTROM_OVERLAP", "1") != "0"   # cross product of the Nystrom refit beside the factorisation of C_kk
 
 
-def _side_stream(device) -> "torch.cuda.Stream":
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+def _side_stream(device, purpose: str = "cov") -> "torch.cuda.Stream":
+    dev = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    key = (dev, purpose)
     if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
     return _SIDE_STREAMS[key]
 
 
@@ -571,9 +573,25 @@ def nystrom_down(Cm: torch.Tensor, idx: torch.Tensor, W_down: torch.Tensor, eps:
     nbytes = lib.mdg_nystrom_down_ws_bytes(n, r, d)
     ws, wsp = _ws(nbytes, Cm.device)
     with torch.cuda.device(Cm.device):
-        check(lib.mdg_nystrom_down(Cm.data_ptr(), n, Cm.stride(0), idx.data_ptr(), r, W_down.data_ptr(), d,
-                                   W_down.stride(0), _DT[W_down.dtype], float(eps), out.data_ptr(), out.stride(0), _p(f64), wsp, nbytes,
-                                   _stream(Cm)), "mdg_nystrom_down")
+        if NYSTROM_OVERLAP:
+            # the gathered cross product on a side stream beside the factorisation of C_kk (independent; the factorisation's
+            # 128-column steps leave most of the chip idle between their GEMMs): 36 -> 27 ms for the two at Llama-3-8B shapes
+            main = torch.cuda.current_stream(Cm.device)
+            side = _side_stream(Cm.device, "nystrom")
+            side.wait_stream(main)                       # (inputs and workspace were produced / allocated on `main`)
+            fork, join = torch.cuda.Event(), torch.cuda.Event()
+            fork.record(main)                            # materialise the HIP events; the library re-records them
+            join.record(main)
+            check(lib.mdg_nystrom_down_overlapped(Cm.data_ptr(), n, Cm.stride(0), idx.data_ptr(), r, W_down.data_ptr(), d,
+                                                  W_down.stride(0), _DT[W_down.dtype], float(eps), out.data_ptr(), out.stride(0),
+                                                  _p(f64), wsp, nbytes, side.cuda_stream, fork.cuda_event, join.cuda_event,
+                                                  main.cuda_stream), "mdg_nystrom_down_overlapped")
+            for t in (Cm, W_down, idx, ws):
+                t.record_stream(side)                    # read (workspace: written) there
+        else:
+            check(lib.mdg_nystrom_down(Cm.data_ptr(), n, Cm.stride(0), idx.data_ptr(), r, W_down.data_ptr(), d,
+                                       W_down.stride(0), _DT[W_down.dtype], float(eps), out.data_ptr(), out.stride(0), _p(f64), wsp, nbytes,
+                                       _stream(Cm)), "mdg_nystrom_down")
     return (out, f64) if want_f64 else out
 
 
