@@ -157,49 +157,52 @@ def step(shape, adapter, layer_idx, batches, keep, n_texts, timer=None):
 
 
 class Pipeline:
-    """Steps back to back with layer L's decomposition chain on a high-priority side stream while layer L + 1's covariance
-    kernels run on the caller's stream.  The chain is latency-bound (228 dependent single-workgroup Cholesky kernels between
-    small GEMMs, two host round trips for the not-positive-definite status) and leaves most of the chip idle; the covariance
-    of the next layer does not depend on it.  Same kernels, same inputs, same results -- only the order in which the two
-    streams' workgroups reach the CUs changes.  Each layer's statistics live in their own buffers until its chain is done."""
+    """Steps back to back with the decomposition chains of the previous `depth` layers on high-priority side streams (one each)
+    while the next layer's covariance kernels run on the caller's stream.  A chain is latency-bound (191 dependent
+    single-workgroup Cholesky steps between small GEMMs) and leaves most of the chip idle between its large GEMMs; the covariance
+    of the next layer does not depend on it, and neither does another layer's chain: two chains side by side fill each other's
+    gaps.  Same kernels, same inputs, same results -- only the order in which the streams' workgroups reach the CUs changes.
+    Each layer's statistics live in their own buffers until its chain is done."""
 
-    def __init__(self, shape, adapter, batches, keep, n_texts, timer=None, enabled=True):
+    def __init__(self, shape, adapter, batches, keep, n_texts, timer=None, enabled=True, depth=2):
         self.a = (shape, adapter, batches, keep, n_texts, timer)
         self.enabled = enabled
+        self.depth = depth if enabled else 1
         dev = batches[0]["h"].device
         self.main = torch.cuda.current_stream(dev)
-        self.side = torch.cuda.Stream(device=dev, priority=-1) if enabled else None
-        self.pending = None
+        self.sides = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(self.depth)] if enabled else []
+        self.pending = []
         self.done = []          # (layer, tensors, mask, covs) in layer order
 
     def _finish(self):
         shape, adapter, _, keep, _, timer = self.a
-        li, covs, ev = self.pending
-        self.pending = None
-        if not self.enabled:
-            tensors, mask = compress_layer(shape, adapter, li, covs, keep, timer)
-        else:
-            self.side.wait_event(ev)
-            with torch.cuda.stream(self.side):
+        for slot, (li, covs, ev) in enumerate(self.pending):
+            if not self.enabled:
                 tensors, mask = compress_layer(shape, adapter, li, covs, keep, timer)
-            for t in covs.values():
-                t.record_stream(self.side)      # allocated on the main stream, last read on the side stream
-        self.done.append((li, tensors, mask, covs))
+            else:
+                side = self.sides[slot]
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    tensors, mask = compress_layer(shape, adapter, li, covs, keep, timer)
+                for t in covs.values():
+                    t.record_stream(side)       # allocated on the main stream, last read on the side stream
+            self.done.append((li, tensors, mask, covs))
+        self.pending = []
 
     def submit(self, layer_idx):
         shape, _, batches, _, n_texts, timer = self.a
-        covs = accumulate_layer(shape, batches, n_texts, timer)      # enqueued on the main stream, returns at once
+        covs = accumulate_layer(shape, batches, n_texts, timer)      # enqueued on the main stream (the host runs ~2 layers ahead)
         ev = torch.cuda.Event()
         ev.record(self.main)
-        if self.pending is not None:
-            self._finish()                                            # the previous layer's chain, beside this covariance
-        self.pending = (layer_idx, covs, ev)
+        if len(self.pending) == self.depth:
+            self._finish()                                            # the previous layers' chains, beside this covariance
+        self.pending.append((layer_idx, covs, ev))
 
     def drain(self):
-        if self.pending is not None:
+        if self.pending:
             self._finish()
-        if self.enabled:
-            self.main.wait_stream(self.side)    # whatever follows on the caller's stream sees the compressed tensors
+        for side in self.sides:
+            self.main.wait_stream(side)         # whatever follows on the caller's stream sees the compressed tensors
         return self.done
 
 
@@ -305,6 +308,8 @@ def parse_args(argv=None):
                     help="(default) layer L's decomposition chain runs on a side stream beside layer L + 1's covariance kernels: "
                          "the chain enqueues without a host round trip (deferred status), so its kernels fill what the covariance "
                          "launches leave idle; +3 %% on the step (A/B/A/B on one box, DESIGN.md section 7)")
+    ap.add_argument("--chain-depth", type=int, default=2,
+                    help="how many layers' decomposition chains run side by side (each on a stream of its own) beside the next covariance")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
                     help="one after the other on one stream: per-kernel figures without interference (reported as value_sequential)")
     ap.add_argument("--no-extra-legs", action="store_true",
@@ -375,11 +380,11 @@ def plumbing_only(a, rank, world):
     sharding.finalize()
 
 
-def timed_steps(shape, adapter, layer_ids, batches, keep, n_texts, timer=None, pipelined=True):
+def timed_steps(shape, adapter, layer_ids, batches, keep, n_texts, timer=None, pipelined=True, depth=2):
     """K steps back to back between two synchronisations; returns (seconds, per-step outputs)."""
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    pipe = Pipeline(shape, adapter, batches, keep, n_texts, timer, enabled=pipelined)
+    pipe = Pipeline(shape, adapter, batches, keep, n_texts, timer, enabled=pipelined, depth=depth)
     for li in layer_ids:
         pipe.submit(li)
     outs = pipe.drain()
@@ -425,7 +430,7 @@ def main():
     timer = LaunchTimer()
     pipelined = a.pipeline
     t0 = time.perf_counter()
-    pipe = Pipeline(shape, adapter, batches, a.keep, n_texts, timer, enabled=pipelined)
+    pipe = Pipeline(shape, adapter, batches, a.keep, n_texts, timer, enabled=pipelined, depth=a.chain_depth)
     for i in range(a.steps):
         pipe.submit(first + a.warmup + i)
     records, last, done = [], None, []
@@ -569,7 +574,7 @@ def main():
             #     and its compressed tensors against the headline leg's, layer by layer, at the full token count
             ops.COV_MODE = "f64"
             t64 = LaunchTimer()
-            sec, outs64 = timed_steps(shape, adapter, ids, batches, a.keep, n_texts, t64, pipelined)
+            sec, outs64 = timed_steps(shape, adapter, ids, batches, a.keep, n_texts, t64, pipelined, a.chain_depth)
             nl, fl, msl = t64.summary()
             out["value_f64_route"] = {"value": len(ids) / sec, "ms_per_step": sec / len(ids) * 1e3, "steps": len(ids),
                                       "cov_kernel_tflops": fl / (msl * 1e-3) / 1e12,

@@ -81,16 +81,40 @@ class ModelAdapter(ABC):
 
     # ---- reconstruction: per-(layer, stage) artefacts and the final swap (model_adapter.py:184-237) ----
     def save_layer(self, output_dir: str, suffix: str, weights: dict, layer_idx):
-        """torch.save({name: bf16 tensor}) to <output_dir>/layer_<i>_<suffix>; env vars in the path expand."""
+        """torch.save({name: bf16 tensor}) to <output_dir>/layer_<i>_<suffix>; env vars in the path expand.  The file is in
+        place when this returns -- unless the run switched the background writer on (async_artifacts(True): run_modegpt does),
+        in which case it is in place after flush_artifacts(), which every reader of the directory here calls first."""
         output_dir = os.path.expandvars(output_dir)
         os.makedirs(output_dir, exist_ok=True)
-        torch.save(weights, os.path.join(output_dir, f"layer_{layer_idx}_{suffix}"))
+        path = os.path.join(output_dir, f"layer_{layer_idx}_{suffix}")
+        writer = getattr(self, "_artifact_writer", None)
+        if writer is not None:
+            writer.submit(path, weights)
+        else:
+            torch.save(weights, path)
+
+    def async_artifacts(self, enable: bool = True) -> None:
+        """Layer artefacts through a background writer (artifact_io.ArtifactWriter): save_layer enqueues the device-to-host copy
+        and returns, the next layer's kernels run meanwhile.  Off by default: a caller that reads a file right after save_layer
+        finds it."""
+        self.flush_artifacts()
+        if enable and os.environ.get("MODEGPT_ASYNC_SAVE", "1") != "0":
+            from ..artifact_io import ArtifactWriter
+            self._artifact_writer = ArtifactWriter()
+        else:
+            self._artifact_writer = None
+
+    def flush_artifacts(self) -> None:
+        writer = getattr(self, "_artifact_writer", None)
+        if writer is not None:
+            writer.flush()
 
     @torch.no_grad()
     def convert_model(self, saved_layers_dir: str = "./compressed_output/layers/", suffixes=("mlp", "qk", "vo"),
                       device: str = "cuda"):
         """Swap every layer's Linears for bias-free bf16 Linears built from the saved artefacts."""
         saved_layers_dir = os.path.expandvars(saved_layers_dir)
+        self.flush_artifacts()
 
         def linear_of(w: Tensor) -> nn.Linear:
             lin = nn.Linear(w.shape[1], w.shape[0], bias=False, device=device, dtype=torch.bfloat16)

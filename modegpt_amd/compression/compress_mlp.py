@@ -10,6 +10,7 @@ from torch import Tensor
 from .. import ops
 from ..adapters.model_adapter import MLPComponents, ModelAdapter
 from ..model_utils import dtype_p, local_device
+from ._window import over_layers
 
 logger = logging.getLogger("MoDeGPT")
 
@@ -50,17 +51,20 @@ def compress_weights(comps: MLPComponents, C: Tensor, keep_ratio: float, layer_i
 def compress_nystrom(adapter: ModelAdapter, cov, keep_ratios, target_layers, ridge_lambda=1e-4):
     """Per-layer driver (compress_mlp.py:67-117).  As upstream, the ridge actually used is
     adapter.config.nystrom_ridge; the `ridge_lambda` argument is ignored."""
-    for layer_idx in target_layers:
-        comps = adapter.get_mlp_components(layer_idx)
+    def enqueue(layer_idx):
         # the layer's whole chain (two Cholesky factorisations, selection, gathers, Nystrom solve) enqueues without a host round
         # trip; the not-positive-definite status of both factorisations is read once (adapter.chain_status)
-        with ops.DeferredStatus(local_device()) as status:
-            up_T, down_T, gate_T, rank = compress_weights(comps, cov[layer_idx], keep_ratios[layer_idx], layer_idx=layer_idx,
-                                                          ridge_lambda=adapter.config.nystrom_ridge)
-        (getattr(adapter, "chain_status", None) or (lambda st: st.check()))(status)     # (a duck-typed adapter: read it now)
+        comps = adapter.get_mlp_components(layer_idx)
+        return compress_weights(comps, cov[layer_idx], keep_ratios[layer_idx], layer_idx=layer_idx,
+                                ridge_lambda=adapter.config.nystrom_ridge)
+
+    def retire(layer_idx, result):
+        up_T, down_T, gate_T, rank = result
         logger.info(f"[MLP] Layer {layer_idx}  compressed to rank {rank}")
         weights = {"up": up_T.T, "down": down_T.T}
         if gate_T is not None:
             weights["gate"] = gate_T.T
         adapter.save_layer(output_dir=adapter.config.temp_storage_dir, suffix="mlp", weights=weights,
                            layer_idx=layer_idx)
+
+    over_layers(adapter, list(target_layers), enqueue, retire)      # (CHAIN_WIDTH layers' chains in flight, artefacts in layer order)

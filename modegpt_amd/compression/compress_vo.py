@@ -10,6 +10,7 @@ from torch import Tensor
 from .. import ops
 from ..adapters.model_adapter import ModelAdapter
 from ..model_utils import dtype_p, local_device
+from ._window import over_layers
 
 logger = logging.getLogger("MoDeGPT")
 
@@ -94,19 +95,27 @@ def compress_vo(adapter: ModelAdapter, cov: List[Tensor], keep_ratios=None, slic
     if target_layers is None:
         target_layers = list(range(adapter.n_layers))
     n_heads, head_dim, arch, n_kv = adapter.n_heads, adapter.head_dim, adapter.arch, adapter.n_kv_heads
-    for layer in target_layers:
-        rank_i = vo_rank_rule(head_dim, keep_ratios[layer], arch)
+    ranks = {}
+
+    def enqueue(layer):
+        ranks[layer] = rank_i = vo_rank_rule(head_dim, keep_ratios[layer], arch)
         C = cov[layer].to(device=local_device(), dtype=dtype_p)
         try:
             comps = adapter.get_attn_components(layer)
             W_v, W_o = comps.v_proj.weight, comps.o_proj.weight
         except Exception as e:  # same tolerance as compress_vo.py:47-53
             logger.warning(f"[VO] Layer {layer}: cannot access v_proj/o_proj: {e}")
-            continue
-        with ops.DeferredStatus(local_device()) as status:      # (the eigensolver's convergence flag: read once, by the adapter)
-            V_heads, O_heads = ops.vo_compress(C, W_v.detach().to(local_device()), W_o.detach().to(local_device()), n_heads, n_kv, head_dim,
-                                               rank_i, adapter.config.ridge_vo)
-        (getattr(adapter, "chain_status", None) or (lambda st: st.check()))(status)     # (a duck-typed adapter: read it now)
+            return None
+        # (the eigensolver's convergence flag is read once per layer, by the adapter: over_layers)
+        return ops.vo_compress(C, W_v.detach().to(local_device()), W_o.detach().to(local_device()), n_heads, n_kv, head_dim,
+                               rank_i, adapter.config.ridge_vo)
+
+    def retire(layer, result):
+        if result is None:
+            return
+        V_heads, O_heads = result
         adapter.save_layer(output_dir=adapter.config.temp_storage_dir, suffix="vo",
                            weights={"v_proj": V_heads, "o_proj": O_heads}, layer_idx=layer)
-        logger.info(f"[VO] Compressed layer {layer} to rank {rank_i} per head")
+        logger.info(f"[VO] Compressed layer {layer} to rank {ranks[layer]} per head")
+
+    over_layers(adapter, list(target_layers), enqueue, retire)

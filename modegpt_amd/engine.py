@@ -186,7 +186,7 @@ class TensorAdapter(ModelAdapter):
 
 
 OVERLAP_VO = os.environ.get("MODEGPT_OVERLAP_VO", "1") != "0"
-_VO_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+_VO_STREAMS: Dict[tuple, "torch.cuda.Stream"] = {}
 
 
 def compress_layer(adapter: TensorAdapter, layer_idx: int, covs: Dict[str, torch.Tensor], keep_ratio: float, check: bool = True):
@@ -201,7 +201,12 @@ def compress_layer(adapter: TensorAdapter, layer_idx: int, covs: Dict[str, torch
     # runs on a stream of its own beside the MLP chain, whose Cholesky steps leave most of the chip idle between their GEMMs
     dev = covs["x"].device
     main = torch.cuda.current_stream(dev)
-    side = _VO_STREAMS.setdefault(dev.index, torch.cuda.Stream(device=dev)) if OVERLAP_VO else None
+    side = None
+    if OVERLAP_VO:
+        key = (dev.index, main.cuda_stream)          # (one per caller's stream: two layers' chains stay independent)
+        side = _VO_STREAMS.get(key)
+        if side is None:
+            side = _VO_STREAMS[key] = torch.cuda.Stream(device=dev)
     if side is not None:
         side.wait_stream(main)
         with torch.cuda.stream(side):

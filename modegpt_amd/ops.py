@@ -354,9 +354,11 @@ COV_OVERLAP_SMALL = os.environ.get("MODEGPT_COV_OVERLAP", "1") != "0"
 NYSTROM_OVERLAP = os.environ.get("MODEGPT_NYSTROM_OVERLAP", "1") != "0"   # cross product of the Nystrom refit beside the factorisation of C_kk
 
 
-def _side_stream(device, purpose: str = "cov") -> "torch.cuda.Stream":
+def _side_stream(device, purpose: str = "cov", beside=None) -> "torch.cuda.Stream":
+    """One helper stream per (device, purpose[, the stream it runs beside]): two layers' chains on two streams of the caller's
+    get a helper each and stay independent of one another."""
     dev = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
-    key = (dev, purpose)
+    key = (dev, purpose, None if beside is None else beside.cuda_stream)
     if key not in _SIDE_STREAMS:
         _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
     return _SIDE_STREAMS[key]
@@ -577,7 +579,7 @@ def nystrom_down(Cm: torch.Tensor, idx: torch.Tensor, W_down: torch.Tensor, eps:
             # the gathered cross product on a side stream beside the factorisation of C_kk (independent; the factorisation's
             # 128-column steps leave most of the chip idle between their GEMMs): 36 -> 27 ms for the two at Llama-3-8B shapes
             main = torch.cuda.current_stream(Cm.device)
-            side = _side_stream(Cm.device, "nystrom")
+            side = _side_stream(Cm.device, "nystrom", beside=main)
             side.wait_stream(main)                       # (inputs and workspace were produced / allocated on `main`)
             fork, join = torch.cuda.Event(), torch.cuda.Event()
             fork.record(main)                            # materialise the HIP events; the library re-records them

@@ -113,6 +113,7 @@ def main(trial=None, config: Optional[CompressionConfig] = None):
     model, tokenizer = reload_compressed_model(config.model)
     adapter = ModelAdapter.from_model(model=model, tokenizer=tokenizer)
     adapter.config = config
+    adapter.async_artifacts(True)       # layer artefacts through a background writer; convert_model / the gather flush it
     if rank == 0:   # (every rank holds the model; the metric is rank 0's business)
         adapter.metrics["baseline-ppl"] = compute_perplexity(model, tokenizer, dataset=config.dataset, adapter=adapter)
         logger.info(f"Baseline ppl: {adapter.metrics['baseline-ppl']}")
@@ -127,6 +128,7 @@ def main(trial=None, config: Optional[CompressionConfig] = None):
     # latter written by rank 0 alone: sharding.gather_layer_artifacts).  One barrier closes the collective phase -- no rank
     # is still packing / writing when rank 0 starts reading -- and the process group is released here, so that the other
     # ranks do not sit in a collective (and its timeout) while rank 0 converts, saves and evaluates.
+    adapter.flush_artifacts()
     sharding.finalize()
     if rank != 0:  # rank 0 alone writes the checkpoint
         return None

@@ -168,6 +168,9 @@ def gather_layer_artifacts(adapter, chunk: Sequence[int], mine: Sequence[int], r
     rms = list(rotary_masks or [])
     if world == 1:
         return rms
+    flush = getattr(adapter, "flush_artifacts", None)
+    if flush is not None:
+        flush()                             # (a background artefact writer: the files are read back below)
     d = os.path.expandvars(adapter.config.temp_storage_dir)
     dev = "cuda" if torch.cuda.is_available() else "cpu"
     records = []

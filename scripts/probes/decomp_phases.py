@@ -121,3 +121,34 @@ if "async" in which:
         print("... and check_chains() did NOT raise: BUG")
     except torch.linalg.LinAlgError as e:
         print("... check_chains() raised LinAlgError:", str(e)[:110])
+if "pair" in which:
+    # two (three, four) layers' chains: back to back on one stream against side by side on a stream each.  A chain is a string of short
+    # dependent kernels between large GEMMs; another layer's chain is independent of it.
+    import time
+    from modegpt_amd import engine
+    shape = engine.SHAPES["llama-3-8b"]
+    nl = 4
+    ws = {i: engine.make_layer_weights(shape, 1234 + i, dev) for i in range(nl)}
+    batch = engine.make_activation_batch(shape, 8192, seed=5, device=dev)
+    covs = engine.new_covs(shape, dev)
+    engine.accumulate(covs, batch, shape)
+    engine.finalize(covs, 4)
+    ad = engine.TensorAdapter(shape, ws)
+    engine.compress_layer(ad, 0, covs, 0.7)                     # warm-up (checked)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nl)]
+    main = torch.cuda.current_stream(dev)
+    for k in (1, 2, 3, 4):
+        for rep in range(2):
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(main)
+            for i in range(k):
+                streams[i].wait_stream(main)
+                with torch.cuda.stream(streams[i]):
+                    engine.compress_layer(ad, i, covs, 0.7, check=False)
+            for i in range(k):
+                main.wait_stream(streams[i])
+            e1.record(main)
+            torch.cuda.synchronize()
+            ad.check_chains()
+        print(f"{k} chain(s) side by side: {e0.elapsed_time(e1):.1f} ms = {e0.elapsed_time(e1) / k:.1f} ms per layer")

@@ -809,3 +809,51 @@ def test_opt_fixture_checkpoint_on_the_gpu_matches_the_reference_modeling(dev, t
     got = opt_drive(m, ids.to(dev)).cpu().numpy()
     want = z["logits_reference"]
     assert np.abs(got - want).max() <= 3e-2 * np.abs(want).max(), float(np.abs(got - want).max())
+
+
+def test_layers_chains_side_by_side_and_background_writer_give_the_same_artefacts(dev, tmp_path, monkeypatch):
+    """compression/_window.over_layers (two layers' chains in flight, a stream each) + artifact_io.ArtifactWriter against the
+    reference's order (one layer after the other, torch.save before the next starts): every artefact file bit-identical, and a
+    statistic that is not positive definite still raises LinAlgError -- from the window, with the other chain joined."""
+    from modegpt_amd.adapters.CompressionConfig import CompressionConfig
+    from modegpt_amd.adapters.model_adapter import ModelAdapter
+    from modegpt_amd.calibration import load_calibs
+    from modegpt_amd.compression import _window
+    from modegpt_amd.compression.compress_mlp import compress_nystrom
+    from modegpt_amd.compression.compress_vo import compress_vo
+    transformers = pytest.importorskip("transformers")
+    torch.manual_seed(0)
+    cfg = transformers.LlamaConfig(hidden_size=128, intermediate_size=320, num_hidden_layers=5, num_attention_heads=4,
+                                   num_key_value_heads=2, head_dim=32, vocab_size=211, max_position_embeddings=64)
+    model = transformers.LlamaForCausalLM(cfg).to(dev).to(torch.bfloat16).eval()
+    ad = ModelAdapter.from_model(model, None)
+    layers = list(range(5))
+    keep = [0.7, 0.6, 0.8, 0.7, 0.65]
+    files = {}
+    for mode, width in (("reference order", 1), ("window", 2), ("window of three", 3)):
+        out = tmp_path / mode.replace(" ", "_")
+        ad.config = CompressionConfig(temp_storage_dir=str(out), dataset="synthetic", calib_size=8, calibs_batch_size=4,
+                                      nystrom_ridge=1e-4, ridge_vo=1e-5)
+        if mode == "reference order":
+            cov_mlp, _, _, cov_x, _ = load_calibs(ad, n_samples=8, batch_size=4, dataset="synthetic", target_layers=layers)
+        monkeypatch.setattr(_window, "CHAIN_WIDTH", width)
+        ad.async_artifacts(width > 1)
+        compress_nystrom(ad, cov_mlp, keep, layers)
+        compress_vo(ad, cov_x, keep, target_layers=layers)
+        ad.flush_artifacts()
+        ad.async_artifacts(False)
+        names = sorted(os.listdir(out))
+        assert names == sorted(f"layer_{i}_{s}" for i in layers for s in ("mlp", "vo")), names
+        files[mode] = {n: torch.load(out / n, map_location="cpu") for n in names}
+    for mode in ("window", "window of three"):
+        for n, want in files["reference order"].items():
+            got = files[mode][n]
+            assert set(got) == set(want)
+            for k in want:
+                assert got[k].shape == want[k].shape and torch.equal(got[k], want[k]), (mode, n, k)
+    bad = [c.clone() for c in cov_mlp]
+    bad[3][5, 5] = -1.0
+    monkeypatch.setattr(_window, "CHAIN_WIDTH", 2)
+    with pytest.raises(torch.linalg.LinAlgError):
+        compress_nystrom(ad, bad, keep, layers)
+    torch.cuda.synchronize()

@@ -401,3 +401,83 @@ def test_gpu_tensor_without_the_engine_is_an_error_not_a_silent_torch_run(monkey
     before = ca.PATH_CALLS["torch"]
     out = ca._rope_gather(x, cos, sin, torch.arange(8).reshape(1, 8).repeat(4, 1), 4, 4, 16)     # CPU: portable path, no error
     assert out.shape == (1, 4, 3, 8) and ca.PATH_CALLS["torch"] == before + 1
+
+
+def test_artifact_writer_files_are_in_place_after_flush_and_errors_surface(tmp_path):
+    """artifact_io.ArtifactWriter (save_layer's torch.save on a worker thread): same file names and payload as the synchronous
+    save, nothing half-written under the final name, the worker's error raised by flush()."""
+    from modegpt_amd.artifact_io import ArtifactWriter
+    w = ArtifactWriter()
+    want = {}
+    for i in range(5):
+        t = {"up": torch.randn(7 + i, 5).to(torch.bfloat16), "down": torch.randn(5, 7 + i).to(torch.bfloat16).T}
+        want[i] = t
+        w.submit(str(tmp_path / f"layer_{i}_mlp"), t)
+    w.flush()
+    assert w.pending() == 0
+    assert sorted(os.listdir(tmp_path)) == [f"layer_{i}_mlp" for i in range(5)]        # (no temporary names left)
+    for i, t in want.items():
+        got = torch.load(tmp_path / f"layer_{i}_mlp")
+        assert set(got) == {"up", "down"} and all(torch.equal(got[k], t[k]) for k in t)
+    w.submit(str(tmp_path / "no_such_dir" / "layer_0_mlp"), want[0])
+    with pytest.raises(RuntimeError, match="writing a layer artefact failed"):
+        w.flush()
+    w.submit(str(tmp_path / "layer_9_mlp"), want[0])      # the writer survives its error
+    w.flush()
+    assert os.path.exists(tmp_path / "layer_9_mlp")
+
+
+def test_save_layer_is_synchronous_unless_the_run_asks_for_the_writer(tmp_path, monkeypatch):
+    transformers = pytest.importorskip("transformers")
+    from modegpt_amd.adapters.model_adapter import ModelAdapter
+    cfg = transformers.LlamaConfig(hidden_size=64, intermediate_size=160, num_hidden_layers=2, num_attention_heads=4,
+                                   num_key_value_heads=2, head_dim=16, vocab_size=97, max_position_embeddings=64)
+    ad = ModelAdapter.from_model(transformers.LlamaForCausalLM(cfg).to(torch.bfloat16), None)
+    mk = lambda r, c: torch.randn(r, c).to(torch.bfloat16)      # noqa: E731
+    ad.save_layer(str(tmp_path), "mlp", {"up": mk(100, 64)}, 0)
+    assert os.path.exists(tmp_path / "layer_0_mlp")             # default: in place on return
+    ad.async_artifacts(True)
+    arts = {}
+    for i in range(2):
+        arts[i] = {"mlp": {"up": mk(100 + i, 64), "gate": mk(100 + i, 64), "down": mk(64, 100 + i)},
+                   "qk": {"q_proj": mk(4 * 8, 64), "k_proj": mk(2 * 8, 64)}, "vo": {"v_proj": mk(2 * 9, 64), "o_proj": mk(64, 4 * 9)}}
+        for suffix, wts in arts[i].items():
+            ad.save_layer(str(tmp_path), suffix, wts, i)
+    ad.convert_model(saved_layers_dir=str(tmp_path), device="cpu")      # flushes the writer before it reads
+    for i in range(2):
+        assert torch.equal(ad.get_mlp_components(i).up_proj.weight, arts[i]["mlp"]["up"])
+        assert torch.equal(ad.get_attn_components(i).o_proj.weight, arts[i]["vo"]["o_proj"])
+    monkeypatch.setenv("MODEGPT_ASYNC_SAVE", "0")
+    ad.async_artifacts(True)
+    assert ad._artifact_writer is None
+
+
+def test_layer_window_keeps_the_reference_order_on_one_stream(monkeypatch):
+    """compression/_window.over_layers without a GPU: one chain at a time, status handed to the adapter before the layer is
+    retired, layers in order (the multi-stream path is covered by the -m gpu end-to-end tests, which compare with the oracle)."""
+    from modegpt_amd.compression import _window as W
+    log = []
+
+    class Status:
+        def __init__(self, dev):
+            pass
+
+        def __enter__(self):
+            log.append("begin")
+            return self
+
+        def __exit__(self, *exc):
+            log.append("end")
+            return False
+
+        def check(self):
+            log.append("check")
+
+    monkeypatch.setattr(W.ops, "DeferredStatus", Status)
+    monkeypatch.setattr(W, "local_device", lambda: torch.device("cpu"))
+
+    class Adapter:
+        pass
+
+    W.over_layers(Adapter(), [3, 5], lambda i: log.append(f"enqueue {i}") or i * 10, lambda i, r: log.append(f"retire {i} {r}"))
+    assert log == ["begin", "enqueue 3", "end", "check", "retire 3 30", "begin", "enqueue 5", "end", "check", "retire 5 50"]
