@@ -9,8 +9,10 @@ from modegpt_amd import ops
 dev = torch.device("cuda:0"); F64 = torch.float64
 g = torch.Generator().manual_seed(int(sys.argv[1]) if len(sys.argv) > 1 else 7)
 worst, routes, bad, worst_ratio, cols_out, worst_bound = 0.0, {}, 0, 0.0, 0, 0.0
+TMAX = int(sys.argv[3]) if len(sys.argv) > 3 else 6000          # python i8_fuzz.py <seed> <cases> [max tokens] [max width / 128]
+NMAX = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 120):
-    T = int(torch.randint(1, 6000, (1,), generator=g)); n = 128 * int(torch.randint(1, 5, (1,), generator=g))
+    T = int(torch.randint(1, TMAX, (1,), generator=g)); n = 128 * int(torch.randint(1, NMAX + 1, (1,), generator=g))
     kind = int(torch.randint(0, 9, (1,), generator=g))
     z = torch.randn(T, n, generator=g)
     if kind == 1: z = z * (torch.rand(T, n, generator=g) < torch.rand(1, generator=g) * 0.5 + 0.01)
