@@ -157,7 +157,7 @@ def step(shape, adapter, layer_idx, batches, keep, n_texts, timer=None):
 
 
 class Pipeline:
-    """Steps back to back with the decomposition chains of the previous `depth` layers on high-priority side streams (one each)
+    """Steps back to back with the decomposition chains of the previous `depth` layers on side streams (one each)
     while the next layer's covariance kernels run on the caller's stream.  A chain is latency-bound (191 dependent
     single-workgroup Cholesky steps between small GEMMs) and leaves most of the chip idle between its large GEMMs; the covariance
     of the next layer does not depend on it, and neither does another layer's chain: two chains side by side fill each other's
@@ -170,7 +170,9 @@ class Pipeline:
         self.depth = depth if enabled else 1
         dev = batches[0]["h"].device
         self.main = torch.cuda.current_stream(dev)
-        self.sides = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(self.depth)] if enabled else []
+        # (same priority as the caller's stream: with high-priority side streams every short chain kernel overtakes the covariance
+        #  launch that is ready next, and the loop is 1.5 % slower -- 962 / 956 against 946 / 944 ms per step on one box)
+        self.sides = [torch.cuda.Stream(device=dev) for _ in range(self.depth)] if enabled else []
         self.pending = []
         self.done = []          # (layer, tensors, mask, covs) in layer order
 
@@ -189,14 +191,14 @@ class Pipeline:
             self.done.append((li, tensors, mask, covs))
         self.pending = []
 
-    def submit(self, layer_idx):
+    def submit(self, layer_idx, last=False):
         shape, _, batches, _, n_texts, timer = self.a
         covs = accumulate_layer(shape, batches, n_texts, timer)      # enqueued on the main stream (the host runs ~2 layers ahead)
         ev = torch.cuda.Event()
         ev.record(self.main)
-        if len(self.pending) == self.depth:
+        if len(self.pending) == self.depth or (last and self.pending):
             self._finish()                                            # the previous layers' chains, beside this covariance
-        self.pending.append((layer_idx, covs, ev))
+        self.pending.append((layer_idx, covs, ev))                    # (last: no covariance follows -- nothing is held back for it)
 
     def drain(self):
         if self.pending:
@@ -386,7 +388,7 @@ def timed_steps(shape, adapter, layer_ids, batches, keep, n_texts, timer=None, p
     t0 = time.perf_counter()
     pipe = Pipeline(shape, adapter, batches, keep, n_texts, timer, enabled=pipelined, depth=depth)
     for li in layer_ids:
-        pipe.submit(li)
+        pipe.submit(li, last=li == layer_ids[-1])
     outs = pipe.drain()
     adapter.check_chains()          # the layers' Cholesky / eigensolver statuses, read once for all of them
     torch.cuda.synchronize()
@@ -432,7 +434,7 @@ def main():
     t0 = time.perf_counter()
     pipe = Pipeline(shape, adapter, batches, a.keep, n_texts, timer, enabled=pipelined, depth=a.chain_depth)
     for i in range(a.steps):
-        pipe.submit(first + a.warmup + i)
+        pipe.submit(first + a.warmup + i, last=i == a.steps - 1)
     records, last, done = [], None, []
     for li, tensors, mask, covs in pipe.drain():
         records.append(sharding.pack_layer(li, {k: tensors.get(k) for k in sharding.TENSOR_ORDER}, mask))
