@@ -423,9 +423,18 @@ def main():
     adapter = engine.TensorAdapter(shape, layers)
     ridges = dict(engine.RECIPE_RIDGES)
 
+    warm, gather_buffers = None, None
     for i in range(a.warmup):
-        step(shape, adapter, first + i, batches, a.keep, n_texts)
+        warm = step(shape, adapter, first + i, batches, a.keep, n_texts)
     adapter.check_chains()
+    if warm is not None:
+        # the gather's one-time costs belong to the warm-up too: RCCL sets up its all-gather channels on the first call, and the
+        # send / receive buffers of the timed gather (K records per rank, ~0.34 GB each, x world on the receiving side: 54 GB at
+        # 8 ranks) come out of the caching allocator instead of a fresh hipMalloc inside the timed region
+        rec = sharding.pack_layer(first + a.warmup - 1, {k: warm[0].get(k) for k in sharding.TENSOR_ORDER}, warm[1])
+        sharding.allgather_records([rec], 1, world)
+        gather_buffers = sharding.gather_buffers(a.steps, world, rec.numel() + 64, dev)    # (every layer: same shapes, same keep ratio)
+        del rec, warm
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -441,7 +450,7 @@ def main():
         last = (li, tensors, mask, covs)
         done.append((li, tensors, mask, None))          # (compressed tensors of every timed layer: compared with the f64 leg's below)
     adapter.check_chains()                               # the layers' Cholesky / eigensolver statuses, read once for all of them
-    gathered = sharding.allgather_records(records, a.steps, world)  # the single RCCL all-gather (no-op copy at N=1)
+    gathered = sharding.allgather_records(records, a.steps, world, buffers=gather_buffers)  # the single RCCL all-gather (no-op copy at N=1)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

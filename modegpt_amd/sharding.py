@@ -135,22 +135,44 @@ def unpack_layer(rec: torch.Tensor) -> Tuple[int, Dict[str, torch.Tensor], Optio
     return layer_idx, out, mask
 
 
-def allgather_records(records: List[torch.Tensor], per_rank: int, world: int, force_collective: bool = False) -> List[torch.Tensor]:
+def gather_buffers(per_rank: int, world: int, record_words: int, device) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """Send / receive buffers for allgather_records, allocated ahead of time (bench.py: outside its timed region -- the receive
+    side is world x per_rank x 0.34 GB at Llama-3-8B shapes).  record_words: an upper bound of a record's length in int16 words."""
+    words = per_rank * (4 + (record_words + 3) // 4 * 4)
+    send = torch.empty(words, dtype=torch.int16, device=device)
+    recv = torch.empty(world * words, dtype=torch.int16, device=device) if world > 1 else None
+    return send, recv
+
+
+def allgather_records(records: List[torch.Tensor], per_rank: int, world: int, force_collective: bool = False,
+                      buffers: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None) -> List[torch.Tensor]:
     """The single data-path collective: every rank contributes `per_rank` records padded to a common stride.
-    force_collective runs the all-gather even at world == 1 (lets a 1-GPU box exercise the RCCL code path)."""
+    force_collective runs the all-gather even at world == 1 (lets a 1-GPU box exercise the RCCL code path).
+    buffers: gather_buffers() of the caller's, used when they are large enough for the stride the ranks agree on."""
     dev = records[0].device if records else torch.device("cuda" if torch.cuda.is_available() else "cpu")
     longest = torch.tensor([max([r.numel() for r in records] + [0])], dtype=torch.int64, device=dev)
     if world > 1 or force_collective:
         dist.all_reduce(longest, op=dist.ReduceOp.MAX)  # 8-byte size agreement, not a data-path exchange
     stride = (int(longest.item()) + 3) // 4 * 4          # rows stay 8-byte aligned for the int64 header views
     PRE = 4                                                 # words 0..3: slot-in-use flag (+ alignment pad)
-    send = torch.zeros(per_rank, PRE + stride, dtype=torch.int16, device=dev)
+    words = per_rank * (PRE + stride)
+    own_send, own_recv = buffers if buffers is not None else (None, None)
+    if own_send is not None and own_send.numel() >= words and own_send.device == dev:
+        send = own_send[:words].view(per_rank, PRE + stride)
+        send[:, :PRE] = 0
+    else:
+        send = torch.empty(per_rank, PRE + stride, dtype=torch.int16, device=dev)
+        send[:, :PRE] = 0
     for i, r in enumerate(records):
         send[i, 0] = 1
         send[i, PRE:PRE + r.numel()] = r
+        send[i, PRE + r.numel():] = 0                      # (padding up to the common stride: defined bytes on the wire)
     if world == 1 and not force_collective:
         return [send[i, PRE:] for i in range(per_rank) if send[i, 0] == 1]
-    recv = torch.empty(world * per_rank, PRE + stride, dtype=torch.int16, device=dev)
+    if own_recv is not None and own_recv.numel() >= world * words and own_recv.device == dev:
+        recv = own_recv[:world * words].view(world * per_rank, PRE + stride)
+    else:
+        recv = torch.empty(world * per_rank, PRE + stride, dtype=torch.int16, device=dev)
     # byte views: every backend moves uint8 (gloo has no int16)
     dist.all_gather_into_tensor(recv.view(torch.uint8), send.view(torch.uint8))
     used = recv[:, 0].cpu()

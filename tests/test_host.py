@@ -481,3 +481,18 @@ def test_layer_window_keeps_the_reference_order_on_one_stream(monkeypatch):
 
     W.over_layers(Adapter(), [3, 5], lambda i: log.append(f"enqueue {i}") or i * 10, lambda i, r: log.append(f"retire {i} {r}"))
     assert log == ["begin", "enqueue 3", "end", "check", "retire 3 30", "begin", "enqueue 5", "end", "check", "retire 5 50"]
+
+
+def test_allgather_records_uses_the_callers_buffers_when_they_fit():
+    from modegpt_amd import sharding as S
+    recs = [torch.arange(10 + 3 * i, dtype=torch.int16) + 100 * i for i in range(3)]
+    send, recv = S.gather_buffers(4, 1, 20, "cpu")
+    assert recv is None and send.numel() == 4 * (4 + 20)
+    send.fill_(-1)                                                    # stale content of an earlier use
+    out = S.allgather_records(recs, 4, 1, buffers=(send, recv))
+    assert len(out) == 3 and all(torch.equal(o[:r.numel()], r) and not o[r.numel():].any() for o, r in zip(out, recs))
+    assert out[0].untyped_storage().data_ptr() == send.untyped_storage().data_ptr()
+    small = S.gather_buffers(4, 1, 4, "cpu")                          # too small for these records: ignored
+    out2 = S.allgather_records(recs, 4, 1, buffers=small)
+    assert all(torch.equal(a, b) for a, b in zip(out, out2))
+    assert out2[0].untyped_storage().data_ptr() != small[0].untyped_storage().data_ptr()
