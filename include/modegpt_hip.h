@@ -26,14 +26,15 @@
 extern "C" {
 #endif
 
-#define MDG_ABI_VERSION 7 /* 2: w_dtype on mdg_nystrom_down / mdg_vo_compress, mdg_rope_gather added; 3: mdg_cov_accum_i8_stats added;
+#define MDG_ABI_VERSION 8 /* 2: w_dtype on mdg_nystrom_down / mdg_vo_compress, mdg_rope_gather added; 3: mdg_cov_accum_i8_stats added;
                              4: mdg_cov_accum_i8 chooses its route on the device (route_counts argument, no host synchronisation);
                                 mdg_comm_* / mdg_allgather_layers added;
                              5: mdg_potrs_lower takes a workspace (mdg_potrs_lower_ws_bytes);
                              6: mdg_cov_accum_i8_multi added (several statistics in one int8 launch); the int8 workspace layout changed;
                              7: the int8 route is derived from a per-call error bound, single columns can leave the int8 path for an fp64
                                 column kernel (route_counts has 4 entries, mdg_cov_accum_i8_route added, workspace layout changed);
-                                mdg_shutdown and mdg_deferred_status_* added */
+                                mdg_shutdown and mdg_deferred_status_* added;
+                             8: mdg_cov_i8_set_tolerance / mdg_cov_i8_tolerance, mdg_nystrom_down_overlapped added */
 
 enum mdg_status {
   MDG_OK = 0,
@@ -143,6 +144,14 @@ int mdg_cov_accum_i8_stats(const void* ws, int64_t n_tokens, int64_t n_feat, uns
  * output pointer may be NULL.  Copies device -> host on `stream` and synchronises it: tests and measurements only. */
 int mdg_cov_accum_i8_route(int count, const mdg_cov_problem* problems, int stat, const void* ws, int* planes, int* n_columns,
                            int* columns, double* bound, void* stream);
+/* The accuracy / speed dial of the int8 route: one factor f in [1, 1e6] on both thresholds of the route (SQ_P <= f 1e-12,
+ * X_P <= f tau_x), process-wide, read when a call is enqueued.  f = 1 (the default) is the guarantee stated above.  A caller who
+ * accepts f times that bound gets five planes where the default takes six -- SiLU-gated MLP activations have X_5 = 3.7e-10, so
+ * f >= 37 moves them to five planes: measured 3.8e-12 instead of 8e-14, the sigma_mlp launch 22 instead of 37 ms -- and fewer
+ * columns on the fp64 column kernel.  Every call still computes and reports its own bound (mdg_cov_accum_i8_route), so what was
+ * guaranteed for a given input is known, whatever f.  Not in the reference (plain fp64 there); off unless asked for. */
+int mdg_cov_i8_set_tolerance(double factor);
+double mdg_cov_i8_tolerance(void);
 /* Up to 4 statistics of ONE calibration batch (the four hooks of a layer) through the int8 digit-plane kernels with ONE
  * persistent product launch: the tiles of all statistics share one static tile schedule, so the small ones fill what the large
  * one's last round leaves idle instead of ending launches of their own, and one route -- the deepest any statistic on the int8 path

@@ -50,6 +50,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include <atomic>
 
 namespace mdg {
 namespace {
@@ -363,6 +364,10 @@ __global__ __launch_bounds__(256) void i8_split_vec_kernel(const bf16_t* x, int6
 // count -- the smallest number of nonzero elements any column of the statistic has:
 // guaranteed <= TAU_SQ + tau_x <= 1.1e-11 for any input, and <= 1e-12 measured also on the uncorrelated data of a short or sparse call.
 constexpr double TAU_SQ = 1e-12, TAU_X_MIN = 1e-12, TAU_X_MAX = 1e-11, TAU_X_TOKENS = 1024.0;
+// mdg_cov_i8_set_tolerance: one factor on both thresholds (1 = the figures above).  A caller who accepts `f` times the guarantee
+// gets five planes where the default asks for six (SiLU-gated activations: X_5 = 3.7e-10, i.e. f >= 37); the bound every call
+// computes (RouteOut::sq, ::x) says what was guaranteed either way.
+static std::atomic<double> g_i8_tolerance{1.0};
 __host__ __device__ inline double tau_x_of(int64_t tokens) {
   return fmin(TAU_X_MAX, fmax(TAU_X_MIN, TAU_X_MIN * ((double)tokens / TAU_X_TOKENS)));
 }
@@ -421,7 +426,7 @@ struct RouteScratch {            // zeroed with the statistics before every call
 // ~10 fp64 square roots per column are spread over the chip and the common case (nothing has to leave) ends there.
 __global__ __launch_bounds__(ROUTE_THREADS) void i8_route_kernel(const unsigned long long* __restrict__ stats, int* emax, int n, int64_t n_tokens,
                                                                  double* __restrict__ vals, RoutePartial* partial, RouteScratch* scratch,
-                                                                 int* flag, RouteOut* out, int* route_counts) {
+                                                                 int* flag, RouteOut* out, int* route_counts, double tolerance) {
   __shared__ unsigned long long group_max[NVAL][64];   // per quantity: maxima of the 64 column classes j % 64 (bit patterns of doubles >= 0)
   __shared__ Top2 wave_top[ROUTE_THREADS / 64][NVAL];
   __shared__ Top2 top[NVAL];
@@ -562,7 +567,7 @@ __global__ __launch_bounds__(ROUTE_THREADS) void i8_route_kernel(const unsigned 
   for (int i = 0; i < NVAL; i++) fl[i] = floor_of[i];
   bool top_valid = true;
   for (int P = 5; P <= 6; P++) {
-    if (n > 64 && route_violation(fl, P, tau_x) > 1.0) continue;   // hopeless for this P (uniform: every thread computes the same)
+    if (n > 64 && route_violation(fl, P, tau_x) > tolerance) continue;   // hopeless for this P (uniform: every thread computes the same)
     n_out = n_forced;
     for (;;) {
       if (!top_valid) {             // (the first look uses pass 1's result)
@@ -598,7 +603,7 @@ __global__ __launch_bounds__(ROUTE_THREADS) void i8_route_kernel(const unsigned 
           A[i] = top[i].m1;
         }
         decision = -1;
-        if (route_violation(A, P, tau_x) <= 1.0) {
+        if (route_violation(A, P, tau_x) <= tolerance) {
           out->planes = P;
           out->n_out = n_out;
           route_terms(A, P, out->sq, out->x);
@@ -1604,7 +1609,8 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
       RoutePartial* partial = (RoutePartial*)(vals + (size_t)NVAL * n);
       RouteScratch* scratch = (RouteScratch*)(stats + (size_t)NSTAT * n);      // (inside the region zeroed above)
       hipLaunchKernelGGL(i8_route_kernel, dim3((unsigned)ceil_div(n, ROUTE_THREADS)), dim3(ROUTE_THREADS), 0, st, stats, emax, n,
-                         n_tokens, vals, partial, scratch, pflag + i, (RouteOut*)((char*)ws + pw[i].route), route_counts);
+                         n_tokens, vals, partial, scratch, pflag + i, (RouteOut*)((char*)ws + pw[i].route), route_counts,
+                         g_i8_tolerance.load(std::memory_order_relaxed));
     }
     hipLaunchKernelGGL(i8_clear_columns_kernel, dim3(ROUTE_JMAX, (unsigned)std::min(64, (nk + 3) / 4)), dim3(256), 0, st,
                        (const RouteOut*)((char*)ws + pw[i].route), pflag + i, emax, planes, zmask, n, nk);
@@ -1797,6 +1803,15 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
   const mdg_cov_problem q = single_problem(x, n_tokens, n_feat, ld, sigma, ld_sigma);
   return mdg_cov_accum_i8_multi(1, &q, ws, ws_bytes, used_i8, route_counts, ev_start, ev_stop, stream);
 }
+
+extern "C" int mdg_cov_i8_set_tolerance(double factor) {
+  MDG_CLEAR();
+  MDG_CHECK_ARG(factor >= 1.0 && factor <= 1e6, "mdg_cov_i8_set_tolerance: factor %g outside [1, 1e6] (1 = guaranteed <= 1.1e-11)", factor);
+  g_i8_tolerance.store(factor, std::memory_order_relaxed);
+  return MDG_OK;
+}
+
+extern "C" double mdg_cov_i8_tolerance(void) { return g_i8_tolerance.load(std::memory_order_relaxed); }
 
 extern "C" int mdg_cov_accum_i8_route(int count, const mdg_cov_problem* problems, int stat, const void* ws, int* planes, int* n_columns,
                                       int* columns, double* bound, void* stream) {

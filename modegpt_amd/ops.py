@@ -234,6 +234,16 @@ def _route_counters(device) -> torch.Tensor:
     return _ROUTE_COUNTERS[key]
 
 
+def set_i8_tolerance(factor: float) -> float:
+    """The accuracy / speed dial of the int8 covariance route (mdg_cov_i8_set_tolerance): `factor` >= 1 on both thresholds of the
+    per-call error bound; 1 = guaranteed <= 1.1e-11 of sqrt(sigma_ii sigma_jj) (the default).  Returns the previous factor.  The
+    environment variable MODEGPT_I8_TOLERANCE sets it when the library is first loaded."""
+    lib = _lib.load()
+    prev = float(lib.mdg_cov_i8_tolerance())
+    check(lib.mdg_cov_i8_set_tolerance(float(factor)), "mdg_cov_i8_set_tolerance")
+    return prev
+
+
 def i8_route_counts(device=None, reset: bool = False) -> dict:
     """How the int8-route requests on `device` (default: the current one) were served so far, counted on the device by the
     kernels that ran: {"i8_5", "i8_6", "fallback_f64"} count statistics, "fp64_columns" the single columns the route handed to

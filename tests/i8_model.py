@@ -103,9 +103,9 @@ def entry_bound(a, rho, P):
     return b + rho[:, None] + rho[None, :] + rho[:, None] * rho[None, :]
 
 
-def route(st, jmax=JMAX, sort=True, tokens=1 << 20):
+def route(st, jmax=JMAX, sort=True, tokens=1 << 20, tolerance=1.0):
     """-> (planes: 5, 6 or 0 = fp64 kernel for the whole statistic; sorted list of columns for the fp64 column kernel;
-    (SQ, X) of the columns that stay)."""
+    (SQ, X) of the columns that stay).  tolerance: mdg_cov_i8_set_tolerance's factor on both thresholds."""
     a, rho = alphas(st)
     tau_x = tau_x_of(tokens)
     vals = np.concatenate([a, rho[None]])            # 7 quantities per column
@@ -114,7 +114,7 @@ def route(st, jmax=JMAX, sort=True, tokens=1 << 20):
         # prefilter: whatever jmax columns leave, the (jmax + 1)-th largest of every quantity stays
         if n > jmax:
             floor = np.partition(vals, n - 1 - jmax, axis=1)[:, n - 1 - jmax]
-            if violation(floor[:6], floor[6], P, tau_x) > 1.0:
+            if violation(floor[:6], floor[6], P, tau_x) > tolerance:
                 continue
         live = np.ones(n, bool)
         out = []
@@ -126,7 +126,7 @@ def route(st, jmax=JMAX, sort=True, tokens=1 << 20):
             m2[np.arange(7), arg1] = -1.0
             max2 = np.maximum(m2.max(axis=1), 0.0)
             max1 = np.maximum(max1, 0.0)
-            if violation(max1[:6], max1[6], P, tau_x) <= 1.0:
+            if violation(max1[:6], max1[6], P, tau_x) <= tolerance:
                 return P, (sorted(out) if sort else out), terms(max1[:6], max1[6], P)
             if len(out) == jmax or not live.any():
                 break
@@ -158,7 +158,7 @@ def product(d, E, P):
     return acc * sc[:, None] * sc[None, :]
 
 
-def route_of(X, chunk=1024):
+def route_of(X, chunk=1024, tolerance=1.0):
     """Route of a whole bf16 activation matrix (torch CPU tensor [T, n]): the statistics are taken in column chunks (int64
     temporaries of a 32768 x 14336 batch would not fit), the decision over all columns.  -> dict like ops.cov_accum_i8's
     route_info: planes, columns (in the order the greedy took them), sq, x, bound."""
@@ -169,5 +169,5 @@ def route_of(X, chunk=1024):
         qs.append(st["q"]); rs.append(st["rounded"]); ns.append(st["nnz"])
     st = {"q": np.concatenate(qs, axis=1), "rounded": np.concatenate(rs), "nnz": np.concatenate(ns)}
     nz = st["nnz"][st["nnz"] > 0]
-    planes, cols, (sq, x) = route(st, sort=False, tokens=min(X.shape[0], int(nz.min()) if nz.size else X.shape[0]))
+    planes, cols, (sq, x) = route(st, sort=False, tokens=min(X.shape[0], int(nz.min()) if nz.size else X.shape[0]), tolerance=tolerance)
     return {"planes": planes, "columns": cols, "sq": sq, "x": x, "bound": sq + x, "stats": st}

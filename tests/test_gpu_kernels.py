@@ -567,15 +567,43 @@ def entry_err(S, ref):
     return (((S - ref).abs() / (d[:, None] * d[None]))[low]).max().item()
 
 
-def check_route(info, X):
+def check_route(info, X, tolerance=1.0):
     """The device's route decision against the host model (tests/i8_model.py) on the same bf16 data: planes, the columns handed
     to the fp64 column kernel IN THE ORDER the greedy took them, and both parts of the bound."""
     from tests import i8_model as M
-    want = M.route_of(X.cpu())
+    want = M.route_of(X.cpu(), tolerance=tolerance)
     assert (info["planes"], info["columns"]) == (want["planes"], want["columns"]), (info, {k: want[k] for k in ("planes", "columns", "sq", "x")})
     if want["planes"]:
         assert abs(info["sq"] - want["sq"]) <= 1e-9 * want["sq"] + 1e-300 and abs(info["x"] - want["x"]) <= 1e-9 * want["x"] + 1e-300
     return want
+
+
+def test_cov_i8_tolerance_dial(ops, dev):
+    """mdg_cov_i8_set_tolerance: one factor on both thresholds of the route.  SiLU-gated columns need six planes at the default
+    and take five at x64 (fewer plane pairs, a looser but still COMPUTED and respected bound); the device's decision equals the
+    host model's at that factor; the factor is process-wide state and goes back to 1."""
+    gen = torch.Generator().manual_seed(31)
+    T, n = 24576, 256
+    X = (torch.nn.functional.silu(torch.randn(T, n, generator=gen)) * torch.randn(T, n, generator=gen)).to(torch.bfloat16)
+    ref = torch.zeros(n, n, dtype=F64)
+    O.cov_accum_tokens(ref, X)
+    assert ops.set_i8_tolerance(1.0) == 1.0
+    got = {}
+    try:
+        for factor in (1.0, 64.0):
+            ops.set_i8_tolerance(factor)
+            S = torch.zeros(n, n, dtype=F64, device=dev)
+            info = {}
+            planes = ops.cov_accum_i8(S, X.to(dev), route_info=info)
+            check_route(info, X, tolerance=factor)
+            err = entry_err(S, ref)
+            assert err <= info["bound"] + 1e-15 and info["sq"] <= factor * 1e-12 and info["x"] <= factor * 1e-11, (factor, err, info)
+            got[factor] = (planes, err, info["bound"])
+        with pytest.raises(RuntimeError, match="outside"):
+            ops.set_i8_tolerance(0.5)
+    finally:
+        assert ops.set_i8_tolerance(1.0) == 64.0
+    assert got[1.0][0] == 6 and got[1.0][1] < 1e-12 and got[64.0][0] == 5 and got[64.0][1] < 64e-12, got
 
 
 @pytest.mark.parametrize("tokens,feat", [(777, 256), (4096, 128), (33, 384), (20000, 256), (65504 + 3000, 128)])

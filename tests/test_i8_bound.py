@@ -103,3 +103,20 @@ def test_worst_case_is_attained_by_a_constant_column():
     a, rho = M.alphas(st)
     rel = measured(X, d, E, 6)
     assert rel[0, 0] > 0 and 0.5 < rel[0, 0] / M.entry_bound(a, rho, 6)[0, 0] <= 1.0 + 1e-9
+
+
+def test_tolerance_factor_trades_planes_for_a_looser_but_still_kept_bound():
+    """mdg_cov_i8_set_tolerance's factor in the host model: SiLU-gated columns go from six planes to five at x64, the (SQ, X) the
+    route reports stay under the scaled thresholds, and the measured error stays under what it reports."""
+    gen = torch.Generator().manual_seed(2)
+    X = family("silu_gated", gen)
+    d, E, _, rounded, nnz = M.digits(X)
+    st = M.column_stats(d, rounded, nnz)
+    strict = M.route(st, jmax=2, tokens=T)
+    loose = M.route(st, jmax=2, tokens=T, tolerance=64.0)
+    assert strict[0] == 6 and loose[0] == 5
+    sq, x = loose[2]
+    assert sq <= 64 * M.TAU_SQ and x <= 64 * M.tau_x_of(T) and (sq > M.TAU_SQ or x > M.tau_x_of(T))
+    keep = np.ones(N, bool)
+    keep[loose[1]] = False
+    assert measured(X, d, E, 5)[np.ix_(keep, keep)].max() <= sq + x + 4e-16
