@@ -11,6 +11,7 @@ g = torch.Generator().manual_seed(int(sys.argv[1]) if len(sys.argv) > 1 else 7)
 worst, routes, bad, worst_ratio, cols_out, worst_bound = 0.0, {}, 0, 0.0, 0, 0.0
 TMAX = int(sys.argv[3]) if len(sys.argv) > 3 else 6000          # python i8_fuzz.py <seed> <cases> [max tokens] [max width / 128]
 NMAX = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+TOL = float(os.environ.get("MODEGPT_I8_TOLERANCE", "1"))        # (the route's tolerance dial scales the measured-typical limit with it)
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 120):
     T = int(torch.randint(1, TMAX, (1,), generator=g)); n = 128 * int(torch.randint(1, NMAX + 1, (1,), generator=g))
     kind = int(torch.randint(0, 9, (1,), generator=g))
@@ -37,7 +38,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 120):
     if r:
         worst_ratio = max(worst_ratio, err / max(info["bound"], 1e-300) if err > 4e-16 else 0.0)
         worst_bound = max(worst_bound, info["bound"])
-    if not err < 1e-12 or (r and err > info["bound"] + 4e-16):
+    if not err < 1e-12 * TOL or (r and err > info["bound"] + 4e-16):
         bad += 1
         print(f"VIOLATION trial {trial}: T={T} n={n} kind={kind} route={r} err={err:.2e} bound={info['bound']:.2e} columns={info['columns']}")
 print(f"routes {routes}; worst error {worst:.2e}; largest bound {worst_bound:.2e}; largest measured / bound {worst_ratio:.3f}; "
