@@ -857,3 +857,28 @@ def test_layers_chains_side_by_side_and_background_writer_give_the_same_artefact
     with pytest.raises(torch.linalg.LinAlgError):
         compress_nystrom(ad, bad, keep, layers)
     torch.cuda.synchronize()
+
+
+def test_bench_line_contract():
+    """`python bench.py` as the driver starts it (one GPU, fewer batches to stay short; extra legs and the CPU baseline off): ONE
+    JSON line on stdout carrying the contract's keys, the metric BASELINE.json names, a roofline object priced on the int8 MFMA
+    roof, and a positive whole-job rate that equals steps / (ms_per_step x steps)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batches", "4",
+                        "--no-cpu-baseline", "--no-extra-legs"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    metric = json.load(open(os.path.join(root, "BASELINE.json")))["metric"]
+    assert d["metric"] == metric and d["unit"] == "layers/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "int8" in d["dtype"] and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 0 and abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-3 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TOP/s" and r["peak"] == 5000.0 and 0.2 < r["frac"] < 1.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5 and r["launches"] == 3 * 4 and r["routes"]["fallback_f64"] == 0
+    assert "cpu_baseline" in d and len(lines[0]) < 4096
