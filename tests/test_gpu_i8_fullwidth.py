@@ -306,21 +306,20 @@ def test_massive_activation_columns_leave_alone_at_product_widths(ops, dev, n, k
     info0 = {}
     assert ops.cov_accum_i8(S8, X0, route_info=info0) == planes and info0["columns"] == []
 
-    def timed(Xin):
+    def once(Xin):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        S8.zero_()
+        e0.record()
         ops.cov_accum_i8(S8, Xin, report=False)
-        best = 1e9
-        for _ in range(3):
-            e0.record()
-            ops.cov_accum_i8(S8, Xin, report=False)
-            e1.record()
-            e1.synchronize()
-            best = min(best, e0.elapsed_time(e1))
-        return best
-    t_clean, t_massive = timed(X0), timed(X)
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1)
+    S8.zero_()
+    once(X0), once(X)                                    # warm-up of both
+    t_clean = t_massive = 1e9
+    for _ in range(5):                                   # alternating, best of five each: clock drift hits both alike
+        t_clean, t_massive = min(t_clean, once(X0)), min(t_massive, once(X))
     print(f"n={n} {kind}: clean {t_clean:.2f} ms, with 4 massive columns {t_massive:.2f} ms (+{100 * (t_massive / t_clean - 1):.1f} %)")
-    assert t_massive < 1.05 * t_clean + 0.3, (t_clean, t_massive)   # (+0.3 ms: at 4096 features the whole call is ~3 ms)
+    assert t_massive < 1.05 * t_clean + 0.4, (t_clean, t_massive)   # (+0.4 ms: at 4096 features the whole call is ~3 ms)
 
 
 def test_device_route_equals_the_host_model_at_sigma_x_width(ops, dev):
