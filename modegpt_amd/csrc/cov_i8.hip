@@ -510,22 +510,41 @@ __global__ __launch_bounds__(ROUTE_THREADS) void i8_route_kernel(const unsigned 
   __syncthreads();
   if (my_ticket != (int)gridDim.x - 1) return;
   __threadfence();
+  // (the merges take the partials four workgroups at a time: four independent loads in flight instead of a chain of gridDim.x
+  //  dependent round trips -- the merge order does not enter the result, top2_merge breaks ties by column index)
+  const unsigned nwg = gridDim.x;
   if (tid < NVAL) {
     Top2 r = partial[0].top[tid];
-    for (unsigned w = 1; w < gridDim.x; w++) top2_merge(r, partial[w].top[tid]);
+    unsigned w = 1;
+    for (; w + 4 <= nwg; w += 4) {
+      const Top2 b0 = partial[w].top[tid], b1 = partial[w + 1].top[tid], b2 = partial[w + 2].top[tid], b3 = partial[w + 3].top[tid];
+      top2_merge(r, b0); top2_merge(r, b1); top2_merge(r, b2); top2_merge(r, b3);
+    }
+    for (; w < nwg; w++) top2_merge(r, partial[w].top[tid]);
     r.m1 = fmax(r.m1, 0.0);
     r.m2 = fmax(r.m2, 0.0);
     top[tid] = r;
   }
   for (int i = tid; i < NVAL * 64; i += ROUTE_THREADS) {
     unsigned long long m = 0ull;
-    for (unsigned w = 0; w < gridDim.x; w++) m = max(m, (&partial[w].cls[0][0])[i]);
+    unsigned w = 0;
+    for (; w + 4 <= nwg; w += 4) {
+      const unsigned long long v0 = (&partial[w].cls[0][0])[i], v1 = (&partial[w + 1].cls[0][0])[i], v2 = (&partial[w + 2].cls[0][0])[i],
+                               v3 = (&partial[w + 3].cls[0][0])[i];
+      m = max(max(m, v0), max(max(v1, v2), v3));
+    }
+    for (; w < nwg; w++) m = max(m, (&partial[w].cls[0][0])[i]);
     (&group_max[0][0])[i] = m;
   }
   if (tid == 0) {
     forced_total = scratch->forced;
     unsigned m = 0xffffffffu;
-    for (unsigned w = 0; w < gridDim.x; w++) m = min(m, partial[w].min_nnz);
+    unsigned w = 0;
+    for (; w + 4 <= nwg; w += 4) {
+      const unsigned v0 = partial[w].min_nnz, v1 = partial[w + 1].min_nnz, v2 = partial[w + 2].min_nnz, v3 = partial[w + 3].min_nnz;
+      m = min(min(m, v0), min(min(v1, v2), v3));
+    }
+    for (; w < nwg; w++) m = min(m, partial[w].min_nnz);
     tau_x_shared = tau_x_of(min(n_tokens, (int64_t)m));
   }
   __syncthreads();
