@@ -121,6 +121,19 @@ def _worker(rank, world, port, tmp):
         assert sorted(written) == sorted((i, s) for i in foreign for s in ("mlp", "qk", "vo"))
     else:
         assert written == []
+    # the gather into buffers of the caller's (bench.py allocates them before its timed region): same records, the receive side
+    # inside the caller's buffer, ragged record lengths and a rank with fewer records than slots
+    mine = [S.pack_layer(10 * rank + i, _layer(3 * rank + i)[0], _layer(3 * rank + i)[1]) for i in range(2 if rank == 0 else 1)]
+    bufs = S.gather_buffers(2, world, 2000, "cpu")
+    bufs[0].fill_(-1)
+    bufs[1].fill_(-1)
+    out = S.allgather_records(mine, 2, world, buffers=bufs)
+    assert len(out) == 3 and out[0].untyped_storage().data_ptr() == bufs[1].untyped_storage().data_ptr()
+    got = {S.unpack_layer(r)[0]: S.unpack_layer(r) for r in out}
+    assert sorted(got) == [0, 1, 10]
+    for li, src in ((0, 0), (1, 1), (10, 3)):
+        _, tensors, mask = got[li]
+        assert torch.equal(mask, _layer(src)[1]) and all(torch.equal(tensors[k], v) for k, v in _layer(src)[0].items())
     S.finalize()                                      # barrier + destroy: the collective phase ends here for every rank
     assert not dist.is_initialized()
     assert not [f for f in os.listdir(shared) if ".tmp" in f]     # (after the barrier: rank 0 has finished its atomic renames)
