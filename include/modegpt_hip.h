@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MDG_ABI_VERSION 8 /* 2: w_dtype on mdg_nystrom_down / mdg_vo_compress, mdg_rope_gather added; 3: mdg_cov_accum_i8_stats added;
+#define MDG_ABI_VERSION 9 /* 2: w_dtype on mdg_nystrom_down / mdg_vo_compress, mdg_rope_gather added; 3: mdg_cov_accum_i8_stats added;
                              4: mdg_cov_accum_i8 chooses its route on the device (route_counts argument, no host synchronisation);
                                 mdg_comm_* / mdg_allgather_layers added;
                              5: mdg_potrs_lower takes a workspace (mdg_potrs_lower_ws_bytes);
@@ -34,7 +34,10 @@ extern "C" {
                              7: the int8 route is derived from a per-call error bound, single columns can leave the int8 path for an fp64
                                 column kernel (route_counts has 4 entries, mdg_cov_accum_i8_route added, workspace layout changed);
                                 mdg_shutdown and mdg_deferred_status_* added;
-                             8: mdg_cov_i8_set_tolerance / mdg_cov_i8_tolerance, mdg_nystrom_down_overlapped added */
+                             8: mdg_cov_i8_set_tolerance / mdg_cov_i8_tolerance, mdg_nystrom_down_overlapped added;
+                             9: the int8 route's tolerance factor is an ARGUMENT of mdg_cov_accum_i8 / mdg_cov_accum_i8_multi (the
+                                process-wide setter / getter of ABI 8 are gone: no accuracy state in the library);
+                                mdg_ridge_select_margin added (certificate of the MLP rank selection) */
 
 enum mdg_status {
   MDG_OK = 0,
@@ -110,8 +113,9 @@ int mdg_cov_accum_multi(int n, const mdg_cov_problem* problems, int dtype, void*
  * DESIGN.md section 7, host model tests/i8_model.py):
  *     |sigma_ij - exact| <= (SQ_P + X_P) sqrt(sigma_ii sigma_jj)   entry-wise, for any input,
  * and the route is the smallest P in {5, 6} with SQ_P <= 1e-12 (the part of the bound that is attained) and X_P <= 1e-11 (cross
- * terms; 20-50x above what uncorrelated columns produce).  GUARANTEED: <= 1.1e-11; MEASURED on every distribution family of
- * scripts/probes/i8_fuzz.py and at the product's widths: <= 1e-12.  Columns that alone break the bound -- a bulk 10-15 binades under a
+ * terms; 20-50x above what uncorrelated columns produce).  GUARANTEED for any input: <= 1.1e-11 (times `tolerance`).  TYPICAL:
+ * 1e-13 (an empirical figure, not a promise: <= 1e-12 on every distribution family of scripts/probes/i8_fuzz.py and at the
+ * product's widths; data whose columns have proportional digit sequences can come arbitrarily close to the bound).  Columns that alone break the bound -- a bulk 10-15 binades under a
  * few massive activations, columns holding an Inf / NaN -- leave the int8 path one by one (at most MDG_I8_MAX_COLUMNS per statistic
  * and call): the fold skips their rows and columns of sigma and an fp64 column kernel (plain fp64 sums of products, the reference's
  * arithmetic, LlamaAdapter.py:127-147) computes them.  Only when that is not enough does the whole statistic run through
@@ -124,13 +128,19 @@ int mdg_cov_accum_multi(int n, const mdg_cov_problem* problems, int dtype, void*
  *   it likes (calibration reads it once, at the end).
  * used_i8 (HOST pointer, optional; measurement and tests): receives the route of THIS call -- 5, 6, or 0 for the fp64 kernel --
  *   at the price of one stream synchronisation.
+ * tolerance: the accuracy / speed dial of THIS call, one factor f in [1, 1e6] on both thresholds of the route (SQ_P <= f 1e-12,
+ *   X_P <= f tau_x).  f = 1 is the guarantee stated above.  A caller who accepts f times that bound gets five planes where the default
+ *   takes six -- SiLU-gated MLP activations have X_5 = 3.7e-10, so f >= 37 moves them to five planes: measured 3.8e-12 instead of
+ *   8e-14, the sigma_mlp launch 29 instead of 37 ms -- and fewer columns on the fp64 column kernel.  The call still computes and
+ *   reports its own bound (mdg_cov_accum_i8_route), so what was guaranteed for a given input is known, whatever f.  An argument,
+ *   not process state: concurrent callers with different factors do not see each other.  Not in the reference (plain fp64 there).
  * n_feat must be a multiple of 128, n_tokens < 2^28.  ws: mdg_cov_accum_i8_ws_bytes (about 6 bytes per element of x).
  * ev_start / ev_stop: optional hipEvent_t recorded on `stream` right before / after the two product launches (bench.py times
  * the dominant kernel alone with them); NULL otherwise. */
 #define MDG_I8_MAX_COLUMNS 32
 size_t mdg_cov_accum_i8_ws_bytes(int64_t n_tokens, int64_t n_feat);
 int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat, int64_t ld, double* sigma, int64_t ld_sigma, void* ws,
-                     size_t ws_bytes, int* used_i8, int* route_counts, void* ev_start, void* ev_stop, void* stream);
+                     size_t ws_bytes, double tolerance, int* used_i8, int* route_counts, void* ev_start, void* ev_stop, void* stream);
 /* v_mfma instructions the product kernel of the LAST mdg_cov_accum_i8 call on workspace `ws` executed (0 after a call that
  * fell back to mdg_cov_accum).  The split pass records, per k-step and 32-row group, which digit planes hold a nonzero
  * there; the product kernel neither loads nor multiplies planes that are all-zero over a tile panel, so the count is at
@@ -144,14 +154,6 @@ int mdg_cov_accum_i8_stats(const void* ws, int64_t n_tokens, int64_t n_feat, uns
  * output pointer may be NULL.  Copies device -> host on `stream` and synchronises it: tests and measurements only. */
 int mdg_cov_accum_i8_route(int count, const mdg_cov_problem* problems, int stat, const void* ws, int* planes, int* n_columns,
                            int* columns, double* bound, void* stream);
-/* The accuracy / speed dial of the int8 route: one factor f in [1, 1e6] on both thresholds of the route (SQ_P <= f 1e-12,
- * X_P <= f tau_x), process-wide, read when a call is enqueued.  f = 1 (the default) is the guarantee stated above.  A caller who
- * accepts f times that bound gets five planes where the default takes six -- SiLU-gated MLP activations have X_5 = 3.7e-10, so
- * f >= 37 moves them to five planes: measured 3.8e-12 instead of 8e-14, the sigma_mlp launch 22 instead of 37 ms -- and fewer
- * columns on the fp64 column kernel.  Every call still computes and reports its own bound (mdg_cov_accum_i8_route), so what was
- * guaranteed for a given input is known, whatever f.  Not in the reference (plain fp64 there); off unless asked for. */
-int mdg_cov_i8_set_tolerance(double factor);
-double mdg_cov_i8_tolerance(void);
 /* Up to 4 statistics of ONE calibration batch (the four hooks of a layer) through the int8 digit-plane kernels with ONE
  * persistent product launch: the tiles of all statistics share one static tile schedule, so the small ones fill what the large
  * one's last round leaves idle instead of ending launches of their own, and one route -- the deepest any statistic on the int8 path
@@ -161,13 +163,13 @@ double mdg_cov_i8_tolerance(void);
  * batch > 1: per-head Grams of an activation [n_tokens][batch * 128] -- n_feat must be 128, sigma contiguous
  * [batch][128][128] (ld_sigma 128, sigma_batch_stride 16384); only the diagonal tiles are computed.  Several statistics need a
  * 256-CU device (the schedule is cut for 8 XCDs x 32 CUs); otherwise call mdg_cov_accum_i8 per statistic.
- * used_i8 / route_counts / ev_start / ev_stop as in mdg_cov_accum_i8 (route_counts += the number of statistics per route;
+ * tolerance / used_i8 / route_counts / ev_start / ev_stop as in mdg_cov_accum_i8 (route_counts += the number of statistics per route;
  * used_i8 = 5 or 6, the planes of the statistics that stayed on the int8 path, 0 when all of them went to the fp64 kernel);
  * mdg_cov_accum_i8_stats(ws, 0, 0, ...) reads the executed-MFMA count of the whole launch.  mdg_cov_accum_i8 is this call with
  * one statistic. */
 size_t mdg_cov_accum_i8_multi_ws_bytes(int count, const mdg_cov_problem* problems);
-int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems, void* ws, size_t ws_bytes, int* used_i8, int* route_counts,
-                           void* ev_start, void* ev_stop, void* stream);
+int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems, void* ws, size_t ws_bytes, double tolerance, int* used_i8,
+                           int* route_counts, void* ev_start, void* ev_stop, void* stream);
 /* sigma[b] <- scale * sigma[b] on the lower triangle, mirrored into the upper.  scale = 1/(n_texts*2048)
  * reproduces calibration.py:141-146. */
 int mdg_cov_finalize(double* sigma, int64_t n, int64_t batch, int64_t ld_sigma, int64_t sigma_batch_stride,

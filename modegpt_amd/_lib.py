@@ -27,7 +27,7 @@ class CovProblem(C.Structure):
                 ("ld_sigma", _i64), ("sigma_batch_stride", _i64)]
 
 
-ABI_VERSION = 8   # include/modegpt_hip.h MDG_ABI_VERSION this binding table was written against
+ABI_VERSION = 9   # include/modegpt_hip.h MDG_ABI_VERSION this binding table was written against
 
 # name -> (restype, argtypes); must list every symbol the header declares (tests/test_abi.py checks it)
 SIGNATURES = {
@@ -41,14 +41,12 @@ SIGNATURES = {
     "mdg_cov_accum_ws_bytes": (_sz, [_i64, _i64, _i64]),
     "mdg_cov_accum": (_i32, [_ptr, _i32, _i64, _i64, _i64, _i64, _i32, _ptr, _i64, _i64, _ptr, _sz, _ptr]),
     "mdg_cov_accum_i8_ws_bytes": (_sz, [_i64, _i64]),
-    "mdg_cov_accum_i8": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _i64, _ptr, _sz, C.POINTER(_i32), _ptr, _ptr, _ptr, _ptr]),
+    "mdg_cov_accum_i8": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _i64, _ptr, _sz, _f64, C.POINTER(_i32), _ptr, _ptr, _ptr, _ptr]),
     "mdg_cov_accum_i8_stats": (_i32, [_ptr, _i64, _i64, C.POINTER(C.c_ulonglong), _ptr]),
     "mdg_cov_accum_i8_route": (_i32, [_i32, C.POINTER(CovProblem), _i32, _ptr, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32),
                                        C.POINTER(_f64), _ptr]),
-    "mdg_cov_i8_set_tolerance": (_i32, [_f64]),
-    "mdg_cov_i8_tolerance": (_f64, []),
     "mdg_cov_accum_i8_multi_ws_bytes": (_sz, [_i32, C.POINTER(CovProblem)]),
-    "mdg_cov_accum_i8_multi": (_i32, [_i32, C.POINTER(CovProblem), _ptr, _sz, C.POINTER(_i32), _ptr, _ptr, _ptr, _ptr]),
+    "mdg_cov_accum_i8_multi": (_i32, [_i32, C.POINTER(CovProblem), _ptr, _sz, _f64, C.POINTER(_i32), _ptr, _ptr, _ptr, _ptr]),
     "mdg_cov_accum_multi_ws_bytes": (_sz, [_i32, C.POINTER(CovProblem), _i32]),
     "mdg_cov_accum_multi": (_i32, [_i32, C.POINTER(CovProblem), _i32, _ptr, _sz, _ptr]),
     "mdg_cov_finalize": (_i32, [_ptr, _i64, _i64, _i64, _i64, _f64, _ptr]),
@@ -119,9 +117,6 @@ def load() -> C.CDLL:
     if lib.mdg_abi_version() != ABI_VERSION:
         raise ModeGPTLibraryError("libmodegpt_hip.so ABI version mismatch")
     _lib = lib
-    if os.environ.get("MODEGPT_I8_TOLERANCE"):      # the int8 route's accuracy / speed dial (ops.set_i8_tolerance), 1 = default
-        if lib.mdg_cov_i8_set_tolerance(float(os.environ["MODEGPT_I8_TOLERANCE"])) != MDG_OK:
-            raise ModeGPTLibraryError("MODEGPT_I8_TOLERANCE: " + lib.mdg_last_error().decode("utf-8", "replace"))
     # the library's cached device allocations are released while the HIP runtime is still alive (Python's atexit runs before
     # the C++ static destructors); the library itself makes no HIP call at exit
     import atexit

@@ -118,6 +118,7 @@ def _calibrate_model(adapter: ModelAdapter, n_samples: int, batch_size: int, tar
         stop_after = None
     if stop_after is not None:
         handles.append(blocks[stop_after].register_forward_hook(_stop_forward))
+    hidden_states_before = getattr(model.config, "output_hidden_states", False)
     model.config.output_hidden_states = bool(want_bi)
     model.eval()
     n_texts = 0
@@ -134,6 +135,7 @@ def _calibrate_model(adapter: ModelAdapter, n_samples: int, batch_size: int, tar
     finally:
         for h in handles:
             h.remove()
+        model.config.output_hidden_states = hidden_states_before     # (the caller's model goes back as it came)
     bi_scores = bi.scores(n_texts) if want_bi else None
     adapter.bi_scores = bi_scores
     sig.finalize(n_texts)

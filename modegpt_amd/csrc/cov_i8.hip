@@ -364,10 +364,10 @@ __global__ __launch_bounds__(256) void i8_split_vec_kernel(const bf16_t* x, int6
 // count -- the smallest number of nonzero elements any column of the statistic has:
 // guaranteed <= TAU_SQ + tau_x <= 1.1e-11 for any input, and <= 1e-12 measured also on the uncorrelated data of a short or sparse call.
 constexpr double TAU_SQ = 1e-12, TAU_X_MIN = 1e-12, TAU_X_MAX = 1e-11, TAU_X_TOKENS = 1024.0;
-// mdg_cov_i8_set_tolerance: one factor on both thresholds (1 = the figures above).  A caller who accepts `f` times the guarantee
-// gets five planes where the default asks for six (SiLU-gated activations: X_5 = 3.7e-10, i.e. f >= 37); the bound every call
-// computes (RouteOut::sq, ::x) says what was guaranteed either way.
-static std::atomic<double> g_i8_tolerance{1.0};
+// The `tolerance` argument of mdg_cov_accum_i8 / _multi: one factor on both thresholds (1 = the figures above), per CALL -- the
+// library keeps no accuracy state (two host threads with different factors each get the route of their own factor).  A caller
+// who accepts `f` times the guarantee gets five planes where the default asks for six (SiLU-gated activations: X_5 = 3.7e-10,
+// i.e. f >= 37); the bound every call computes (RouteOut::sq, ::x) says what was guaranteed either way.
 __host__ __device__ inline double tau_x_of(int64_t tokens) {
   return fmin(TAU_X_MAX, fmax(TAU_X_MIN, TAU_X_MIN * ((double)tokens / TAU_X_TOKENS)));
 }
@@ -1321,7 +1321,8 @@ __global__ __launch_bounds__(64) void i8_columns_kernel(ColArgs a) {
       unsigned w[COLK_BATCH][4];
 #pragma unroll
       for (int i = 0; i < COLK_BATCH; i++) {
-        const int64_t tok = min(t + tb + i, t1 - 1);          // (clamped: the group's staged values beyond the chunk are zero)
+        const bool live = t + tb + i < t1;
+        const int64_t tok = live ? t + tb + i : t1 - 1;        // (the address stays inside the chunk ...)
         if (a.vec) {
           const i32x4 v = *(const i32x4*)(xs + tok * a.ld + c0);
           w[i][0] = v[0]; w[i][1] = v[1]; w[i][2] = v[2]; w[i][3] = v[3];
@@ -1329,6 +1330,10 @@ __global__ __launch_bounds__(64) void i8_columns_kernel(ColArgs a) {
 #pragma unroll
           for (int h = 0; h < 4; h++) w[i][h] = xs[tok * a.ld + c0 + 2 * h] | ((unsigned)xs[tok * a.ld + c0 + 2 * h + 1] << 16);
         }
+        // ... and a slot beyond the chunk's end contributes exact zeros: the group's staged values are zero there, but the re-read
+        // last token may hold an Inf / NaN -- the very columns this kernel exists for -- and 0 * Inf would turn the +-Inf the
+        // reference's fp64 product gives into NaN
+        if (!live) w[i][0] = w[i][1] = w[i][2] = w[i][3] = 0u;
       }
 #pragma unroll
       for (int i = 0; i < COLK_BATCH; i++) {
@@ -1574,10 +1579,12 @@ extern "C" size_t mdg_cov_accum_i8_multi_ws_bytes(int count, const mdg_cov_probl
   return layout(count, problems, nullptr, nullptr);
 }
 
-extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems, void* ws, size_t ws_bytes, int* used_i8,
-                                      int* route_counts, void* ev_start, void* ev_stop, void* stream) {
+extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems, void* ws, size_t ws_bytes, double tolerance,
+                                      int* used_i8, int* route_counts, void* ev_start, void* ev_stop, void* stream) {
   MDG_CLEAR();
   if (used_i8) *used_i8 = 0;
+  MDG_CHECK_ARG(tolerance >= 1.0 && tolerance <= 1e6, "mdg_cov_accum_i8_multi: tolerance factor %g outside [1, 1e6] (1 = guaranteed <= 1.1e-11)",
+                tolerance);
   MDG_CHECK_ARG(problems_ok(count, problems),
                 "mdg_cov_accum_i8_multi: 1..%d statistics of the same token count; full ones need n_feat %% 128 == 0, per-head ones "
                 "head_dim 128 with contiguous [heads][128][128] sigma; leading dimensions at least the widths (use mdg_cov_accum)",
@@ -1629,7 +1636,7 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
       RouteScratch* scratch = (RouteScratch*)(stats + (size_t)NSTAT * n);      // (inside the region zeroed above)
       hipLaunchKernelGGL(i8_route_kernel, dim3((unsigned)ceil_div(n, ROUTE_THREADS)), dim3(ROUTE_THREADS), 0, st, stats, emax, n,
                          n_tokens, vals, partial, scratch, pflag + i, (RouteOut*)((char*)ws + pw[i].route), route_counts,
-                         g_i8_tolerance.load(std::memory_order_relaxed));
+                         tolerance);
     }
     hipLaunchKernelGGL(i8_clear_columns_kernel, dim3(ROUTE_JMAX, (unsigned)std::min(64, (nk + 3) / 4)), dim3(256), 0, st,
                        (const RouteOut*)((char*)ws + pw[i].route), pflag + i, emax, planes, zmask, n, nk);
@@ -1811,8 +1818,8 @@ extern "C" size_t mdg_cov_accum_i8_ws_bytes(int64_t n_tokens, int64_t n_feat) {
 }
 
 extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat, int64_t ld, double* sigma, int64_t ld_sigma,
-                                void* ws, size_t ws_bytes, int* used_i8, int* route_counts, void* ev_start, void* ev_stop,
-                                void* stream) {
+                                void* ws, size_t ws_bytes, double tolerance, int* used_i8, int* route_counts, void* ev_start,
+                                void* ev_stop, void* stream) {
   MDG_CLEAR();
   if (used_i8) *used_i8 = 0;
   MDG_CHECK_ARG(n_tokens >= 0 && n_feat > 0, "mdg_cov_accum_i8: bad sizes (tokens=%lld feat=%lld)", (long long)n_tokens,
@@ -1820,17 +1827,8 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
   MDG_CHECK_ARG(n_feat % TI == 0, "mdg_cov_accum_i8: n_feat=%lld must be a multiple of %d (use mdg_cov_accum)",
                 (long long)n_feat, TI);
   const mdg_cov_problem q = single_problem(x, n_tokens, n_feat, ld, sigma, ld_sigma);
-  return mdg_cov_accum_i8_multi(1, &q, ws, ws_bytes, used_i8, route_counts, ev_start, ev_stop, stream);
+  return mdg_cov_accum_i8_multi(1, &q, ws, ws_bytes, tolerance, used_i8, route_counts, ev_start, ev_stop, stream);
 }
-
-extern "C" int mdg_cov_i8_set_tolerance(double factor) {
-  MDG_CLEAR();
-  MDG_CHECK_ARG(factor >= 1.0 && factor <= 1e6, "mdg_cov_i8_set_tolerance: factor %g outside [1, 1e6] (1 = guaranteed <= 1.1e-11)", factor);
-  g_i8_tolerance.store(factor, std::memory_order_relaxed);
-  return MDG_OK;
-}
-
-extern "C" double mdg_cov_i8_tolerance(void) { return g_i8_tolerance.load(std::memory_order_relaxed); }
 
 extern "C" int mdg_cov_accum_i8_route(int count, const mdg_cov_problem* problems, int stat, const void* ws, int* planes, int* n_columns,
                                       int* columns, double* bound, void* stream) {

@@ -5,8 +5,10 @@ libmodegpt_hip.so.  Every function requires CUDA(HIP) tensors and raises otherwi
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
+import threading
 from typing import Optional, Tuple
 
 import torch
@@ -104,12 +106,13 @@ def cov_accum(sigma: torch.Tensor, x: torch.Tensor, n_heads: int = 1, relu: bool
 
 
 def cov_accum_i8(sigma: torch.Tensor, x: torch.Tensor, events=None, mfma_stats: Optional[dict] = None,
-                 report: bool = True, route_info: Optional[dict] = None) -> Optional[int]:
+                 report: bool = True, route_info: Optional[dict] = None, tolerance: Optional[float] = None) -> Optional[int]:
     """sigma (lower triangle) += X^T X for one bf16 matrix through the int8 digit-plane kernel (csrc/cov_i8.hip): error-free
     split into digit planes, truncated plane-pair product.  The route -- five planes or six, which columns leave the int8 path
     for the fp64 column kernel (at most 32), or the fp64 kernel for the whole statistic -- is derived on the device from a
-    per-call error bound (guaranteed <= 1.1e-11 of sqrt(sigma_ii sigma_jj) entry-wise, measured <= 1e-12; include/modegpt_hip.h);
-    the result is valid either way.  report=True (tests, measurements) returns the route of this
+    per-call error bound (guaranteed <= 1.1e-11 of sqrt(sigma_ii sigma_jj) entry-wise, typically 1e-13; include/modegpt_hip.h);
+    the result is valid either way.  tolerance: the factor on the route's thresholds for THIS call (None: i8_tolerance(), the
+    calling thread's default).  report=True (tests, measurements) returns the route of this
     call (5, 6, or 0 for the fp64 kernel) at the price of one stream synchronisation and books it in I8_STATS;
     report=False (the hooks: cov_accum_multi) only enqueues and returns None -- the per-device counters behind
     i8_route_counts() are updated by the kernels themselves in both modes.  Feature count must be a multiple of 128.
@@ -137,7 +140,7 @@ def cov_accum_i8(sigma: torch.Tensor, x: torch.Tensor, events=None, mfma_stats: 
     used = C.c_int(0)
     with torch.cuda.device(x.device):
         check(lib.mdg_cov_accum_i8(x2.data_ptr(), x2.shape[0], n, x2.stride(0), sigma.data_ptr(), sigma.stride(0), wsp, nbytes,
-                                   C.byref(used) if report else None, _route_counters(x.device).data_ptr(),
+                                   i8_tolerance() if tolerance is None else float(tolerance), C.byref(used) if report else None, _route_counters(x.device).data_ptr(),
                                    None if events is None else events[0].cuda_event,
                                    None if events is None else events[1].cuda_event, _stream(x)), "mdg_cov_accum_i8")
         if mfma_stats is not None and used.value in (5, 6):
@@ -166,7 +169,7 @@ def _read_route(lib, count, arr, stat, wsp, stream) -> dict:
 
 
 def cov_accum_i8_multi(items, events=None, mfma_stats: Optional[dict] = None, report: bool = False,
-                       route_info: Optional[list] = None) -> Optional[int]:
+                       route_info: Optional[list] = None, tolerance: Optional[float] = None) -> Optional[int]:
     """Several statistics of ONE calibration batch through the int8 digit-plane kernels in one persistent product launch
     (mdg_cov_accum_i8_multi): items = sequence of (sigma, x, n_heads), largest first, at most 4, all bf16 with the same token
     count.  n_heads == 1: sigma [n, n], n a multiple of 128; n_heads > 1: per-head Grams, sigma [n_heads, 128, 128] of an
@@ -204,7 +207,8 @@ def cov_accum_i8_multi(items, events=None, mfma_stats: Optional[dict] = None, re
     report = report or mfma_stats is not None or route_info is not None
     used = C.c_int(0)
     with torch.cuda.device(dev):
-        check(lib.mdg_cov_accum_i8_multi(len(items), arr, wsp, nbytes, C.byref(used) if report else None,
+        check(lib.mdg_cov_accum_i8_multi(len(items), arr, wsp, nbytes, i8_tolerance() if tolerance is None else float(tolerance),
+                                         C.byref(used) if report else None,
                                          _route_counters(dev).data_ptr(), None if events is None else events[0].cuda_event,
                                          None if events is None else events[1].cuda_event, _stream(keep[0])),
               "mdg_cov_accum_i8_multi")
@@ -234,14 +238,49 @@ def _route_counters(device) -> torch.Tensor:
     return _ROUTE_COUNTERS[key]
 
 
+# The accuracy / speed dial of the int8 covariance route is an ARGUMENT of every call (mdg_cov_accum_i8's `tolerance`, ABI 9); the
+# library keeps no accuracy state.  What is kept here, on the Python side, is only the default a call without an explicit
+# `tolerance=` uses: a process default (set_i8_tolerance; initialised from the environment variable MODEGPT_I8_TOLERANCE when this
+# module is imported) that a thread can override for itself (i8_tolerance_scope) without touching any other caller's arithmetic.
+def _checked_tolerance(factor) -> float:
+    f = float(factor)
+    if not (1.0 <= f <= 1e6):
+        raise ValueError(f"int8 route tolerance factor {f!r} outside [1, 1e6] (1 = guaranteed <= 1.1e-11)")
+    return f
+
+
+_I8_TOLERANCE_DEFAULT = _checked_tolerance(os.environ.get("MODEGPT_I8_TOLERANCE", "1") or "1")
+_I8_TOLERANCE_LOCAL = threading.local()
+
+
+def i8_tolerance() -> float:
+    """The tolerance factor a cov_accum_i8 / cov_accum_i8_multi / cov_accum_multi call made by THIS thread uses when it is not
+    given one: the innermost i8_tolerance_scope of the thread, else the process default."""
+    stack = getattr(_I8_TOLERANCE_LOCAL, "stack", None)
+    return stack[-1] if stack else _I8_TOLERANCE_DEFAULT
+
+
 def set_i8_tolerance(factor: float) -> float:
-    """The accuracy / speed dial of the int8 covariance route (mdg_cov_i8_set_tolerance): `factor` >= 1 on both thresholds of the
-    per-call error bound; 1 = guaranteed <= 1.1e-11 of sqrt(sigma_ii sigma_jj) (the default).  Returns the previous factor.  The
-    environment variable MODEGPT_I8_TOLERANCE sets it when the library is first loaded."""
-    lib = _lib.load()
-    prev = float(lib.mdg_cov_i8_tolerance())
-    check(lib.mdg_cov_i8_set_tolerance(float(factor)), "mdg_cov_i8_set_tolerance")
+    """Sets the process DEFAULT of the int8 route's tolerance factor (`factor` >= 1 on both thresholds of the per-call error bound;
+    1 = guaranteed <= 1.1e-11 of sqrt(sigma_ii sigma_jj)) and returns the previous default.  A Python-side default only: every
+    library call carries its factor as an argument."""
+    global _I8_TOLERANCE_DEFAULT
+    prev, _I8_TOLERANCE_DEFAULT = _I8_TOLERANCE_DEFAULT, _checked_tolerance(factor)
     return prev
+
+
+@contextlib.contextmanager
+def i8_tolerance_scope(factor: float):
+    """`with ops.i8_tolerance_scope(64): ...` -- the calling THREAD's default inside the block (hooks enqueued from it included);
+    other threads keep theirs."""
+    stack = getattr(_I8_TOLERANCE_LOCAL, "stack", None)
+    if stack is None:
+        stack = _I8_TOLERANCE_LOCAL.stack = []
+    stack.append(_checked_tolerance(factor))
+    try:
+        yield
+    finally:
+        stack.pop()
 
 
 def i8_route_counts(device=None, reset: bool = False) -> dict:

@@ -27,8 +27,8 @@ imports it relatively), the way the reference ships its self-contained modeling 
 depends on torch and transformers only.  The fused HIP kernel is used when the modegpt_amd package is importable and the
 tensors live on a GPU; anywhere else (another machine, a CPU) the same chain runs as plain torch ops, the reference's own
 expression op for op -- the checkpoint loads and evaluates wherever the reference's would.  Which path ran is counted in
-PATH_CALLS; MODEGPT_REQUIRE_HIP=1 turns the torch path into an error, and a GPU tensor without an importable engine is an
-error by itself unless MODEGPT_ALLOW_TORCH=1 (CPU tensors always take the portable path).
+PATH_CALLS; MODEGPT_REQUIRE_HIP=1 turns the torch path into an error.  One case raises by itself: the engine is installed here but
+its library does not load (a broken installation) and the tensors are on a GPU -- unless MODEGPT_ALLOW_TORCH=1.
 
 Inference only: the kernel has no backward.
 """
@@ -45,19 +45,30 @@ import torch.nn as nn
 logger = logging.getLogger("MoDeGPT")
 PATH_CALLS = {"hip": 0, "torch": 0}     # rope/norm chains served by mdg_rope_gather / by the torch expression
 _HIP_OPS = None
+_HIP_BROKEN = None                      # why the engine, although installed here, cannot serve (its library failed to load)
 
 
 def _hip_ops():
-    """modegpt_amd.ops when this process can import it (the checkpoint is being used on the machine that holds the engine),
-    else None -- decided once."""
-    global _HIP_OPS
+    """modegpt_amd.ops when this process can import the engine AND its library loads, else None -- decided once.  Two different
+    reasons for None: the package is simply not on this machine (a checkpoint taken elsewhere: the portable torch path, with one
+    warning), or it is here and libmodegpt_hip.so does not load (a broken installation: _HIP_BROKEN holds the reason and GPU
+    tensors raise instead of quietly running ten eager passes per layer)."""
+    global _HIP_OPS, _HIP_BROKEN
     if _HIP_OPS is None:
         try:
-            from modegpt_amd import ops as _ops
-            _HIP_OPS = _ops
+            import modegpt_amd  # noqa: F401
         except Exception as exc:  # not installed here: the portable path
             _HIP_OPS = False
-            logger.warning("compressed attention: modegpt_amd is not importable (%s); running the torch expression", exc)
+            logger.warning("compressed attention: modegpt_amd is not importable (%s); running the reference's torch expression", exc)
+            return None
+        try:
+            from modegpt_amd import _lib, ops as _ops
+            if torch.cuda.is_available():
+                _lib.load()
+            _HIP_OPS = _ops
+        except Exception as exc:
+            _HIP_OPS = False
+            _HIP_BROKEN = f"{type(exc).__name__}: {exc}"
     return _HIP_OPS or None
 
 
@@ -98,12 +109,12 @@ def _rope_gather(x, cos, sin, mask, n_heads, n_kv, head_dim, norm_weight=None, e
     if os.environ.get("MODEGPT_REQUIRE_HIP", "0") == "1":
         raise RuntimeError("compressed attention: MODEGPT_REQUIRE_HIP=1 but the HIP kernel cannot serve this call "
                            f"(tensor on {x.device}, modegpt_amd importable: {_hip_ops() is not None})")
-    if x.is_cuda and os.environ.get("MODEGPT_ALLOW_TORCH", "0") != "1":
-        # a GPU tensor and no engine: on a GPU box that is a broken installation, not portability -- say so instead of quietly
-        # running ten eager passes per layer.  A checkpoint taken to a machine without the engine sets MODEGPT_ALLOW_TORCH=1
-        # (CPU tensors always take the portable path).
-        raise RuntimeError("compressed attention: the tensors are on a GPU but modegpt_amd (libmodegpt_hip.so) cannot be imported "
-                           "in this process, so mdg_rope_gather is unavailable.  Install / build the engine, or set "
+    if x.is_cuda and _HIP_BROKEN and os.environ.get("MODEGPT_ALLOW_TORCH", "0") != "1":
+        # the engine IS installed here and its library does not load: a broken installation on a GPU box, not portability -- say so.
+        # (A machine without the engine -- a CUDA box, lm-eval -- takes the portable torch path below with the one warning of
+        # _hip_ops, as the reference's self-contained checkpoints do; MODEGPT_REQUIRE_HIP=1 is the strict opt-in.)
+        raise RuntimeError("compressed attention: modegpt_amd is installed but libmodegpt_hip.so cannot be used in this process "
+                           f"({_HIP_BROKEN}), so mdg_rope_gather is unavailable for these GPU tensors.  Rebuild the engine, or set "
                            "MODEGPT_ALLOW_TORCH=1 to run the reference's torch expression on the GPU instead.")
     PATH_CALLS["torch"] += 1
     return _rope_gather_torch(x, cos.to(x.dtype), sin.to(x.dtype), mask, n_heads, n_kv,

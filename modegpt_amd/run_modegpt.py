@@ -78,9 +78,16 @@ def compress_chunk(adapter: ModelAdapter, config: CompressionConfig, chunk: List
         adapter.calib_want_bi = rank == bi_rank and getattr(adapter, "bi_scores_cached", None) is None
         adapter.calib_stop_after = mine[-1] if mine else chunk[0]
         adapter.calib_no_hooks = not mine          # (`target_layers=[]` means "all layers" upstream: say "none" explicitly)
-    cov_mlp, cov_q, cov_k, cov_x, bi_scores = load_calibs(
-        adapter=adapter, n_samples=config.calib_size, batch_size=config.calibs_batch_size, dataset=config.dataset,
-        target_layers=mine)
+    try:
+        cov_mlp, cov_q, cov_k, cov_x, bi_scores = load_calibs(
+            adapter=adapter, n_samples=config.calib_size, batch_size=config.calibs_batch_size, dataset=config.dataset,
+            target_layers=mine)
+    finally:
+        # the three switches belong to THIS call: a later load_calibs on the same adapter (another trial, a one-rank re-run, a test
+        # reusing the adapter) must get the full forward, its hooks and its BI scores again
+        for name in ("calib_want_bi", "calib_stop_after", "calib_no_hooks"):
+            if hasattr(adapter, name):
+                delattr(adapter, name)
     if world > 1:
         bi_scores = _share_bi_scores(adapter, bi_scores, bi_rank, rank)
     keep = allocate_global_sparsity(bi_scores, compression_ratio=config.compression_ratio,

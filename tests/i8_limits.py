@@ -1,0 +1,46 @@
+"""What the tests may assert about the int8 digit-plane covariance route, and in which words.
+
+Two different statements exist about its entry-wise error over sqrt(sigma_ii sigma_jj) (include/modegpt_hip.h at mdg_cov_accum_i8):
+
+GUARANTEED -- holds for ANY input, by construction of the route: the error is at most the bound the call itself computed and
+    reported (SQ_P + X_P of mdg_cov_accum_i8_route), and that bound is at most 1.1e-11 times the call's tolerance factor.  A
+    violation is a bug.  Every parity test asserts it, against the call's own bound wherever the test has it.
+
+TYPICAL -- an EMPIRICAL figure: <= 1e-12 (times the factor) on the distribution families the route was measured on
+    (MEASURED_FAMILIES; scripts/probes/i8_fuzz.py + i8_fuzz_multi.py, 2 420 calls, profiles/r03_i8_fuzz.log; the full-width runs of
+    tests/test_gpu_i8_fullwidth.py).  It is a property of those data, not of the method: columns whose digit sequences are
+    proportional over the tokens reach the guaranteed bound (tests/test_i8_bound.py builds one).  It was also TUNED: the first
+    bound-derived route measured 1.46e-12 ... 3.1e-12 on 33- and 142-token calls, and the tau_x(T_eff) schedule of
+    csrc/cov_i8.hip is what brought those under 1e-12.  A test therefore asserts it only where it names one of the measured
+    families, and a failure of that part on new data is a finding about the data, not a defect of the kernel.
+"""
+GUARANTEED = 1.1e-11
+TYPICAL = 1e-12
+ROUNDING = 1e-15   # fp64 rounding of the reference sum the error is measured against
+
+# the families of scripts/probes/i8_fuzz.py (kinds 0-8), the bench generator, and the shapes of the full-width tests
+MEASURED_FAMILIES = {
+    "gaussian",         # z * c_j, column scales log-uniform (the bench / SURVEY 8(d) generator; fuzz kind 0)
+    "sparse",           # gaussian with 50-99 % exact zeros (fuzz kind 1)
+    "one_signed",       # |z|, ReLU(z) (fuzz kind 2; OPT's fc1 hook)
+    "silu_gated",       # silu(g) * u -- the MLP statistic of a Llama / Qwen3 layer (fuzz kind 3)
+    "cubed",            # z^3 (fuzz kind 4)
+    "outliers",         # a few elements 10 .. 1e5 times the bulk: massive activations (fuzz kind 5)
+    "student_t",        # Student-t(3..4) (fuzz kind 6)
+    "token_scaled",     # z * exp(2 N(0,1)) per token (fuzz kind 7)
+    "quantised",        # round(4 z) / 4: few distinct values (fuzz kind 8)
+    "laplace",          # scripts/probes/i8_error_bound.py
+    "model_forward",    # activations out of a random-init Llama / Qwen3 / OPT forward pass (test_gpu_e2e.py; r03 e2e runs)
+}
+
+
+def check_i8_error(err, bound=None, family=None, tolerance=1.0, ctx=None):
+    """err: measured entry-wise error of an int8-route result.  bound: the bound the call reported (route_info["bound"]), None
+    when the test did not read it back.  family: one of MEASURED_FAMILIES to ALSO assert the empirical 1e-12 figure."""
+    limit = GUARANTEED * tolerance if bound is None else bound
+    assert limit <= GUARANTEED * tolerance * (1 + 1e-12), ("the call's own bound exceeds the guarantee", bound, tolerance, ctx)
+    assert err <= limit + ROUNDING, ("GUARANTEED part violated: error above the call's bound", err, bound, tolerance, ctx)
+    if family is not None:
+        assert family in MEASURED_FAMILIES, family
+        assert err < TYPICAL * tolerance, (f"EMPIRICAL figure exceeded on family {family!r} (typical <= {TYPICAL * tolerance:g}; "
+                                           "not a guarantee -- see tests/i8_limits.py)", err, bound, ctx)

@@ -22,7 +22,7 @@ def test_header_matches_binding_table():
 
 def test_library_loads_and_exports_everything():
     lib = _lib.load()  # no GPU needed to dlopen and bind
-    assert lib.mdg_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.mdg_abi_version() == _lib.ABI_VERSION == 9
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = set(re.findall(r" T (mdg_[a-z0-9_]+)", out))
     assert header_symbols() <= exported

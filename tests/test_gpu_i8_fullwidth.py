@@ -7,7 +7,8 @@ What is compared with what:
   * n = 2048, 4096: the CPU oracle's fp64 H^T H (oracle/modegpt_oracle.py:cov_accum_tokens) directly;
   * every width: the v_mfma_f64 kernel (ops.cov_accum, itself held to 1e-13 of the oracle by test_cov_golden / test_cov_shapes
     and spot-checked against torch at full size in test_gpu_e2e.py), ENTRY-WISE over the lower triangle, normalised by
-    sqrt(sigma_ii sigma_jj): <= 1e-12 (tolerance of the route, DESIGN.md section 2);
+    sqrt(sigma_ii sigma_jj): within the bound the call computed (the guarantee, <= 1.1e-11) and -- both data kinds here being
+    families the route was measured on -- within the empirical 1e-12 (tests/i8_limits.py says which is which);
   * every width: spot blocks against a plain torch fp64 product of the same columns + the trace checksum sum(x^2);
   * n = 14336: the MLP rank selection (ridge scores -> k smallest, sorted) from sigma_i8 must be IDENTICAL to the one from
     sigma_f64 (north_star: "rank selections bit-identical"), at keep 0.7 and 0.6 (BASELINE configs 3 and 4).
@@ -18,6 +19,7 @@ import pytest
 import torch
 
 from oracle import modegpt_oracle as O
+from tests.i8_limits import check_i8_error
 
 pytestmark = pytest.mark.gpu
 F64 = torch.float64
@@ -95,23 +97,24 @@ def test_i8_route_at_product_widths(ops, dev, n, kind, planes):
     X = (gaussian if kind == "gaussian" else silu_gated)(dev, T_BATCH, n, 100 + n)
     S8 = torch.zeros(n, n, dtype=F64, device=dev)
     S64 = torch.zeros_like(S8)
-    stats = {}
-    assert ops.cov_accum_i8(S8, X, mfma_stats=stats) == planes
+    stats, info = {}, {}
+    assert ops.cov_accum_i8(S8, X, mfma_stats=stats, route_info=info) == planes
     assert 0 < stats["executed"] <= stats["dense"]
     ops.cov_accum(S64, X)
-    err = entrywise_err(S8, S64)
-    assert err < 1e-12, (n, kind, err)
+    check_i8_error(entrywise_err(S8, S64), info["bound"], family=kind, ctx=(n, info))
     spot, trace = spot_and_trace(S8, X, n)
-    assert spot < 1e-12 and trace < 1e-13, (n, kind, spot, trace)
+    check_i8_error(spot, info["bound"], family=kind, ctx=(n, "spot blocks against torch"))
+    assert trace < 1e-13, (n, kind, trace)
     if n <= 4096:   # straight against the oracle (CPU fp64; seconds at these widths)
         ref = torch.zeros(n, n, dtype=F64)
         O.cov_accum_tokens(ref, X.cpu())
-        assert entrywise_err(S8.cpu(), ref) < 1e-12
+        check_i8_error(entrywise_err(S8.cpu(), ref), info["bound"], family=kind, ctx=(n, "oracle"))
     # a second batch accumulates on top (the hook's +=), and the mirrored, normalised result is exactly symmetric
     X2 = (gaussian if kind == "gaussian" else silu_gated)(dev, 4096 + 40, n, 7 + n)
-    assert ops.cov_accum_i8(S8, X2) in (5, 6)
+    info2 = {}
+    assert ops.cov_accum_i8(S8, X2, route_info=info2) in (5, 6)
     ops.cov_accum(S64, X2)
-    assert entrywise_err(S8, S64) < 1e-12
+    check_i8_error(entrywise_err(S8, S64), max(info["bound"], info2["bound"]), family=kind, ctx=(n, "two batches"))
     ops.cov_finalize(S8, 1.0 / (T_BATCH + 4136))
     assert torch.equal(S8, S8.T)
 
@@ -124,12 +127,13 @@ def test_i8_route_across_the_int32_fold_with_super_blocks(ops, dev, kind, planes
     X = (gaussian if kind == "gaussian" else silu_gated)(dev, T, n, 11)
     S8 = torch.zeros(n, n, dtype=F64, device=dev)
     S64 = torch.zeros_like(S8)
-    assert ops.cov_accum_i8(S8, X) == planes
+    info = {}
+    assert ops.cov_accum_i8(S8, X, route_info=info) == planes
     ops.cov_accum(S64, X)
-    assert entrywise_err(S8, S64) < 1e-12
+    check_i8_error(entrywise_err(S8, S64), info["bound"], family=kind, ctx=info)
     ref = torch.zeros(n, n, dtype=F64)
     O.cov_accum_tokens(ref, X.cpu())
-    assert entrywise_err(S8.cpu(), ref) < 1e-12
+    check_i8_error(entrywise_err(S8.cpu(), ref), info["bound"], family=kind, ctx="oracle")
 
 
 @pytest.mark.parametrize("kind", ["gaussian", "silu_gated"])
@@ -170,14 +174,16 @@ def test_persistent_launch_shapes(ops, dev, n, T, kind):
     X = (gaussian if kind == "gaussian" else silu_gated)(dev, T, n, 31 + n)
     S8 = torch.zeros(n, n, dtype=F64, device=dev)
     S64 = torch.zeros_like(S8)
-    assert ops.cov_accum_i8(S8, X) in (5, 6)
+    info = {}
+    assert ops.cov_accum_i8(S8, X, route_info=info) in (5, 6)
     ops.cov_accum(S64, X)
-    assert entrywise_err(S8, S64) < 1e-12
+    check_i8_error(entrywise_err(S8, S64), info["bound"], family=kind, ctx=(n, T, info))
     # every tile of the lower triangle was visited exactly once: a second call doubles the result exactly
     ops.cov_accum_i8(S8, X)
     low = torch.tril(torch.ones(n, n, dtype=torch.bool, device=dev))
     ref = S64 * 2
-    assert entrywise_err(S8, ref) < 1e-12 and bool(torch.isfinite(S8[low]).all())
+    check_i8_error(entrywise_err(S8, ref), info["bound"], family=kind, ctx=(n, T, "second call"))
+    assert bool(torch.isfinite(S8[low]).all())
 
 
 def _fused_case(ops, dev, widths, heads, T, kind_first, seed):
@@ -194,16 +200,19 @@ def _fused_case(ops, dev, widths, heads, T, kind_first, seed):
         R = torch.zeros_like(sigma)
         ops.cov_accum(R, X, n_heads=nh)
         refs.append(R)
-    route = ops.cov_accum_i8_multi(items, report=True)
-    return items, refs, route
+    info = []
+    route = ops.cov_accum_i8_multi(items, report=True, route_info=info)
+    return items, refs, route, info
 
 
-def _check_against(S, R):
+def _check_against(S, R, bound=None, family="gaussian"):
+    """bound: the statistic's own reported bound where the caller read it back (else the guarantee 1.1e-11); family: the data of
+    the _fused_case / cov_accum_multi tests are gaussian or silu_gated -- both measured families (empirical 1e-12 asserted too)."""
     if S.dim() == 2:
-        assert entrywise_err(S, R) < 1e-12
+        check_i8_error(entrywise_err(S, R), bound, family=family)
     else:
         for h in range(S.shape[0]):
-            assert entrywise_err(S[h], R[h]) < 1e-12, h
+            check_i8_error(entrywise_err(S[h], R[h]), bound, family=family, ctx=h)
 
 
 @pytest.mark.parametrize("widths,heads,T,kind,planes", [
@@ -217,17 +226,18 @@ def _check_against(S, R):
 def test_fused_int8_launch_of_a_layers_statistics(ops, dev, widths, heads, T, kind, planes):
     """mdg_cov_accum_i8_multi: sigma_mlp, sigma_x and the per-head sigma_q / sigma_k (head_dim 128: diagonal tiles only) of one
     batch in ONE persistent launch over a shared tile schedule, one route for all.  Every statistic against the v_mfma_f64
-    kernel entry-wise (1e-12), a second call doubling the result, and the device route counters advancing by the number of
+    kernel entry-wise (within its own bound), a second call doubling the result, and the device route counters advancing by the number of
     statistics."""
     ops.i8_route_counts(dev, reset=True)
-    items, refs, route = _fused_case(ops, dev, widths, heads, T, kind, 900 + T % 97)
+    items, refs, route, info = _fused_case(ops, dev, widths, heads, T, kind, 900 + T % 97)
     assert route == planes or (planes is None and route in (5, 6))
     planes = route
-    for (S, _, _), R in zip(items, refs):
-        _check_against(S, R)
+    fam = ["silu_gated" if (i == 0 and kind == "silu_gated") else "gaussian" for i in range(len(items))]
+    for (S, _, _), R, i_, f_ in zip(items, refs, info, fam):
+        _check_against(S, R, i_["bound"], f_)
     ops.cov_accum_i8_multi(items, report=False)
-    for (S, _, _), R in zip(items, refs):
-        _check_against(S, 2 * R)
+    for (S, _, _), R, i_, f_ in zip(items, refs, info, fam):
+        _check_against(S, 2 * R, i_["bound"], f_)
     counts = ops.i8_route_counts(dev, reset=True)
     assert counts[{5: "i8_5", 6: "i8_6"}[planes]] == 2 * len(items) and counts["i8_5"] + counts["i8_6"] + counts["fallback_f64"] == 2 * len(items)
     assert counts["fp64_columns"] == 0 or T < 10240        # (short calls: the cross-term threshold is tighter, columns may leave)
@@ -257,9 +267,9 @@ def test_fused_int8_launch_lets_columns_and_statistics_leave_alone(ops, dev):
         R = torch.zeros_like(S)
         ops.cov_accum(R, X, n_heads=nh)
         refs.append(R)
-    for (S, _, _), R in zip(items, refs):
-        _check_against(S, R)
-    assert not torch.equal(items[0][0], refs[0])           # (an int8 result: equal to 1e-12, not to the bit)
+    for (S, _, _), R, i_ in zip(items, refs, info):
+        _check_against(S, R, i_["bound"], "outliers" if i_["columns"] else "gaussian")
+    assert not torch.equal(items[0][0], refs[0])           # (an int8 result: equal within its bound, not to the bit)
     # a statistic with nothing the int8 path can certify goes to the fp64 kernel, alone
     Xh = (torch.randn(T, 2048, device=dev) ** 5 * torch.randn(T, 2048, device=dev) ** 3).to(torch.bfloat16)
     Rh = torch.zeros(2048, 2048, dtype=F64, device=dev)
@@ -290,7 +300,8 @@ def massive(X, cols, spikes=3, gap=12, seed=0):
 def test_massive_activation_columns_leave_alone_at_product_widths(ops, dev, n, kind, planes):
     """four BOS-like columns (bulk 12-15 binades under 3 spikes) at the widths of sigma_x and sigma_mlp.  The
     launch stays on its digit planes, exactly those four columns go to the fp64 column kernel, every entry equals the fp64
-    kernel's to 1e-12, and the call costs less than 5 % more than the clean one."""
+    kernel's within the call's bound (and the empirical 1e-12 of this measured family), and the call costs less than 5 % more than
+    the clean one."""
     cols = [5, 129, n // 2 + 77, n - 1]
     X0 = (gaussian if kind == "gaussian" else silu_gated)(dev, T_BATCH, n, 300 + n)
     X = massive(X0, cols)
@@ -300,8 +311,7 @@ def test_massive_activation_columns_leave_alone_at_product_widths(ops, dev, n, k
     assert ops.cov_accum_i8(S8, X, route_info=info) == planes
     assert sorted(info["columns"]) == cols and info["bound"] <= 1.1e-11, info
     ops.cov_accum(S64, X)
-    err = entrywise_err(S8, S64)
-    assert err < 1e-12 and err <= info["bound"] + 1e-15, (err, info)
+    check_i8_error(entrywise_err(S8, S64), info["bound"], family="outliers", ctx=info)
     # the clean batch takes the same planes, no columns
     info0 = {}
     assert ops.cov_accum_i8(S8, X0, route_info=info0) == planes and info0["columns"] == []
@@ -337,14 +347,13 @@ def test_device_route_equals_the_host_model_at_sigma_x_width(ops, dev):
         assert (info["planes"], info["columns"]) == (want["planes"], want["columns"]), (kind, cols, info, want["planes"], want["columns"])
         assert abs(info["sq"] - want["sq"]) <= 1e-9 * want["sq"] and abs(info["x"] - want["x"]) <= 1e-9 * want["x"]
         ops.cov_accum(S64, X)
-        err = entrywise_err(S8, S64)
-        assert err < 1e-12 and err <= info["bound"] + 1e-15, (kind, cols, err, info)
+        check_i8_error(entrywise_err(S8, S64), info["bound"], family="outliers" if cols else kind, ctx=(kind, cols, info))
 
 
 def test_cov_accum_multi_routes_a_llama_layer(ops, dev, monkeypatch):
     """ops.cov_accum_multi in "i8" mode (what the adapter hooks call): sigma_mlp in a launch and on a route of its own (six
     planes on SiLU-gated data), sigma_x + sigma_q + sigma_k together in one cov_accum_i8_multi launch (five planes); with
-    MODEGPT_I8_FUSE off the per-head statistics go through the fp64 kernel instead -- same results to 1e-12."""
+    MODEGPT_I8_FUSE off the per-head statistics go through the fp64 kernel instead -- same results within the route's bound."""
     T, f, d, nh, nkv = 12288, 4096, 2048, 8, 2
     H, X, Q, K = silu_gated(dev, T, f, 1), gaussian(dev, T, d, 2), gaussian(dev, T, nh * 128, 3), gaussian(dev, T, nkv * 128, 4)
 
@@ -360,5 +369,5 @@ def test_cov_accum_multi_routes_a_llama_layer(ops, dev, monkeypatch):
     apart, c0 = run(False)
     assert c1 == {"i8_5": 3, "i8_6": 1, "fallback_f64": 0, "fp64_columns": 0}   # sigma_mlp alone on six planes; x, q, k share a five-plane launch
     assert c0 == {"i8_5": 1, "i8_6": 1, "fallback_f64": 0, "fp64_columns": 0}   # separate launches: sigma_mlp six planes, sigma_x five, heads fp64
-    for a, b in zip(fused, apart):
-        _check_against(a, b)
+    for i, (a, b) in enumerate(zip(fused, apart)):
+        _check_against(a, b, None, "silu_gated" if i == 0 else "gaussian")

@@ -5,6 +5,7 @@ import torch
 
 from oracle import modegpt_oracle as O
 from tests.golden_util import CASES, ROPE_CASES, Case, RopeCase, canon_rows, vo_products
+from tests.i8_limits import check_i8_error
 
 pytestmark = pytest.mark.gpu
 F64 = torch.float64
@@ -578,38 +579,80 @@ def check_route(info, X, tolerance=1.0):
     return want
 
 
-def test_cov_i8_tolerance_dial(ops, dev):
-    """mdg_cov_i8_set_tolerance: one factor on both thresholds of the route.  SiLU-gated columns need six planes at the default
-    and take five at x64 (fewer plane pairs, a looser but still COMPUTED and respected bound); the device's decision equals the
-    host model's at that factor; the factor is process-wide state and goes back to 1."""
+def test_cov_i8_tolerance_is_an_argument_of_the_call(ops, dev):
+    """ABI 9: the route's tolerance factor travels with each call (mdg_cov_accum_i8's `tolerance`); the library keeps no accuracy
+    state.  SiLU-gated columns need six planes at factor 1 and take five at 64 (fewer plane pairs, a looser but still COMPUTED and
+    respected bound); the device's decision equals the host model's at that factor.  Two host threads with different factors, calling
+    at the same time, each get the route of their OWN factor -- through the explicit argument and through the thread's default
+    (ops.i8_tolerance_scope); the process default (ops.set_i8_tolerance) is Python-side only and untouched by either."""
+    import threading
     gen = torch.Generator().manual_seed(31)
     T, n = 24576, 256
     X = (torch.nn.functional.silu(torch.randn(T, n, generator=gen)) * torch.randn(T, n, generator=gen)).to(torch.bfloat16)
     ref = torch.zeros(n, n, dtype=F64)
     O.cov_accum_tokens(ref, X)
-    assert ops.set_i8_tolerance(1.0) == 1.0
-    got = {}
+    Xd = X.to(dev)
+    assert ops.i8_tolerance() == 1.0
+    got, failures = {}, []
+    barrier = threading.Barrier(2)
+
+    def worker(factor, explicit):
+        try:
+            stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(stream):
+                for rep in range(3):
+                    S = torch.zeros(n, n, dtype=F64, device=dev)
+                    info = {}
+                    barrier.wait(timeout=60)      # both threads enqueue their call at the same moment
+                    if explicit:
+                        planes = ops.cov_accum_i8(S, Xd, route_info=info, tolerance=factor)
+                    else:
+                        with ops.i8_tolerance_scope(factor):
+                            assert ops.i8_tolerance() == factor
+                            planes = ops.cov_accum_i8(S, Xd, route_info=info)
+                    check_route(info, X, tolerance=factor)
+                    err = entry_err(S, ref)
+                    assert info["sq"] <= factor * 1e-12 and info["x"] <= factor * 1e-11, (factor, info)
+                    check_i8_error(err, info["bound"], family="silu_gated", tolerance=factor, ctx=(factor, explicit, rep))
+                    got.setdefault(factor, set()).add(planes)
+        except BaseException as e:     # noqa: BLE001  (reported by the main thread)
+            failures.append((factor, repr(e)))
+            barrier.abort()
+
+    for explicit in (True, False):
+        threads = [threading.Thread(target=worker, args=(f, explicit)) for f in (1.0, 64.0)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        barrier.reset()
+        assert not failures, failures
+    assert got == {1.0: {6}, 64.0: {5}}, got
+    assert ops.i8_tolerance() == 1.0            # a scope is the thread's own
+    # the process default: Python-side, validated, restored
+    assert ops.set_i8_tolerance(64.0) == 1.0
     try:
-        for factor in (1.0, 64.0):
-            ops.set_i8_tolerance(factor)
-            S = torch.zeros(n, n, dtype=F64, device=dev)
-            info = {}
-            planes = ops.cov_accum_i8(S, X.to(dev), route_info=info)
-            check_route(info, X, tolerance=factor)
-            err = entry_err(S, ref)
-            assert err <= info["bound"] + 1e-15 and info["sq"] <= factor * 1e-12 and info["x"] <= factor * 1e-11, (factor, err, info)
-            got[factor] = (planes, err, info["bound"])
-        with pytest.raises(RuntimeError, match="outside"):
-            ops.set_i8_tolerance(0.5)
+        S = torch.zeros(n, n, dtype=F64, device=dev)
+        assert ops.cov_accum_i8(S, Xd) == 5 and ops.cov_accum_i8(S, Xd, tolerance=1.0) == 6
     finally:
         assert ops.set_i8_tolerance(1.0) == 64.0
-    assert got[1.0][0] == 6 and got[1.0][1] < 1e-12 and got[64.0][0] == 5 and got[64.0][1] < 64e-12, got
+    with pytest.raises(ValueError, match="outside"):
+        ops.set_i8_tolerance(0.5)
+    with pytest.raises(RuntimeError, match="outside"):       # the library refuses it too (a caller of the C ABI has no Python check)
+        from modegpt_amd import _lib
+        import ctypes as C
+        lib = _lib.load()
+        ws = torch.empty(lib.mdg_cov_accum_i8_ws_bytes(T, n), dtype=torch.uint8, device=dev)
+        S = torch.zeros(n, n, dtype=F64, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.mdg_cov_accum_i8(Xd.data_ptr(), T, n, n, S.data_ptr(), n, ws.data_ptr(), ws.numel(), 0.5, None, None, None, None,
+                                            torch.cuda.current_stream(dev).cuda_stream), "mdg_cov_accum_i8")
 
 
 @pytest.mark.parametrize("tokens,feat", [(777, 256), (4096, 128), (33, 384), (20000, 256), (65504 + 3000, 128)])
 def test_cov_i8_matches_the_fp64_oracle(ops, dev, tokens, feat):
     """The int8 route (error-free split, truncated product) against the oracle's fp64 X^T X, entry-wise over sqrt(s_ii s_jj):
-    below 1e-12 AND below the bound the call itself computed; the route equals the host model's; a second call accumulates;
+    below the bound the call itself computed (guaranteed) and below 1e-12 (the empirical figure of this family); the route equals the host model's; a second call accumulates;
     68504 tokens cross the int32 fold boundary (2047 k-steps = 65504 tokens, scripts/probes/i8_int32_bound.py)."""
     gen = torch.Generator().manual_seed(tokens + feat)
     X = acts(gen, tokens, feat)
@@ -619,12 +662,11 @@ def test_cov_i8_matches_the_fp64_oracle(ops, dev, tokens, feat):
     info = {}
     assert ops.cov_accum_i8(S, X.to(dev), route_info=info) in (5, 6)
     check_route(info, X)
-    err = entry_err(S, ref)
-    assert err < 1e-12 and err <= info["bound"] + 1e-15, (err, info)
+    check_i8_error(entry_err(S, ref), info["bound"], family="gaussian", ctx=info)
     X2 = acts(gen, 200, feat)
     O.cov_accum_tokens(ref, X2)
     assert ops.cov_accum_i8(S, X2.to(dev)) in (5, 6)
-    assert entry_err(S, ref) < 1e-12
+    check_i8_error(entry_err(S, ref), family="gaussian")      # (two calls: each within its own bound of the accumulated diagonal)
 
 
 def test_cov_i8_agrees_with_the_fp64_kernel_and_is_deterministic(ops, dev):
@@ -636,7 +678,7 @@ def test_cov_i8_agrees_with_the_fp64_kernel_and_is_deterministic(ops, dev):
     assert ops.cov_accum_i8(S8, X) == 5 and ops.cov_accum_i8(S8b, X) == 5
     ops.cov_accum(S64, X)
     assert torch.equal(S8, S8b), "integer accumulation: bit-identical from run to run"
-    assert entry_err(S8, torch.tril(S64) + torch.tril(S64, -1).T) < 1e-12
+    check_i8_error(entry_err(S8, torch.tril(S64) + torch.tril(S64, -1).T), family="gaussian")
     ops.cov_finalize(S8, 1.0 / 5000)
     assert torch.equal(S8, S8.T)
 
@@ -658,7 +700,7 @@ def test_cov_i8_hands_outlier_columns_to_the_fp64_column_kernel(ops, dev):
     assert sorted(info["columns"]) == [40, 131]
     check_route(info, X)
     assert ops.i8_route_counts(dev, reset=True) == {"i8_5": 1, "i8_6": 0, "fallback_f64": 0, "fp64_columns": 2}
-    assert entry_err(S, ref) < 1e-12
+    check_i8_error(entry_err(S, ref), info["bound"], family="outliers", ctx=info)
     low = torch.tril(S).cpu()
     full = low + torch.tril(low, -1).T
     for j in (40, 131):      # the column kernel's entries: fp64 sums of exact products
@@ -671,13 +713,13 @@ def test_cov_i8_hands_outlier_columns_to_the_fp64_column_kernel(ops, dev):
     info2 = {}
     assert ops.cov_accum_i8(S, X2.to(dev), route_info=info2) == 5 and info2["columns"][0] == 200
     check_route(info2, X2)      # (1000 tokens: the threshold on the cross terms is 1e-12, a few more columns leave to stay on five planes)
-    assert entry_err(S, ref) < 1e-12
+    check_i8_error(entry_err(S, ref), max(info["bound"], info2["bound"]), family="outliers", ctx=(info, info2))
     # the same through the strided / unaligned element-wise passes
     wide = torch.zeros(3000, 263, dtype=torch.bfloat16)
     wide[:, 3:259] = X
     S3 = torch.zeros(256, 256, dtype=F64, device=dev)
     assert ops.cov_accum_i8(S3, wide.to(dev)[:, 3:259]) == 5
-    assert entry_err(S3, ref_first) < 1e-12
+    check_i8_error(entry_err(S3, ref_first), info["bound"], family="outliers")
 
 
 @pytest.mark.parametrize("kind", ["silu_gated", "laplace", "relu", "cubed", "student_t"])
@@ -685,7 +727,8 @@ def test_cov_i8_route_follows_the_error_bound(ops, dev, kind):
     """The route is derived from the per-call bound (Cauchy-Schwarz on the plane energies): light tails -> five planes,
     SiLU-gated products (the MLP statistic of a real Llama) -> six, heavier tails -> columns leave for the fp64 column kernel
     or, when 32 are not enough, the whole statistic goes to the fp64 kernel.  Whatever is chosen must equal the host model's
-    choice and hold the measured error below 1e-12 and below the computed bound."""
+    choice and hold the measured error below the computed bound (<= 1.1e-11: the guarantee) -- and, on these measured families,
+    below the empirical 1e-12."""
     gen = torch.Generator().manual_seed(21)
     T, n = 6000, 256
     g, u = torch.randn(T, n, generator=gen), torch.randn(T, n, generator=gen)
@@ -700,9 +743,10 @@ def test_cov_i8_route_follows_the_error_bound(ops, dev, kind):
     assert planes == want["planes"]
     assert planes == {"silu_gated": 6, "relu": 5}.get(kind, planes)
     err = entry_err(S, ref)
-    assert err < 1e-12, err
     if planes:
-        assert info["bound"] <= 1.1e-11 and err <= info["bound"] + 1e-15, (err, info)
+        check_i8_error(err, info["bound"], family={"relu": "one_signed"}.get(kind, kind), ctx=info)
+    else:
+        assert err < 1e-13, err      # the whole statistic went through the fp64 kernel: fp64 rounding only
 
 
 def test_cov_i8_special_values_and_errors(ops, dev):
@@ -718,7 +762,7 @@ def test_cov_i8_special_values_and_errors(ops, dev):
     S = torch.zeros(128, 128, dtype=F64, device=dev)
     ops.cov_accum_i8(S, X.to(dev))
     low = torch.tril(torch.ones(128, 128, dtype=torch.bool))
-    assert ((S.cpu() - ref)[low].abs().max() / ref.abs().max()).item() < 1e-12
+    check_i8_error(((S.cpu() - ref)[low].abs().max() / ref.abs().max()).item(), family="gaussian")
     assert S[9, 9].item() == ref[9, 9].item() != 0.0          # products of denormals are exact
     Xn = X.clone()
     Xn[3, 7] = float("inf")
@@ -733,7 +777,20 @@ def test_cov_i8_special_values_and_errors(ops, dev):
     assert torch.equal(torch.isfinite(Sn.cpu())[lown], torch.isfinite(refn)[lown])   # ... which propagates them as the reference does
     assert not bool(torch.isfinite(Sn[7, 7])) and not bool(torch.isfinite(Sn[100, 7]))
     fin = torch.isfinite(refn) & lown
-    assert ((Sn.cpu() - refn)[fin].abs().max() / ref.abs().max()).item() < 1e-12
+    check_i8_error(((Sn.cpu() - refn)[fin].abs().max() / ref.abs().max()).item(), info["bound"], family="gaussian")
+    # An Inf in the LAST token of a call whose token chunks do not end on the column kernel's batch of 8 (1003 tokens -> chunks of
+    # 16, the last one 11 long): the entries of that column are +-Inf, as in the reference's fp64 product -- not NaN (the kernel's
+    # padding slots used to re-read the last token against a zero: 0 * Inf)
+    Xi = acts(gen, 1003, 128).abs() + torch.tensor(0.25).to(torch.bfloat16)       # (no zeros: every reference entry of the column is +Inf)
+    Xi[1002, 21] = float("inf")
+    Si = torch.zeros(128, 128, dtype=F64, device=dev)
+    infoi = {}
+    assert ops.cov_accum_i8(Si, Xi.to(dev), route_info=infoi) in (5, 6) and infoi["columns"] == [21]
+    refi = torch.zeros(128, 128, dtype=F64)
+    O.cov_accum_tokens(refi, Xi)
+    got_i, low_i = Si.cpu(), torch.tril(torch.ones(128, 128, dtype=torch.bool))
+    assert bool(torch.isinf(refi[21]).all()) and not bool(torch.isnan(got_i[low_i]).any())
+    assert torch.equal(torch.isinf(got_i)[low_i], torch.isinf(refi)[low_i]) and bool((got_i[low_i][torch.isinf(got_i)[low_i]] > 0).all())
     with pytest.raises(RuntimeError, match="multiple of 128"):
         ops.cov_accum_i8(torch.zeros(200, 200, dtype=F64, device=dev), acts(gen, 64, 200).to(dev))
     with pytest.raises(ValueError):
@@ -751,7 +808,7 @@ def test_cov_i8_reads_a_column_slice_in_place(ops, dev):
     ref = torch.zeros(384, 384, dtype=F64)
     O.cov_accum_tokens(ref, X.cpu())
     low = torch.tril(torch.ones(384, 384, dtype=torch.bool))
-    assert ((S.cpu() - ref)[low].abs().max() / ref.abs().max()).item() < 1e-12
+    check_i8_error(((S.cpu() - ref)[low].abs().max() / ref.abs().max()).item(), family="gaussian")
     # rows that are not 16-byte addressable (odd pitch, 6-byte offset): the element-wise passes
     odd = acts(gen, 900, 653).to(dev)
     Y = odd[:, 3:3 + 384]
@@ -759,12 +816,13 @@ def test_cov_i8_reads_a_column_slice_in_place(ops, dev):
     assert ops.cov_accum_i8(S2, Y) == 5
     ref2 = torch.zeros(384, 384, dtype=F64)
     O.cov_accum_tokens(ref2, Y.cpu())
-    assert ((S2.cpu() - ref2)[low].abs().max() / ref2.abs().max()).item() < 1e-12
+    check_i8_error(((S2.cpu() - ref2)[low].abs().max() / ref2.abs().max()).item(), family="gaussian")
 
 
 def test_cov_i8_randomised_shapes_and_scales(ops, dev):
     """Sweep of shapes, column scales across the whole bf16 exponent range (2^-120 .. 2^120), sparse columns, sign patterns:
-    whichever route a call takes, it must agree with the fp64 kernel entry-wise to 1e-12 of sqrt(sigma_ii sigma_jj)."""
+    whichever route a call takes, it must agree with the fp64 kernel entry-wise within the bound it computed (guaranteed) and, these
+    being measured families, within the empirical 1e-12 of sqrt(sigma_ii sigma_jj)."""
     gen = torch.Generator().manual_seed(2024)
     routes = set()
     for trial in range(12):
@@ -782,13 +840,17 @@ def test_cov_i8_randomised_shapes_and_scales(ops, dev):
         X = (z.double() * torch.pow(torch.tensor(2.0, dtype=F64), expo)).to(torch.bfloat16).to(dev)
         S8 = torch.zeros(n, n, dtype=F64, device=dev)
         S64 = torch.zeros_like(S8)
-        routes.add(ops.cov_accum_i8(S8, X))
+        info = {}
+        routes.add(ops.cov_accum_i8(S8, X, route_info=info))
         ops.cov_accum(S64, X)
         d = torch.sqrt(torch.diag(S64))
         d = torch.where(d > 0, d, torch.ones_like(d))
         low = torch.tril(torch.ones(n, n, dtype=torch.bool, device=dev))
         err = (((S8 - S64).abs() / (d[:, None] * d[None]))[low]).max().item()
-        assert err < 1e-12, (trial, T, n, kind, err)
+        if info["planes"]:
+            check_i8_error(err, info["bound"], family=("gaussian", "sparse", "one_signed", "silu_gated")[kind], ctx=(trial, T, n, kind))
+        else:
+            assert err < 1e-13, (trial, T, n, kind, err)
         assert bool(torch.isfinite(S8[low]).all())
     assert routes & {5, 6}, routes
 
@@ -819,7 +881,7 @@ def test_cov_accum_multi_side_stream_overlap_changes_nothing(ops, dev, monkeypat
     for _, q, _ in batches:
         O.cov_accum_heads(ref, q.cpu(), nh, hd)
     low = torch.tril(torch.ones(hd, hd, dtype=torch.bool))
-    assert ((a[1].cpu() - ref)[:, low].abs().max() / ref.abs().max()).item() < 1e-12
+    assert ((a[1].cpu() - ref)[:, low].abs().max() / ref.abs().max()).item() < 1e-12      # (head_dim 64: the fp64 kernel)
 
 
 def test_cov_i8_zero_plane_skipping_is_exact(ops, dev, monkeypatch):
@@ -854,7 +916,7 @@ def test_cov_i8_zero_plane_skipping_is_exact(ops, dev, monkeypatch):
     d = torch.sqrt(torch.diag(S64))
     low = torch.tril(torch.ones(n, n, dtype=torch.bool, device=dev))
     err = (((S8 - S64).abs() / (d[:, None] * d[None]))[low]).max().item()
-    assert err < 1e-12, err
+    check_i8_error(err, family="gaussian")
     pairs, floor_pairs = {5: (15, 9), 6: (21, 15)}[planes]
     assert stats["dense"] == ops.i8_dense_mfma_count(T, n, planes)
     assert stats["dense"] * floor_pairs // pairs <= stats["executed"] < stats["dense"], stats
@@ -874,7 +936,7 @@ def test_cov_i8_zero_plane_skipping_is_exact(ops, dev, monkeypatch):
     ops.cov_accum(R6, Z)
     d6 = torch.sqrt(torch.diag(R6))
     low6 = torch.tril(torch.ones(256, 256, dtype=torch.bool, device=dev))
-    assert (((S6 - R6).abs() / (d6[:, None] * d6[None]))[low6]).max().item() < 1e-12
+    check_i8_error((((S6 - R6).abs() / (d6[:, None] * d6[None]))[low6]).max().item(), family="silu_gated")
 
 
 # ---------------------------------------------------------------- the collective behind the C ABI

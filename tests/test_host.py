@@ -381,9 +381,11 @@ def test_every_reference_function_exists_with_its_parameters(rel_path):
     assert not problems, "\n".join(problems)
 
 
-def test_gpu_tensor_without_the_engine_is_an_error_not_a_silent_torch_run(monkeypatch):
-    """in the shipped modeling file a tensor on a GPU with modegpt_amd un-importable raises (a broken
-    installation on a GPU box), unless MODEGPT_ALLOW_TORCH=1; CPU tensors keep the portable torch path."""
+def test_gpu_tensor_with_a_broken_engine_is_an_error_and_without_the_engine_is_portable(monkeypatch):
+    """The shipped modeling file: a tensor on a GPU while modegpt_amd IS installed but its library does not load raises (a broken
+    installation on a GPU box: VERDICT r2 item 10), unless MODEGPT_ALLOW_TORCH=1; a machine WITHOUT the engine keeps the portable
+    torch path with one warning -- a compressed checkpoint evaluates wherever the reference's would; CPU tensors always
+    take the portable path."""
     import torch
     from modegpt_amd.patchers import compressed_attention as ca
 
@@ -391,10 +393,21 @@ def test_gpu_tensor_without_the_engine_is_an_error_not_a_silent_torch_run(monkey
         is_cuda = True
         device = "cuda:0"
     monkeypatch.setattr(ca, "_hip_ops", lambda: None)
+    monkeypatch.setattr(ca, "_HIP_BROKEN", "ModeGPTLibraryError: libmodegpt_hip.so is missing")
     monkeypatch.delenv("MODEGPT_REQUIRE_HIP", raising=False)
     monkeypatch.delenv("MODEGPT_ALLOW_TORCH", raising=False)
     with pytest.raises(RuntimeError, match="MODEGPT_ALLOW_TORCH"):
         ca._rope_gather(OnGpu(), None, None, None, 4, 4, 16)
+    # engine absent (not broken): the GPU tensor reaches the torch expression (here it fails inside it: the stand-in is no tensor)
+    monkeypatch.setattr(ca, "_HIP_BROKEN", None)
+    calls = ca.PATH_CALLS["torch"]
+    with pytest.raises((AttributeError, TypeError)):
+        ca._rope_gather(OnGpu(), None, None, None, 4, 4, 16)
+    assert ca.PATH_CALLS["torch"] == calls + 1
+    monkeypatch.setenv("MODEGPT_REQUIRE_HIP", "1")          # the strict opt-in
+    with pytest.raises(RuntimeError, match="MODEGPT_REQUIRE_HIP"):
+        ca._rope_gather(OnGpu(), None, None, None, 4, 4, 16)
+    monkeypatch.delenv("MODEGPT_REQUIRE_HIP")
     x = torch.randn(1, 3, 4 * 8).to(torch.bfloat16)
     ang = torch.rand(1, 3, 8)
     cos, sin = torch.cat((ang, ang), -1).cos(), torch.cat((ang, ang), -1).sin()
