@@ -37,7 +37,7 @@ extern "C" {
                              8: mdg_cov_i8_set_tolerance / mdg_cov_i8_tolerance, mdg_nystrom_down_overlapped added;
                              9: the int8 route's tolerance factor is an ARGUMENT of mdg_cov_accum_i8 / mdg_cov_accum_i8_multi (the
                                 process-wide setter / getter of ABI 8 are gone: no accuracy state in the library);
-                                mdg_ridge_select_margin added (certificate of the MLP rank selection) */
+                                mdg_ridge_scores takes `sens`, mdg_select_margin added (certificate of the MLP rank selection) */
 
 enum mdg_status {
   MDG_OK = 0,
@@ -222,13 +222,29 @@ int mdg_syevj_batched(double* A, int64_t n, int64_t batch, double* evals, double
 
 /* ------------------------------------------------------------------ MLP: ridge-leverage + Nystrom
  * scores = diag((C + ridge I)^-1).  `ridge` is added as given: pass the fp32-rounded lambda to reproduce the
- * float32 eye of compress_mlp.py:18.  C is not modified.  ws: mdg_ridge_scores_ws_bytes(n).  SYNCHRONISES. */
+ * float32 eye of compress_mlp.py:18.  C is not modified.  ws: mdg_ridge_scores_ws_bytes(n).  SYNCHRONISES.
+ * sens (optional, [n]; NULL = not wanted): the first-order sensitivity of every score to an ENTRY-WISE RELATIVE perturbation of C,
+ * |E_ab| <= eps sqrt(c_aa c_bb) -- the form of the covariance routes' error bounds (mdg_cov_accum_i8: eps <= 1.1e-11 guaranteed;
+ * fp64 accumulation: eps <= tokens 2^-53):  |delta scores[j]| <= eps sens[j] + O(eps^2),
+ *     sens[j] = (sum_b |X_bj| sum_a |X_ba| sqrt(c_aa))^2 >= (sum_a sqrt(c_aa) |((C + ridge I)^-1)_aj|)^2,   X = inv(chol(C + ridge I)).
+ * Two extra passes over the triangle of X the call holds anyway (1.6 GB of reads at n = 14336, < 1 ms); the scores are the same
+ * bits with or without it. */
 size_t mdg_ridge_scores_ws_bytes(int64_t n);
-int mdg_ridge_scores(const double* C, int64_t n, int64_t ldc, double ridge, double* scores, void* ws,
+int mdg_ridge_scores(const double* C, int64_t n, int64_t ldc, double ridge, double* scores, double* sens, void* ws,
                      size_t ws_bytes, void* stream);
 /* idx[0..k) = indices of the k smallest scores, ascending index order (topk(largest=False) + sort,
  * compress_mlp.py:45-47).  Ties: lower index first.  NaN ranks as largest. */
 int mdg_select_smallest_sorted(const double* scores, int64_t n, int64_t k, int64_t* idx, void* stream);
+/* The certificate of that selection ("rank selections bit-identical" made checkable): with every score known only up to
+ * eps * sens[j] (mdg_ridge_scores), can the selected SET differ?  idx [k]: the selection (ascending); out8 (DEVICE, 8 doubles):
+ *   [0] largest selected score s_(k)      [1] smallest unselected score s_(k+1)     -> margin = ([1] - [0]) / [0]
+ *   [2] max over selected of s + eps sens [3] min over unselected of s - eps sens   -> certified iff [2] < [3]
+ *   [4] / [5] largest sens among the selected / unselected   ([1] - [0]) / ([4] + [5]) <= the largest eps that still certifies
+ *   [6] how many scores' intervals reach across the midpoint of [0] and [1]        [7] 1.0 if certified else 0.0
+ * Only enqueues; the caller reads the 8 doubles when it next waits for the stream (modegpt_amd reads them with the chain's
+ * status).  Not in the reference: there the selection is whatever torch.topk makes of the fp64 scores (compress_mlp.py:45-47). */
+int mdg_select_margin(const double* scores, const double* sens, const int64_t* idx, int64_t n, int64_t k, double eps,
+                      double* out8, void* stream);
 /* out[i,:] = src[rows[i],:] for 2-byte elements (W_u[topk,:], W_g[topk,:], compress_mlp.py:49-50;
  * Q/K row gathers, compress_qk.py:375-376). */
 int mdg_gather_rows_16(const void* src, int64_t ld_src, const int64_t* rows, int64_t n_rows, int64_t n_cols,

@@ -62,8 +62,9 @@ SIGNATURES = {
     "mdg_chol_inverse_diag": (_i32, [_ptr, _i64, _i64, _ptr, _ptr, _ptr, _sz, _ptr]),
     "mdg_syevj_batched": (_i32, [_ptr, _i64, _i64, _ptr, _ptr, _ptr]),
     "mdg_ridge_scores_ws_bytes": (_sz, [_i64]),
-    "mdg_ridge_scores": (_i32, [_ptr, _i64, _i64, _f64, _ptr, _ptr, _sz, _ptr]),
+    "mdg_ridge_scores": (_i32, [_ptr, _i64, _i64, _f64, _ptr, _ptr, _ptr, _sz, _ptr]),
     "mdg_select_smallest_sorted": (_i32, [_ptr, _i64, _i64, _ptr, _ptr]),
+    "mdg_select_margin": (_i32, [_ptr, _ptr, _ptr, _i64, _i64, _f64, _ptr, _ptr]),
     "mdg_gather_rows_16": (_i32, [_ptr, _i64, _ptr, _i64, _i64, _ptr, _i64, _ptr]),
     "mdg_nystrom_down_ws_bytes": (_sz, [_i64, _i64, _i64]),
     "mdg_nystrom_down": (_i32, [_ptr, _i64, _i64, _ptr, _i64, _ptr, _i64, _i64, _i32, _f64, _ptr, _i64, _ptr, _ptr, _sz,

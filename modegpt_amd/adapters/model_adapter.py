@@ -79,6 +79,35 @@ class ModelAdapter(ABC):
         that keeps results on the device (engine.TensorAdapter) collects the statuses and checks them later."""
         status.check()
 
+    # ---- the certificate of the MLP rank selections (not upstream; north_star: "rank selections bit-identical") ----
+    def selection_margin(self, layer_idx: int, out8, eps: float) -> None:
+        """compress_nystrom hands over ops.select_margin's 8 numbers (still on the device) for layer `layer_idx`."""
+        self.__dict__.setdefault("_selection_margins", {})[int(layer_idx)] = (out8, float(eps))
+
+    def report_selection_margins(self, log=None) -> dict:
+        """Reads the recorded certificates (one 64-byte copy per layer; call it where the host waits for the chains anyway), writes
+        them to metrics["mlp_selection"] = {layer: {"margin", "score_bound", "eps", "eps_certifiable", "scores_at_risk", "certified"}}
+        and WARNS for every layer whose selection the covariance error bound cannot certify: there the k-th and (k+1)-th ridge
+        scores sit closer than the bound on what the route's sigma error can do to them, and another accumulation order / route /
+        the reference's CPU arithmetic may select a different column set (compress_mlp.py:45-47)."""
+        log = log or logging.getLogger("MoDeGPT")
+        pending = self.__dict__.pop("_selection_margins", {})
+        report = {}
+        for layer in sorted(pending):
+            out8, eps = pending[layer]
+            m = ops.decode_margin(out8.cpu().tolist(), eps)
+            report[layer] = {k: m[k] for k in ("margin", "score_bound", "eps", "eps_certifiable", "scores_at_risk", "certified")}
+            if not m["certified"]:
+                log.warning(f"[MLP] Layer {layer}: rank selection NOT certified -- threshold margin {m['margin']:.3e} against a score "
+                            f"perturbation bound {m['score_bound']:.3e} (covariance error bound eps = {eps:.2e}); "
+                            f"{m['scores_at_risk']} scores within reach of the threshold")
+        if report:
+            if not isinstance(getattr(self, "metrics", None), dict):
+                self.metrics = {}
+            store = self.metrics.setdefault("mlp_selection", {})
+            store.update({str(k): v for k, v in report.items()})
+        return report
+
     # ---- reconstruction: per-(layer, stage) artefacts and the final swap (model_adapter.py:184-237) ----
     def save_layer(self, output_dir: str, suffix: str, weights: dict, layer_idx):
         """torch.save({name: bf16 tensor}) to <output_dir>/layer_<i>_<suffix>; env vars in the path expand.  The file is in

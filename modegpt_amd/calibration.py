@@ -121,10 +121,11 @@ def _calibrate_model(adapter: ModelAdapter, n_samples: int, batch_size: int, tar
     hidden_states_before = getattr(model.config, "output_hidden_states", False)
     model.config.output_hidden_states = bool(want_bi)
     model.eval()
-    n_texts = 0
+    n_texts = n_tokens = 0
     try:
         for batch in adapter.calibs:
             n_texts += len(batch)
+            n_tokens += int(batch.numel()) if hasattr(batch, "numel") else 0
             try:
                 out = model(batch, output_hidden_states=bool(want_bi))
             except StopForward:
@@ -138,6 +139,7 @@ def _calibrate_model(adapter: ModelAdapter, n_samples: int, batch_size: int, tar
         model.config.output_hidden_states = hidden_states_before     # (the caller's model goes back as it came)
     bi_scores = bi.scores(n_texts) if want_bi else None
     adapter.bi_scores = bi_scores
+    adapter.calib_tokens = n_tokens       # (how many tokens each statistic summed over: the fp64 route's rounding bound scales with it)
     sig.finalize(n_texts)
     if ops.COV_MODE == "i8":   # the route of every large-statistic launch was picked on the device; read the tally once
         adapter.cov_routes = ops.i8_route_counts(reset=True)

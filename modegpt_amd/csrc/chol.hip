@@ -279,21 +279,58 @@ __global__ __launch_bounds__(256) void place_inv_diag_kernel(const double* inv, 
 }
 
 // out[j] = sum_{i >= j} X[i][j]^2 ; one workgroup per 64 columns, 4 row-strided waves.
-__global__ __launch_bounds__(256) void lower_colnorm2_kernel(const double* X, int64_t ldx, int64_t n, double* out) {
-  __shared__ double red[4][64];
+// SENS: the same pass also takes t_j = sum_{i >= j} |X[i][j]| u[i] and writes sens[j] = t_j^2 (see lower_abs_rowsum_kernel); the sums
+// behind out[j] are formed in the same order either way (the scores do not change by a bit when the sensitivity is asked for).
+template <bool SENS>
+__global__ __launch_bounds__(256) void lower_colnorm2_kernel(const double* X, int64_t ldx, int64_t n, double* out, const double* u,
+                                                             double* sens) {
+  __shared__ double red[4][64], red_t[SENS ? 4 : 1][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t j = (int64_t)blockIdx.x * 64 + lane;
   const int64_t i0 = (int64_t)blockIdx.x * 64;
-  double s = 0.;
+  double s = 0., t = 0.;
   if (j < n)
     for (int64_t i = i0 + wave; i < n; i += 4)
       if (i >= j) {
         double v = X[i * ldx + j];
         s += v * v;
+        if (SENS) t += fabs(v) * u[i];
       }
   red[wave][lane] = s;
+  if (SENS) red_t[wave][lane] = t;
   __syncthreads();
-  if (wave == 0 && j < n) out[j] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+  if (wave == 0 && j < n) {
+    out[j] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    if (SENS) {
+      const double tt = red_t[0][lane] + red_t[1][lane] + red_t[2][lane] + red_t[3][lane];
+      sens[j] = tt * tt;
+    }
+  }
+}
+
+// The sensitivity of the ridge scores to an ENTRY-WISE RELATIVE perturbation of C (what the int8 covariance route guarantees:
+// |E_ab| <= eps sqrt(c_aa c_bb)).  With A = C + ridge I = L L^T, X = inv(L), z_j = inv(A) e_j = X^T X e_j and s_j = (inv(A))_jj,
+// to first order  delta s_j = -z_j^T E z_j,  so
+//     |delta s_j| <= eps (sum_a sqrt(c_aa) |z_aj|)^2 <= eps (sum_b |X_bj| u_b)^2 =: eps sens_j,    u_b = sum_a |X_ba| sqrt(c_aa)
+// (the triangle inequality inside z_aj = sum_b X_ba X_bj).  Two passes over the triangle of X that mdg_ridge_scores has in its
+// workspace anyway (n^2 / 2 * 8 B each: 0.8 GB at n = 14336), no extra GEMM: d = sqrt(diag C), u = |X| d (this kernel, one wave per
+// row), t = |X|^T u (fused into the column-norm pass above).  mdg_select_margin turns sens into the certificate of the selection.
+__global__ __launch_bounds__(256) void sqrt_diag_kernel(const double* C, int64_t ldc, int64_t n, double* d) {
+  const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (a < n) {
+    const double c = C[a * ldc + a];
+    d[a] = c > 0. ? sqrt(c) : 0.;
+  }
+}
+__global__ __launch_bounds__(256) void lower_abs_rowsum_kernel(const double* X, int64_t ldx, int64_t n, const double* d, double* u) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= n) return;
+  double acc = 0.;
+  for (int64_t a = lane; a <= b; a += 64) acc += fabs(X[b * ldx + a]) * d[a];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) u[b] = acc;
 }
 
 
@@ -387,12 +424,22 @@ int tri_inverse_doubling(const double* L, int64_t n, int64_t ldl, const double* 
   return MDG_OK;
 }
 
-// X = inv(L), then column norms.
+// X = inv(L), then column norms.  sens != nullptr: also the first-order sensitivities of out[j] to an entry-wise relative
+// perturbation of C (C, ldc: the matrix whose diagonal scales the perturbation; T, free again after the doubling, holds d and u).
 int chol_inverse_diag(const double* L, int64_t n, int64_t ldl, const double* inv_diag, double* out, double* X,
-                      double* T, hipStream_t st) {
+                      double* T, hipStream_t st, const double* C = nullptr, int64_t ldc = 0, double* sens = nullptr) {
   const int64_t ldx = n;
   MDG_TRY(tri_inverse_doubling(L, n, ldl, inv_diag, X, ldx, T, n, st));
-  hipLaunchKernelGGL(lower_colnorm2_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, st, X, ldx, n, out);
+  if (sens) {
+    double* d = T;          // (T has n^2 / 4 + 128^2 elements >= 2 n)
+    double* u = T + n;
+    hipLaunchKernelGGL(sqrt_diag_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, C, ldc, n, d);
+    hipLaunchKernelGGL(lower_abs_rowsum_kernel, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st, X, ldx, n, d, u);
+    hipLaunchKernelGGL(lower_colnorm2_kernel<true>, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, st, X, ldx, n, out, u, sens);
+  } else {
+    hipLaunchKernelGGL(lower_colnorm2_kernel<false>, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, st, X, ldx, n, out,
+                       (const double*)nullptr, (double*)nullptr);
+  }
   MDG_LAUNCH_CHECK();
   return MDG_OK;
 }
@@ -492,7 +539,7 @@ extern "C" size_t mdg_ridge_scores_ws_bytes(int64_t n) {
          mdg_chol_inverse_diag_ws_bytes(n);
 }
 
-extern "C" int mdg_ridge_scores(const double* C, int64_t n, int64_t ldc, double ridge, double* scores, void* ws,
+extern "C" int mdg_ridge_scores(const double* C, int64_t n, int64_t ldc, double ridge, double* scores, double* sens, void* ws,
                                 size_t ws_bytes, void* stream) {
   MDG_CLEAR();
   MDG_CHECK_ARG(C && scores && n > 0 && ldc >= n, "mdg_ridge_scores: bad arguments");
@@ -504,5 +551,5 @@ extern "C" int mdg_ridge_scores(const double* C, int64_t n, int64_t ldc, double 
   double* rest = inv + mdg_potrf_inv_diag_elems(n);
   MDG_TRY(copy_lower(C, ldc, nullptr, Lb, n, n, ridge, st));
   MDG_TRY(potrf_lower(Lb, n, n, inv, st));
-  return chol_inverse_diag(Lb, n, n, inv, scores, rest, rest + (size_t)n * n, st);
+  return chol_inverse_diag(Lb, n, n, inv, scores, rest, rest + (size_t)n * n, st, C, ldc, sens);
 }

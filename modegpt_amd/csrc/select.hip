@@ -53,6 +53,62 @@ __global__ __launch_bounds__(1024) void compact_kernel(const double* s, int64_t 
     if (i == it || before_asc(s[i], i, t, it)) idx[pos++] = i;
 }
 
+// The certificate of a selection of the k smallest scores (idx: the selected indices, ascending) against a perturbation of every
+// score by at most eps * sens[j]: one workgroup.  out[0] = largest selected score, out[1] = smallest unselected score,
+// out[2] = max over selected (s + eps sens), out[3] = min over unselected (s - eps sens), out[4] / out[5] = largest sens among the
+// selected / the unselected, out[6] = number of scores whose interval [s - eps sens, s + eps sens] reaches across the midpoint of
+// out[0] and out[1], out[7] = 1 if out[2] < out[3] (no perturbation within the bound can change the selected SET) else 0.
+// NaN scores rank last (mdg_select_smallest_sorted) and take no part.  k == 0 or k == n: nothing to separate, certified.
+__global__ __launch_bounds__(1024) void select_margin_kernel(const double* s, const double* sens, const int64_t* idx, int64_t n, int64_t k,
+                                                             double eps, double* out) {
+  __shared__ double red[6][1024];
+  __shared__ int cnt[1024];
+  const int tid = threadIdx.x;
+  const double inf = __longlong_as_double(0x7ff0000000000000ll);
+  double sel_max = -inf, unsel_min = inf, hi = -inf, lo = inf, b_sel = 0., b_unsel = 0.;
+  for (int64_t j = tid; j < n; j += 1024) {
+    const double v = s[j];
+    if (v != v) continue;
+    int64_t a = 0, b = k;                       // is j among idx[0 .. k)?  (sorted ascending: binary search)
+    while (a < b) {
+      const int64_t m = (a + b) >> 1;
+      if (idx[m] < j) a = m + 1; else b = m;
+    }
+    const bool selected = a < k && idx[a] == j;
+    const double w = eps * sens[j];
+    if (selected) { sel_max = fmax(sel_max, v); hi = fmax(hi, v + w); b_sel = fmax(b_sel, sens[j]); }
+    else { unsel_min = fmin(unsel_min, v); lo = fmin(lo, v - w); b_unsel = fmax(b_unsel, sens[j]); }
+  }
+  red[0][tid] = sel_max; red[1][tid] = unsel_min; red[2][tid] = hi; red[3][tid] = lo; red[4][tid] = b_sel; red[5][tid] = b_unsel;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (tid < o) {
+      red[0][tid] = fmax(red[0][tid], red[0][tid + o]); red[1][tid] = fmin(red[1][tid], red[1][tid + o]);
+      red[2][tid] = fmax(red[2][tid], red[2][tid + o]); red[3][tid] = fmin(red[3][tid], red[3][tid + o]);
+      red[4][tid] = fmax(red[4][tid], red[4][tid + o]); red[5][tid] = fmax(red[5][tid], red[5][tid + o]);
+    }
+    __syncthreads();
+  }
+  const double mid = 0.5 * (red[0][0] + red[1][0]);
+  int c = 0;
+  if (red[0][0] > -inf && red[1][0] < inf)
+    for (int64_t j = tid; j < n; j += 1024) {
+      const double v = s[j], w = eps * sens[j];
+      if (v == v && v - w <= mid && mid <= v + w) c++;
+    }
+  cnt[tid] = c;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (tid < o) cnt[tid] += cnt[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    for (int i = 0; i < 6; i++) out[i] = red[i][0];
+    out[6] = (double)cnt[0];
+    out[7] = red[2][0] < red[3][0] ? 1. : 0.;
+  }
+}
+
 __global__ __launch_bounds__(256) void gather_rows16_kernel(const unsigned short* src, int64_t ld_src,
                                                             const int64_t* rows, int64_t n_cols, unsigned short* out,
                                                             int64_t ld_out, int vec_ok) {
@@ -159,6 +215,15 @@ extern "C" int mdg_select_smallest_sorted(const double* scores, int64_t n, int64
   hipLaunchKernelGGL(rank_threshold_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, scores, n, k, idx);
   MDG_LAUNCH_CHECK();
   hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(1024), 0, st, scores, n, idx);
+  MDG_LAUNCH_CHECK();
+  return MDG_OK;
+}
+
+extern "C" int mdg_select_margin(const double* scores, const double* sens, const int64_t* idx, int64_t n, int64_t k, double eps,
+                                 double* out8, void* stream) {
+  MDG_CLEAR();
+  MDG_CHECK_ARG(scores && sens && out8 && n > 0 && k >= 0 && k <= n && (idx || k == 0) && eps >= 0., "mdg_select_margin: bad arguments");
+  hipLaunchKernelGGL(select_margin_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, scores, sens, idx, n, k, eps, out8);
   MDG_LAUNCH_CHECK();
   return MDG_OK;
 }

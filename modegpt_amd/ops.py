@@ -568,20 +568,23 @@ def sqrt_psd_large(M: torch.Tensor, ridge: float, scaled: bool, want_inverse: bo
 
 
 # ------------------------------------------------------------------ MLP
-def ridge_scores(Cm: torch.Tensor, ridge: float) -> torch.Tensor:
-    """diag((C + ridge I)^-1) for a symmetric PD fp64 matrix."""
+def ridge_scores(Cm: torch.Tensor, ridge: float, want_sens: bool = False):
+    """diag((C + ridge I)^-1) for a symmetric PD fp64 matrix.  want_sens: also the first-order sensitivities `sens` of the scores to
+    an entry-wise relative perturbation of C (|delta score_j| <= eps sens_j for |E_ab| <= eps sqrt(c_aa c_bb); mdg_ridge_scores)
+    -> (scores, sens)."""
     _need_gpu(Cm)
     lib = _lib.load()
     if Cm.dtype != torch.float64 or Cm.stride(1) != 1:
         raise ValueError("C must be float64 with unit column stride")
     n = Cm.shape[0]
     scores = torch.empty(n, dtype=torch.float64, device=Cm.device)
+    sens = torch.empty(n, dtype=torch.float64, device=Cm.device) if want_sens else None
     nbytes = lib.mdg_ridge_scores_ws_bytes(n)
     ws, wsp = _ws(nbytes, Cm.device)
     with torch.cuda.device(Cm.device):
-        check(lib.mdg_ridge_scores(Cm.data_ptr(), n, Cm.stride(0), float(ridge), scores.data_ptr(), wsp, nbytes,
+        check(lib.mdg_ridge_scores(Cm.data_ptr(), n, Cm.stride(0), float(ridge), scores.data_ptr(), _p(sens), wsp, nbytes,
                                    _stream(Cm)), "mdg_ridge_scores")
-    return scores
+    return (scores, sens) if want_sens else scores
 
 
 def select_smallest_sorted(scores: torch.Tensor, k: int) -> torch.Tensor:
@@ -594,6 +597,38 @@ def select_smallest_sorted(scores: torch.Tensor, k: int) -> torch.Tensor:
         check(lib.mdg_select_smallest_sorted(s.data_ptr(), s.numel(), k, idx.data_ptr(), _stream(s)),
               "mdg_select_smallest_sorted")
     return idx
+
+
+MARGIN_FIELDS = ("s_selected_max", "s_unselected_min", "selected_upper", "unselected_lower", "sens_selected_max", "sens_unselected_max",
+                 "scores_at_risk", "certified")
+
+
+def select_margin(scores: torch.Tensor, sens: torch.Tensor, idx: torch.Tensor, eps: float) -> torch.Tensor:
+    """The certificate of a k-smallest selection (mdg_select_margin): 8 fp64 numbers ON THE DEVICE (MARGIN_FIELDS), enqueued only --
+    read them when the stream is waited for anyway (decode_margin)."""
+    _need_gpu(scores, sens, idx)
+    lib = _lib.load()
+    s = scores if (scores.dtype == torch.float64 and scores.is_contiguous()) else scores.to(torch.float64).contiguous()
+    b = sens if (sens.dtype == torch.float64 and sens.is_contiguous()) else sens.to(torch.float64).contiguous()
+    idx = idx.to(torch.int64).contiguous()
+    out = torch.empty(8, dtype=torch.float64, device=s.device)
+    with torch.cuda.device(s.device):
+        check(lib.mdg_select_margin(s.data_ptr(), b.data_ptr(), idx.data_ptr() if idx.numel() else None, s.numel(), idx.numel(),
+                                    float(eps), out.data_ptr(), _stream(s)), "mdg_select_margin")
+    return out
+
+
+def decode_margin(out8, eps: float) -> dict:
+    """Host-side reading of select_margin's 8 numbers (a list / CPU tensor): the relative margin of the selection threshold, the
+    bound on what a perturbation of relative size eps can do to a score there, and whether the selected set is certified."""
+    v = [float(x) for x in out8]
+    s_k, s_k1 = v[0], v[1]
+    finite = s_k > float("-inf") and s_k1 < float("inf")
+    margin = (s_k1 - s_k) / abs(s_k) if finite and s_k != 0 else float("inf")
+    spread = v[4] + v[5]
+    return {"margin": margin, "score_bound": eps * max(v[4], v[5]) / abs(s_k) if finite and s_k != 0 else 0.0,
+            "eps": eps, "eps_certifiable": (s_k1 - s_k) / spread if finite and spread > 0 else float("inf"),
+            "scores_at_risk": int(v[6]), "certified": bool(v[7] == 1.0), **{k: x for k, x in zip(MARGIN_FIELDS[:4], v[:4])}}
 
 
 def gather_rows(W: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:

@@ -103,6 +103,7 @@ def compress_chunk(adapter: ModelAdapter, config: CompressionConfig, chunk: List
         compress_vo(adapter=adapter, cov=cov_x, keep_ratios=keep, target_layers=mine)
     del cov_mlp, cov_q, cov_k, cov_x
     _free()
+    adapter.report_selection_margins(logger)    # certificates of this chunk's MLP rank selections -> metrics["mlp_selection"], warnings
     return sharding.gather_layer_artifacts(adapter, chunk, mine, masks, rank, world)
 
 

@@ -246,6 +246,102 @@ def test_select_ties_lower_index_first(ops, dev):
     assert got.cpu().tolist() == [1, 3, 7]
 
 
+@pytest.mark.parametrize("n,correlated", [(384, False), (640, True), (2048 + 77, True)])
+def test_ridge_score_sensitivity_bounds_what_a_relative_error_of_sigma_can_do(ops, dev, n, correlated):
+    """mdg_ridge_scores' `sens` (the certificate's first-order bound, include/modegpt_hip.h): the same scores to the bit with or
+    without it; sens equals its definition (sum_b |X_bj| sum_a |X_ba| sqrt(c_aa))^2 computed on the CPU from inv(chol(C + ridge I));
+    and it does what it is for -- for perturbations |E_ab| <= eps sqrt(c_aa c_bb) of either sign pattern (random, and the adversarial
+    one for a given column: E = -eps sign(z_j z_j^T) d d^T) the scores of C + E, recomputed in fp64 on the CPU by the oracle, move
+    by at most eps sens_j (plus the second-order term)."""
+    gen = torch.Generator().manual_seed(n)
+    H = acts(gen, 3 * n, n).double()
+    if correlated:                       # mix the features: inv(A) gets dense columns, the triangle inequality has something to lose
+        H = H @ (torch.eye(n, dtype=F64) + 0.3 * torch.randn(n, n, generator=gen, dtype=F64) / n ** 0.5)
+    Cm = H.T @ H / (3 * n)
+    lam = float(torch.tensor(1e-4, dtype=torch.float32).double())
+    plain = ops.ridge_scores(Cm.to(dev), lam)
+    scores, sens = ops.ridge_scores(Cm.to(dev), lam, want_sens=True)
+    assert torch.equal(plain, scores)
+    scores, sens = scores.cpu(), sens.cpu()
+    A = Cm + lam * torch.eye(n, dtype=F64)
+    X = torch.linalg.inv(torch.linalg.cholesky(A))
+    d = torch.sqrt(torch.diagonal(Cm))
+    want_sens = (X.abs().T @ (X.abs() @ d)) ** 2
+    assert rel(sens, want_sens) < 1e-10
+    Z = torch.linalg.inv(A)
+    exact_first_order = (Z.abs().T @ d) ** 2              # (sum_a sqrt(c_aa) |z_aj|)^2 <= sens_j
+    assert bool((exact_first_order <= want_sens * (1 + 1e-12)).all())
+    eps = 1e-7
+    dd = d[:, None] * d[None, :]
+    R = torch.rand(n, n, generator=gen, dtype=F64) * 2 - 1
+    trials = [eps * torch.tril(R) * dd]
+    for j in (0, n // 2, int(torch.argmax(want_sens / scores))):
+        zj = Z[:, j]
+        trials.append(-eps * torch.sign(zj[:, None] * zj[None, :]) * dd)
+    for E in trials:
+        E = torch.tril(E) + torch.tril(E, -1).T
+        moved = (O.ridge_scores(Cm + E, 1e-4) - O.ridge_scores(Cm, 1e-4)).abs()
+        assert bool((moved <= eps * want_sens * (1 + 1e-3) + 1e-12 * scores).all()), (moved / (eps * want_sens)).max().item()
+    # the adversarial pattern comes close to the exact first-order bound for its column: the bound is not slack by construction
+    zj = Z[:, 0]
+    E = -eps * torch.sign(zj[:, None] * zj[None, :]) * dd
+    moved0 = (O.ridge_scores(Cm + E, 1e-4) - O.ridge_scores(Cm, 1e-4))[0].abs().item()
+    assert moved0 > 0.99 * eps * exact_first_order[0].item()
+
+
+def test_selection_margin_certifies_or_flags(ops, dev, caplog):
+    """mdg_select_margin + the reporting around it (ModelAdapter.report_selection_margins): a selection whose threshold scores
+    are well apart is CERTIFIED against the covariance error bound; a constructed near-tie -- two columns whose scores differ by
+    2e-13 relatively, straddling the threshold -- is FLAGGED (warning, metrics entry, certified False), although the selection
+    itself is still made (lower score first, as the reference's topk would on these exact numbers)."""
+    import logging
+    from modegpt_amd import engine
+    shape = dict(engine.SHAPES["tiny"], n_layers=1)
+    n, keep = shape["d_ff"], 0.7
+    rank = int(n * keep)
+    gen = torch.Generator().manual_seed(5)
+    weights = engine.make_layer_weights(shape, 1, dev)
+
+    def run(diag):
+        H = torch.randn(4 * n, n, generator=gen, dtype=F64) * 1e-3
+        C = H.T @ H / (4 * n)                                # weak correlations between the columns ...
+        C = C - torch.diag(torch.diagonal(C)) + torch.diag(diag)     # ... under an exactly prescribed diagonal
+        adapter = engine.TensorAdapter(shape, {0: weights})
+        adapter.cov_error_eps = 1.1e-11
+        from modegpt_amd.compression.compress_mlp import compress_nystrom
+        compress_nystrom(adapter=adapter, cov=[C.to(dev)], keep_ratios=[keep], target_layers=[0])
+        adapter.check_chains()
+        with caplog.at_level(logging.WARNING, logger="MoDeGPT"):
+            caplog.clear()
+            rep = adapter.report_selection_margins()
+        return adapter, rep[0], [r.getMessage() for r in caplog.records], O.ridge_scores(C, 1e-4)
+
+    # scores ~ 1 / (c_jj + ridge): a geometric ladder of diagonal entries -> every neighbouring pair of scores 1 % apart
+    ladder = 0.5 * 1.01 ** torch.arange(n, dtype=F64)
+    adapter, rep, warnings, sc = run(ladder[torch.randperm(n, generator=gen)])
+    assert rep["certified"] and not warnings and rep["scores_at_risk"] == 0
+    srt = torch.sort(sc).values
+    assert abs(rep["margin"] - ((srt[rank] - srt[rank - 1]) / srt[rank - 1]).item()) < 1e-9
+    assert rep["score_bound"] < 1e-9 < rep["margin"] and rep["eps_certifiable"] > 1e-6
+    assert adapter.metrics["mlp_selection"]["0"]["certified"] is True
+    # the near-tie: the k-th and (k+1)-th largest diagonal entries 2e-13 apart
+    near = ladder.clone()
+    order = torch.argsort(near, descending=True)          # smallest scores = largest diagonal entries
+    a, b = order[rank - 1].item(), order[rank].item()
+    near[b] = near[a] * (1 - 2e-13)
+    adapter, rep, warnings, sc = run(near)
+    assert not rep["certified"] and rep["scores_at_risk"] >= 2 and rep["margin"] < 1e-11
+    assert len(warnings) == 1 and "NOT certified" in warnings[0] and "Layer 0" in warnings[0]
+    assert adapter.metrics["mlp_selection"]["0"]["certified"] is False
+    got_up = adapter.store[(0, "mlp")]["up"]
+    assert got_up.shape[0] == rank                         # (the selection is still made)
+    # raw entry point: k == n and k == 0 have nothing to separate
+    s = torch.rand(50, dtype=F64, device=dev)
+    full = ops.decode_margin(ops.select_margin(s, torch.ones_like(s), torch.arange(50, device=dev), 1e-3).cpu().tolist(), 1e-3)
+    none = ops.decode_margin(ops.select_margin(s, torch.ones_like(s), torch.arange(0, device=dev), 1e-3).cpu().tolist(), 1e-3)
+    assert full["certified"] and none["certified"] and full["margin"] == float("inf")
+
+
 def test_gather_rows(ops, dev):
     gen = torch.Generator().manual_seed(2)
     W = torch.randn(500, 264, generator=gen).to(torch.bfloat16)

@@ -416,6 +416,74 @@ def test_gpu_tensor_with_a_broken_engine_is_an_error_and_without_the_engine_is_p
     assert out.shape == (1, 4, 3, 8) and ca.PATH_CALLS["torch"] == before + 1
 
 
+def test_selection_margin_report_certified_or_flagged(caplog):
+    """Host side of the selection certificate (ops.decode_margin, ModelAdapter.report_selection_margins) on hand-made numbers: a
+    margin above the bound is certified silently, one below it is flagged with a warning and certified False in the metrics; the
+    error bound of the covariance route comes from the adapter (stated, or derived from the route and the token count)."""
+    import logging
+    from modegpt_amd import engine, ops
+    from modegpt_amd.compression.compress_mlp import covariance_error_eps
+    ad = engine.TensorAdapter(dict(engine.SHAPES["tiny"]), {})
+    eps = 1.1e-11
+    #                         s_k   s_k+1          s_k + eps b        s_k+1 - eps b'       b    b'   at risk  certified
+    ad.selection_margin(3, torch.tensor([2.0, 2.0 * (1 + 1e-6), 2.0 + eps * 40, 2.0 * (1 + 1e-6) - eps * 60, 40., 60., 0., 1.], dtype=torch.float64), eps)
+    ad.selection_margin(7, torch.tensor([2.0, 2.0 * (1 + 1e-13), 2.0 + eps * 40, 2.0 * (1 + 1e-13) - eps * 60, 40., 60., 2., 0.], dtype=torch.float64), eps)
+    with caplog.at_level(logging.WARNING, logger="MoDeGPT"):
+        rep = ad.report_selection_margins()
+    assert rep[3]["certified"] and abs(rep[3]["margin"] - 1e-6) < 1e-15 and abs(rep[3]["score_bound"] - eps * 60 / 2.0) < 1e-20
+    assert abs(rep[3]["eps_certifiable"] - 2e-6 / 100) < 1e-15
+    assert not rep[7]["certified"] and rep[7]["scores_at_risk"] == 2 and rep[7]["margin"] < rep[7]["score_bound"]
+    msgs = [r.getMessage() for r in caplog.records]
+    assert len(msgs) == 1 and "Layer 7" in msgs[0] and "NOT certified" in msgs[0]
+    assert ad.metrics["mlp_selection"]["7"]["certified"] is False and ad.metrics["mlp_selection"]["3"]["certified"] is True
+    assert ad.report_selection_margins() == {}                      # (read once)
+    # which eps the certificate is taken against
+    ad.cov_error_eps = 5e-12
+    assert covariance_error_eps(ad, 14336) == 5e-12
+    ad.cov_error_eps = None
+    ad.calib_tokens = 1 << 20
+    f64 = ((1 << 20) / 4 + 4) * 2.0 ** -53
+    assert ops.COV_MODE == "i8" and abs(covariance_error_eps(ad, 14336) - (1.1e-11 + 64 * 2.0 ** -53)) < 1e-25
+    assert covariance_error_eps(ad, 640) == f64                     # (below ops.I8_MIN_FEATURES: the fp64 kernel)
+    with ops.i8_tolerance_scope(64.0):
+        assert abs(covariance_error_eps(ad, 14336) - (64 * 1.1e-11 + 64 * 2.0 ** -53)) < 1e-22
+    ad.cov_routes = {"i8_5": 10, "i8_6": 0, "fallback_f64": 1, "fp64_columns": 0}
+    assert covariance_error_eps(ad, 14336) == max(f64, 1.1e-11 + 64 * 2.0 ** -53)
+
+
+def test_int8_tolerance_default_is_python_side_and_per_thread():
+    """ABI 9: the library has no tolerance state; ops keeps the default a call without `tolerance=` uses -- process-wide
+    (set_i8_tolerance) with a per-thread override (i8_tolerance_scope) that other threads do not see."""
+    import threading
+    from modegpt_amd import ops
+    assert ops.i8_tolerance() == 1.0
+    seen = {}
+
+    def other():
+        seen["other"] = ops.i8_tolerance()
+
+    with ops.i8_tolerance_scope(8.0):
+        with ops.i8_tolerance_scope(64.0):
+            assert ops.i8_tolerance() == 64.0
+            t = threading.Thread(target=other)
+            t.start()
+            t.join()
+        assert ops.i8_tolerance() == 8.0
+    assert ops.i8_tolerance() == 1.0 and seen["other"] == 1.0
+    prev = ops.set_i8_tolerance(4.0)
+    try:
+        assert prev == 1.0 and ops.i8_tolerance() == 4.0
+        with ops.i8_tolerance_scope(2.0):
+            assert ops.i8_tolerance() == 2.0
+    finally:
+        ops.set_i8_tolerance(prev)
+    for bad in (0.5, 2e6, float("nan")):
+        with pytest.raises(ValueError):
+            ops.set_i8_tolerance(bad)
+    from modegpt_amd import _lib
+    assert not any("tolerance" in name for name in _lib.SIGNATURES)      # (no setter / getter left in the ABI)
+
+
 def test_artifact_writer_files_are_in_place_after_flush_and_errors_surface(tmp_path):
     """artifact_io.ArtifactWriter (save_layer's torch.save on a worker thread): same file names and payload as the synchronous
     save, nothing half-written under the final name, the worker's error raised by flush()."""
