@@ -116,11 +116,24 @@ class ModelAdapter(ABC):
         output_dir = os.path.expandvars(output_dir)
         os.makedirs(output_dir, exist_ok=True)
         path = os.path.join(output_dir, f"layer_{layer_idx}_{suffix}")
+        held = getattr(self, "_held_artifacts", None)
+        if held is not None:                     # a sharded run: the gather packs its send buffer from these, not from the files
+            held.setdefault(int(layer_idx), {}).update(weights)
         writer = getattr(self, "_artifact_writer", None)
         if writer is not None:
             writer.submit(path, weights)
         else:
             torch.save(weights, path)
+
+    def hold_artifacts(self, enable: bool = True) -> None:
+        """Keep a reference to every tensor handed to save_layer (on its device) until take_held_artifacts(layer) collects it:
+        sharding.gather_layer_artifacts packs the all-gather's send buffer from them instead of reading the files back.  ~0.3 GB
+        per layer at Llama-3-8B / 30 %, for the layers of one chunk a rank owns."""
+        self._held_artifacts = {} if enable else None
+
+    def take_held_artifacts(self, layer_idx: int) -> dict:
+        held = getattr(self, "_held_artifacts", None)
+        return {} if held is None else held.pop(int(layer_idx), {})
 
     def async_artifacts(self, enable: bool = True) -> None:
         """Layer artefacts through a background writer (artifact_io.ArtifactWriter): save_layer enqueues the device-to-host copy

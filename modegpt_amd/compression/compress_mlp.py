@@ -87,11 +87,15 @@ def compress_nystrom(adapter: ModelAdapter, cov, keep_ratios, target_layers, rid
         # the layer's whole chain (two Cholesky factorisations, selection, gathers, Nystrom solve) enqueues without a host round
         # trip; the not-positive-definite status of both factorisations is read once (adapter.chain_status)
         comps = adapter.get_mlp_components(layer_idx)
+        record = getattr(adapter, "selection_margin", None)          # (a duck-typed adapter without it: no certificate)
+        if record is None:
+            return compress_weights(comps, cov[layer_idx], keep_ratios[layer_idx], layer_idx=layer_idx,
+                                    ridge_lambda=adapter.config.nystrom_ridge)
         eps, margin = covariance_error_eps(adapter, cov[layer_idx].shape[0]), []
         result = compress_weights(comps, cov[layer_idx], keep_ratios[layer_idx], layer_idx=layer_idx,
                                   ridge_lambda=adapter.config.nystrom_ridge, margin_eps=eps, margin_out=margin)
         # the selection's certificate stays on the device until the adapter next waits for the chain (report_selection_margins)
-        adapter.selection_margin(layer_idx, margin[0], eps)
+        record(layer_idx, margin[0], eps)
         return result
 
     def retire(layer_idx, result):

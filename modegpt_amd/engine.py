@@ -48,14 +48,15 @@ def make_layer_weights(shape: dict, seed: int, device) -> Dict[str, torch.Tensor
     return out
 
 
-def make_activation_batch(shape: dict, tokens: int, seed: int, device) -> Dict[str, torch.Tensor]:
+def make_activation_batch(shape: dict, tokens: int, seed: int, device, scale_seed: int = 977) -> Dict[str, torch.Tensor]:
     """One calibration batch's hook inputs: z * c_j, z ~ N(0,1), per-feature scale log-uniform[0.05, 2]
-    (non-flat spectrum so selections are not tie-dominated), bf16."""
+    (non-flat spectrum so selections are not tie-dominated), bf16.  scale_seed: the seed of the per-feature scales -- a property
+    of the LAYER (the same for all its batches); give every layer its own to get layers with different statistics."""
     g = torch.Generator(device=device).manual_seed(seed)
     d, f, nh, nkv, hd = shape["d"], shape["d_ff"], shape["n_heads"], shape["n_kv_heads"], shape["head_dim"]
 
     def a(feat, salt):
-        gs = torch.Generator(device=device).manual_seed(977 + salt)  # the scale is a property of the feature, not the batch
+        gs = torch.Generator(device=device).manual_seed(scale_seed + salt)  # the scale is a property of the feature, not the batch
         c = torch.exp(torch.empty(feat, device=device).uniform_(math.log(0.05), math.log(2.0), generator=gs))
         return (torch.randn(tokens, feat, device=device, generator=g) * c).to(torch.bfloat16)
 

@@ -103,7 +103,9 @@ def compress_chunk(adapter: ModelAdapter, config: CompressionConfig, chunk: List
         compress_vo(adapter=adapter, cov=cov_x, keep_ratios=keep, target_layers=mine)
     del cov_mlp, cov_q, cov_k, cov_x
     _free()
-    adapter.report_selection_margins(logger)    # certificates of this chunk's MLP rank selections -> metrics["mlp_selection"], warnings
+    report = getattr(adapter, "report_selection_margins", None)     # (a duck-typed adapter has none)
+    if report is not None:
+        report(logger)                          # certificates of this chunk's MLP rank selections -> metrics["mlp_selection"], warnings
     return sharding.gather_layer_artifacts(adapter, chunk, mine, masks, rank, world)
 
 
@@ -122,6 +124,7 @@ def main(trial=None, config: Optional[CompressionConfig] = None):
     adapter = ModelAdapter.from_model(model=model, tokenizer=tokenizer)
     adapter.config = config
     adapter.async_artifacts(True)       # layer artefacts through a background writer; convert_model / the gather flush it
+    adapter.hold_artifacts(world > 1)   # sharded: the all-gather's send buffer is packed from the tensors save_layer holds
     if rank == 0:   # (every rank holds the model; the metric is rank 0's business)
         adapter.metrics["baseline-ppl"] = compute_perplexity(model, tokenizer, dataset=config.dataset, adapter=adapter)
         logger.info(f"Baseline ppl: {adapter.metrics['baseline-ppl']}")

@@ -10,7 +10,8 @@ Packed record per layer (all 2-byte words, bf16 bit patterns or int16 quarters o
     header  : 16 x int64  = [layer_idx, n_tensors, (rows, cols) x 7 tensors]   (up, gate, down, q, k, v, o)
     mask hdr:  2 x int64  = [n_kv, rank]  followed by the int64 rotary mask
     payload : the tensors' bf16 words back to back
-Records are padded to the largest record of the call (per-layer ranks differ with the keep ratios).
+Records are padded to the largest record of the call (per-layer ranks differ with the keep ratios); a rank sends as many
+records as it owns layers (the counts travel with the stride agreement), so uneven blocks do not pad to the largest block.
 """
 from __future__ import annotations
 
@@ -144,39 +145,77 @@ def gather_buffers(per_rank: int, world: int, record_words: int, device) -> Tupl
     return send, recv
 
 
+def _allgather_rows(send: torch.Tensor, recv: torch.Tensor, counts: List[int], rank: int) -> None:
+    """recv = the ranks' row blocks back to back, rank g contributing counts[g] rows of send's width.  ONE collective either way:
+    equal counts -> all_gather_into_tensor (ncclAllGather; what bench.py's equal blocks take); ragged counts -> torch's all_gather
+    with unevenly sized outputs, which the nccl backend runs as one coalesced group of broadcasts (an all-gather-v: every rank's
+    block crosses each xGMI link once, nothing is padded to the largest block).  gloo has no uneven all-gather: the CPU tests walk
+    the ranks with one broadcast each -- same offsets, same result, test plumbing only."""
+    width = send.shape[1]
+    if len(set(counts)) == 1:
+        dist.all_gather_into_tensor(recv.view(torch.uint8), send.view(torch.uint8))     # byte views: gloo has no int16
+        return
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + c)
+    outs = [recv[offs[g]:offs[g + 1]].view(torch.uint8).reshape(-1) for g in range(len(counts))]
+    mine = send.view(torch.uint8).reshape(-1)
+    assert mine.numel() == counts[rank] * width * 2
+    if dist.get_backend() == "nccl":
+        dist.all_gather(outs, mine)
+    else:
+        for g in range(len(counts)):
+            if g == rank:
+                outs[g].copy_(mine)
+            dist.broadcast(outs[g], src=g)
+
+
 def allgather_records(records: List[torch.Tensor], per_rank: int, world: int, force_collective: bool = False,
                       buffers: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None) -> List[torch.Tensor]:
-    """The single data-path collective: every rank contributes `per_rank` records padded to a common stride.
+    """The single data-path collective: every rank contributes ITS records (at most `per_rank`), each padded to the common record
+    stride; a rank with fewer records than another sends fewer rows -- the ranks' counts travel in the control message that
+    already agrees on the stride (one MAX all-reduce of 8 (world + 1) bytes), so the balanced partition of a real model
+    (9, 6, 5, 4, 3, 2, 2, 1 layers at 8 ranks) moves 32 records, not 8 x 9.
     force_collective runs the all-gather even at world == 1 (lets a 1-GPU box exercise the RCCL code path).
     buffers: gather_buffers() of the caller's, used when they are large enough for the stride the ranks agree on."""
     dev = records[0].device if records else torch.device("cuda" if torch.cuda.is_available() else "cpu")
-    longest = torch.tensor([max([r.numel() for r in records] + [0])], dtype=torch.int64, device=dev)
-    if world > 1 or force_collective:
-        dist.all_reduce(longest, op=dist.ReduceOp.MAX)  # 8-byte size agreement, not a data-path exchange
-    stride = (int(longest.item()) + 3) // 4 * 4          # rows stay 8-byte aligned for the int64 header views
+    collective = world > 1 or force_collective
+    rank = dist.get_rank() if (collective and dist.is_initialized()) else 0
+    if len(records) > per_rank:
+        raise ValueError(f"{len(records)} records for {per_rank} slots")
+    ctrl = torch.zeros(world + 1, dtype=torch.int64, device=dev)
+    ctrl[0] = max([r.numel() for r in records] + [0])
+    ctrl[1 + rank] = len(records)
+    if collective:
+        dist.all_reduce(ctrl, op=dist.ReduceOp.MAX)    # size agreement (stride + every rank's record count), not a data-path exchange
+    ctrl = ctrl.cpu().tolist()
+    stride = (int(ctrl[0]) + 3) // 4 * 4                 # rows stay 8-byte aligned for the int64 header views
+    counts = [int(c) for c in ctrl[1:]]
+    if len(set(counts)) > 1:
+        counts = [max(c, 1) for c in counts]             # (ragged: an empty rank still sends one unused row -- no zero-size operands)
     PRE = 4                                                 # words 0..3: slot-in-use flag (+ alignment pad)
-    words = per_rank * (PRE + stride)
+    rows = counts[rank]
+    words = rows * (PRE + stride)
     own_send, own_recv = buffers if buffers is not None else (None, None)
     if own_send is not None and own_send.numel() >= words and own_send.device == dev:
-        send = own_send[:words].view(per_rank, PRE + stride)
-        send[:, :PRE] = 0
+        send = own_send[:words].view(rows, PRE + stride)
     else:
-        send = torch.empty(per_rank, PRE + stride, dtype=torch.int16, device=dev)
-        send[:, :PRE] = 0
+        send = torch.empty(rows, PRE + stride, dtype=torch.int16, device=dev)
+    send[:, :PRE] = 0
     for i, r in enumerate(records):
         send[i, 0] = 1
         send[i, PRE:PRE + r.numel()] = r
         send[i, PRE + r.numel():] = 0                      # (padding up to the common stride: defined bytes on the wire)
-    if world == 1 and not force_collective:
-        return [send[i, PRE:] for i in range(per_rank) if send[i, 0] == 1]
-    if own_recv is not None and own_recv.numel() >= world * words and own_recv.device == dev:
-        recv = own_recv[:world * words].view(world * per_rank, PRE + stride)
+    if not collective:
+        return [send[i, PRE:] for i in range(rows) if send[i, 0] == 1]
+    total = sum(counts)
+    if own_recv is not None and own_recv.numel() >= total * (PRE + stride) and own_recv.device == dev:
+        recv = own_recv[:total * (PRE + stride)].view(total, PRE + stride)
     else:
-        recv = torch.empty(world * per_rank, PRE + stride, dtype=torch.int16, device=dev)
-    # byte views: every backend moves uint8 (gloo has no int16)
-    dist.all_gather_into_tensor(recv.view(torch.uint8), send.view(torch.uint8))
+        recv = torch.empty(total, PRE + stride, dtype=torch.int16, device=dev)
+    _allgather_rows(send, recv, counts, rank)
     used = recv[:, 0].cpu()
-    return [recv[i, PRE:] for i in range(world * per_rank) if used[i] == 1]
+    return [recv[i, PRE:] for i in range(total) if used[i] == 1]
 
 
 def gather_layer_artifacts(adapter, chunk: Sequence[int], mine: Sequence[int], rotary_masks, rank: int, world: int,
@@ -190,18 +229,23 @@ def gather_layer_artifacts(adapter, chunk: Sequence[int], mine: Sequence[int], r
     rms = list(rotary_masks or [])
     if world == 1:
         return rms
+    # The send records are packed from the tensors save_layer was handed -- still on the device when the run asked the adapter to
+    # hold them (adapter.hold_artifacts(True): run_modegpt does for sharded runs) -- so the compressed layers go HBM -> xGMI, not
+    # HBM -> host -> disk -> host -> HBM.  An adapter that holds nothing (a duck-typed one; a resumed run) reads its files back.
+    held = getattr(adapter, "take_held_artifacts", None)
     flush = getattr(adapter, "flush_artifacts", None)
     if flush is not None:
-        flush()                             # (a background artefact writer: the files are read back below)
+        flush()         # a background artefact writer: this rank's own files are complete before anybody else can touch their names
     d = os.path.expandvars(adapter.config.temp_storage_dir)
     dev = "cuda" if torch.cuda.is_available() else "cpu"
     records = []
     for pos, layer in enumerate(mine):
-        tensors = {}
-        for suffix in ("mlp", "qk", "vo"):
-            p = os.path.join(d, f"layer_{layer}_{suffix}")
-            if os.path.exists(p):
-                tensors.update(torch.load(p, map_location=dev))
+        tensors = held(layer) if held is not None else {}
+        if not tensors:
+            for suffix in ("mlp", "qk", "vo"):
+                p = os.path.join(d, f"layer_{layer}_{suffix}")
+                if os.path.exists(p):
+                    tensors.update(torch.load(p, map_location=dev))
         records.append(pack_layer(layer, tensors, rms[pos] if pos < len(rms) else None))
     per = max_block(len(chunk), world)
     masks = {}

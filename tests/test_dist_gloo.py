@@ -144,6 +144,89 @@ def test_two_rank_compress_chunk_with_a_shared_artefact_directory():
         mp.spawn(_worker, args=(2, _free_port(), tmp), nprocs=2, join=True)
 
 
+def _worker_balanced(rank, world, port, tmp):
+    """Three ranks, ONE chunk of 5 layers under the forward-balanced partition (share 2 -> blocks of 3, 2 and 0 layers): the last
+    rank owns nothing and only computes the BI scores; the send records come from the tensors ModelAdapter.save_layer HOLDS (no file
+    is read back: torch.load is forbidden during the gather); the ranks send 3 / 2 / 1(unused) rows, not 3 x 3."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MODEGPT_SHARD_FORWARD_SHARE="2.0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from modegpt_amd import engine, run_modegpt as R, sharding as S
+    from modegpt_amd.adapters.CompressionConfig import CompressionConfig
+    from modegpt_amd.adapters.model_adapter import ModelAdapter
+    n = 5
+    assert S.partition(n, world) == [(0, 3), (3, 5), (5, 5)]
+    shared = os.path.join(tmp, "layers")
+
+    class B(engine.TensorAdapter):                 # a concrete adapter with the REAL save_layer (files + held tensors)
+        save_layer = ModelAdapter.save_layer
+
+    ad = B(dict(engine.SHAPES["tiny"], n_layers=n), {})
+    ad.config = CompressionConfig(temp_storage_dir=shared, calib_size=4, calibs_batch_size=2, compression_ratio=0.3)
+    ad.async_artifacts(True)
+    ad.hold_artifacts(True)
+    seen = {}
+
+    def load_calibs(adapter, n_samples, batch_size, dataset, target_layers):
+        seen["calib"] = (list(target_layers), adapter.calib_stop_after, adapter.calib_want_bi, adapter.calib_no_hooks)
+        none = [None] * n
+        return none, none, none, none, ([0.5 + i for i in range(n)] if adapter.calib_want_bi else None)
+
+    def allocate(bi, **kw):
+        seen["bi"] = list(bi)
+        return [0.7] * n
+
+    def nystrom(adapter, cov, keep_ratios, target_layers):
+        for i in target_layers:
+            adapter.save_layer(adapter.config.temp_storage_dir, "mlp", {k: _layer(i)[0][k] for k in ("up", "gate", "down")}, i)
+
+    def qk(adapter, cov, keep_ratios, target_layers):
+        for i in target_layers:
+            adapter.save_layer(adapter.config.temp_storage_dir, "qk", {k: _layer(i)[0][k] for k in ("q_proj", "k_proj")}, i)
+        return [_layer(i)[1] for i in target_layers]
+
+    def vo(adapter, cov, keep_ratios, target_layers):
+        for i in target_layers:
+            adapter.save_layer(adapter.config.temp_storage_dir, "vo", {k: _layer(i)[0][k] for k in ("v_proj", "o_proj")}, i)
+
+    R.load_calibs, R.allocate_global_sparsity, R.compress_nystrom, R.compress_qk, R.compress_vo = load_calibs, allocate, nystrom, qk, vo
+    R._free = lambda: None
+    rows = []
+    real_rows = S._allgather_rows
+    S._allgather_rows = lambda send, recv, counts, r: (rows.append((tuple(send.shape), list(counts))), real_rows(send, recv, counts, r))[1]
+    real_load = torch.load
+
+    def no_load(*a, **k):
+        raise AssertionError("the gather must pack its send buffer from the held tensors, not read files back")
+    chunk = list(range(n))
+    mine = S.my_layers(chunk, rank, world)
+    assert mine == [[0, 1, 2], [3, 4], []][rank]
+    torch.load = no_load
+    try:
+        masks = R.compress_chunk(ad, ad.config, chunk, rank, world)
+    finally:
+        torch.load = real_load
+    # the switches of the sharded calibration: only the last rank wants BI (and runs the whole forward); it owns no layer -> no hooks
+    assert seen["calib"] == (mine, mine[-1] if mine else 0, rank == world - 1, not mine)
+    assert not any(hasattr(ad, a) for a in ("calib_want_bi", "calib_stop_after", "calib_no_hooks"))      # (reset after the call)
+    assert seen["bi"] == [0.5 + i for i in range(n)]                                             # everybody got rank 2's BI scores
+    assert len(masks) == n and all(torch.equal(masks[i], _layer(i)[1]) for i in range(n))
+    assert rows == [((max(len(mine), 1), rows[0][0][1]), [3, 2, 1])]                              # 3 + 2 + 1 rows on the wire, not 3 x 3
+    assert ad.take_held_artifacts(0) == {}                                                       # (collected by the gather)
+    S.finalize()
+    if rank == 0:      # rank 0 holds every layer's files: its own from save_layer, the others' from the gathered records
+        for i in chunk:
+            got = {}
+            for suffix in ("mlp", "qk", "vo"):
+                got.update(torch.load(os.path.join(shared, f"layer_{i}_{suffix}")))
+            assert all(torch.equal(got[k], v) for k, v in _layer(i)[0].items()), i
+
+
+def test_three_ranks_balanced_partition_empty_last_rank_and_held_artefacts():
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker_balanced, args=(3, _free_port(), tmp), nprocs=3, join=True)
+
+
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus 2` with no torchrun environment: the script spawns two fresh ranks itself (here on CPU over gloo,
     plumbing only -- the kernels need a GPU), rank 0 prints the one JSON line, exit code 0."""

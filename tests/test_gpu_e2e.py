@@ -525,6 +525,184 @@ def test_other_baseline_shapes_one_layer(dev, name, keep):
         assert torch.equal(omask, mask.cpu())
 
 
+def test_default_int8_route_on_real_forward_pass_activations(dev, tmp_path, monkeypatch):
+    """SURVEY 8(f) row 2 / VERDICT r3 item 1b: the route that ships by default, on what a model actually emits.  A random-init
+    Llama (d = 2048, d_ff = 8192, 16 q / 4 kv heads of 128, 2 layers) runs real HF forward passes over 2 x 16 x 2048 tokens; the
+    adapter's hooks (LlamaAdapter.py:71-147) feed the statistics
+      (a) through the default int8 digit-plane route   (ops.COV_MODE = "i8": sigma_mlp 8192 and sigma_x 2048 wide, both >= I8_MIN_FEATURES),
+      (b) through the v_mfma_f64 kernels                (ops.COV_MODE = "f64"),
+    and (c) independent torch hooks capture the same activations for the CPU oracle's fp64 sums.
+    Asserted: every sigma_mlp call took six planes (SiLU-gated activations) and none fell back; (a) is within the bound its own calls
+    computed of (c), entry-wise -- the guarantee -- and, forward-pass activations being a measured family, within the empirical 1e-12;
+    (b) equals (c) to fp64 rounding; and the MLP index set, the gathered up / gate rows, the QK masks and q / k rows from (a), (b) and
+    the oracle's own compression of (c) are IDENTICAL, layer by layer; down_proj agrees to bf16 rounding."""
+    transformers = pytest.importorskip("transformers")
+    from modegpt_amd import ops
+    from modegpt_amd.adapters.CompressionConfig import CompressionConfig
+    from modegpt_amd.adapters.model_adapter import ModelAdapter
+    from modegpt_amd.calibration import load_calibs
+    from modegpt_amd.compression.compress_mlp import compress_nystrom
+    from modegpt_amd.compression.compress_qk import compress_qk
+    from tests.i8_limits import check_i8_error
+
+    torch.manual_seed(0)
+    cfg = transformers.LlamaConfig(hidden_size=2048, intermediate_size=8192, num_hidden_layers=2, num_attention_heads=16,
+                                   num_key_value_heads=4, head_dim=128, vocab_size=1024, max_position_embeddings=2048)
+    model = transformers.LlamaForCausalLM(cfg).to(dev).to(torch.bfloat16).eval()
+    ad = ModelAdapter.from_model(model, None)
+    keep = [0.7, 0.7]
+    layers = [0, 1]
+
+    # every int8 call of the hooks reports its route and bound to the test (the product path only enqueues)
+    infos = {"single": [], "multi": []}
+    real_single, real_multi = ops.cov_accum_i8, ops.cov_accum_i8_multi
+
+    def single(sigma, x, **kw):
+        info = {}
+        kw.pop("report", None)
+        out = real_single(sigma, x, route_info=info, **kw)
+        infos["single"].append((sigma.shape[-1], info))
+        return out
+
+    def multi(items, **kw):
+        items, info = list(items), []
+        kw.pop("report", None)
+        out = real_multi(items, route_info=info, **kw)
+        infos["multi"].append(([s_.shape[-1] for s_, _, _ in items], info))
+        return out
+
+    results = {}
+    for mode in ("i8", "f64"):
+        monkeypatch.setattr(ops, "COV_MODE", mode)
+        monkeypatch.setattr(ops, "cov_accum_i8", single)
+        monkeypatch.setattr(ops, "cov_accum_i8_multi", multi)
+        ad.config = CompressionConfig(temp_storage_dir=str(tmp_path / f"layers_{mode}"), nystrom_ridge=1e-4, ridge_qk=1e-2, ridge_vo=1e-5,
+                                      dataset="synthetic", calib_size=32, calibs_batch_size=16, order="mlp,qk")
+        ops.i8_route_counts(dev, reset=True)
+        cov_mlp, cov_q, cov_k, cov_x, bi = load_calibs(ad, n_samples=32, batch_size=16, dataset="synthetic", target_layers=[])
+        routes = dict(ad.cov_routes) if mode == "i8" else None
+        monkeypatch.setattr(ops, "cov_accum_i8", real_single)
+        monkeypatch.setattr(ops, "cov_accum_i8_multi", real_multi)
+        compress_nystrom(ad, cov_mlp, keep, layers)
+        masks = compress_qk(ad, (cov_q, cov_k), keep, target_layers=layers)
+        margins = ad.report_selection_margins()
+        art = {}
+        for l in layers:
+            art[l] = {}
+            for suffix in ("mlp", "qk"):
+                art[l].update(torch.load(os.path.join(ad.config.temp_storage_dir, f"layer_{l}_{suffix}"), map_location="cpu"))
+        results[mode] = dict(cov={"mlp": [c.cpu() for c in cov_mlp], "x": [c.cpu() for c in cov_x], "q": [c.cpu() for c in cov_q],
+                                  "k": [c.cpu() for c in cov_k]}, art=art, masks=[m.cpu() for m in masks], routes=routes, margins=margins)
+        del cov_mlp, cov_q, cov_k, cov_x
+    assert len(ad.calibs) == 2 and tuple(ad.calibs[0].shape) == (16, 2048)
+
+    # (a) the routes the hooks' calls took: sigma_mlp alone, on six planes, every call; sigma_x + sigma_q + sigma_k together on five
+    mlp_calls = [i for n_, i in infos["single"] if n_ == 8192]
+    assert len(mlp_calls) == 4 and all(i["planes"] == 6 and not i["columns"] for i in mlp_calls), [i["planes"] for i in mlp_calls]
+    assert len(infos["multi"]) == 4 and all(w == [2048, 128, 128] for w, _ in infos["multi"])
+    assert results["i8"]["routes"]["fallback_f64"] == 0 and results["i8"]["routes"]["i8_6"] == 4 and results["i8"]["routes"]["i8_5"] == 12
+    bound_mlp = max(i["bound"] for i in mlp_calls)
+    bound_rest = [max(info[k]["bound"] for _, info in infos["multi"]) for k in range(3)]
+    assert all(info[k]["planes"] in (5, 6) for _, info in infos["multi"] for k in range(3))
+
+    # (c) the oracle's statistics from independently captured activations
+    store, _, n_texts = _capture(ad, ad.calibs)
+    assert n_texts == 32
+
+    def entry_err(S, R):
+        d = torch.sqrt(torch.diagonal(R, dim1=-2, dim2=-1))
+        return ((S - R).abs() / (d[..., :, None] * d[..., None, :])).max().item()
+
+    shape = dict(arch=ad.arch, n_heads=ad.n_heads, n_kv_heads=ad.n_kv_heads, head_dim=ad.head_dim)
+    ridges = dict(nystrom_ridge=1e-4, ridge_qk=1e-2, ridge_vo=1e-5)
+    for l in layers:
+        ref = {"mlp": torch.zeros(8192, 8192, dtype=F64), "x": torch.zeros(2048, 2048, dtype=F64),
+               "q": torch.zeros(16, 128, 128, dtype=F64), "k": torch.zeros(4, 128, 128, dtype=F64)}
+        for t in store[l]["h"]:
+            O.cov_accum_tokens(ref["mlp"], t)
+        for t in store[l]["x"]:
+            O.cov_accum_tokens(ref["x"], t)
+        for t in store[l]["q"]:
+            O.cov_accum_heads(ref["q"], t, 16, 128)
+        for t in store[l]["k"]:
+            O.cov_accum_heads(ref["k"], t, 4, 128)
+        for v in ref.values():
+            O.cov_finalize(v, n_texts)
+        store[l] = None
+        i8c, f64c = results["i8"]["cov"], results["f64"]["cov"]
+        check_i8_error(entry_err(i8c["mlp"][l], ref["mlp"]), bound_mlp, family="model_forward", ctx=("sigma_mlp", l))
+        for k, kind in enumerate(("x", "q", "k")):
+            check_i8_error(entry_err(i8c[kind][l], ref[kind]), bound_rest[k], family="model_forward", ctx=("sigma_" + kind, l))
+        for kind in ("mlp", "x", "q", "k"):
+            assert entry_err(f64c[kind][l], ref[kind]) < 1e-13, (kind, l)
+        w = {"up": ad.get_mlp_tensors(l).up_proj.detach().cpu(), "gate": ad.get_mlp_tensors(l).gate_proj.detach().cpu(),
+             "down": ad.get_mlp_tensors(l).down_proj.detach().cpu(), "q": ad.get_qk_tensors(l).query_proj.detach().cpu(),
+             "k": ad.get_qk_tensors(l).key_proj.detach().cpu()}
+        mlp, aux = O.compress_mlp_layer(w["up"], w["gate"], w["down"], ref["mlp"], keep[l], ridges["nystrom_ridge"])
+        qk, omask = O.compress_qk_layer(w["q"], w["k"], ref["q"], ref["k"], 16, 4, 128, O.qk_rank(128, keep[l], "llama"), "llama",
+                                        ridges["ridge_qk"])
+        for mode in ("i8", "f64"):
+            a_ = results[mode]["art"][l]
+            assert torch.equal(a_["up"], mlp["up"]) and torch.equal(a_["gate"], mlp["gate"]), (mode, l, "MLP index set")
+            assert torch.equal(results[mode]["masks"][l], omask), (mode, l, "QK mask")
+            assert torch.equal(a_["q_proj"], qk["q_proj"]) and torch.equal(a_["k_proj"], qk["k_proj"]), (mode, l)
+            assert bf16_mismatch(a_["down"], mlp["down"]) < 2e-3, (mode, l)
+        assert torch.equal(results["i8"]["art"][l]["up"], results["f64"]["art"][l]["up"])
+        del ref
+    print("selection margins (layer: margin / score bound / certified):",
+          {m: {l: (f"{v['margin']:.2e}", f"{v['score_bound']:.2e}", v["certified"]) for l, v in results[m]["margins"].items()} for m in results})
+    assert all(set(results[m]["margins"]) == {0, 1} for m in results)
+
+
+def test_opt_125m_real_layer_against_the_oracle_in_full(dev):
+    """BASELINE config #1 at its REAL layer shape and token count: OPT-125m, d = 768, ffn 3072, 12 heads of 64,
+    128 samples x 2048 tokens in batches of 16, 20 % compression (keep 0.8), ReLU on the fc1 hook, no gate matrix, the two-SVD MHA
+    VO path, CR without RoPE pairing.  The whole layer fits the CPU oracle in seconds, so everything is compared in full: the four
+    statistics (fp64 kernels: OPT's ReLU statistic and its 768-wide sigma_x stay on v_mfma_f64), ridge scores, the MLP index set,
+    up rows, the Nystrom down_proj (fp64 and bf16), q / k rows, and the VO factors through their invariant products."""
+    from modegpt_amd import engine, ops
+    shape = dict(engine.SHAPES["opt-125m"])
+    assert (shape["d"], shape["d_ff"], shape["n_heads"], shape["head_dim"]) == (768, 3072, 12, 64)
+    keep, n_texts, batch = 0.8, 128, 16
+    w = engine.make_layer_weights(shape, 125, dev)
+    assert "gate" not in w
+    ad = engine.TensorAdapter(shape, {0: w})
+    ad.calib_tokens = n_texts * 2048
+    covs = engine.new_covs(shape, dev)
+    ref = {k: torch.zeros_like(v, device="cpu") for k, v in covs.items()}
+    for b in range(n_texts // batch):
+        bt = engine.make_activation_batch(shape, batch * 2048, seed=1250 + b, device=dev)
+        bt["h"] = bt["h"] - bt["h"].abs().mean(0, keepdim=True) * 0.2          # (fc1 output: negative about half the time, ReLU cuts it)
+        engine.accumulate(covs, bt, shape)
+        O.cov_accum_tokens_relu(ref["mlp"], bt["h"].cpu())
+        O.cov_accum_tokens(ref["x"], bt["x"].cpu())
+        O.cov_accum_heads(ref["q"], bt["q"].cpu(), 12, 64)
+        O.cov_accum_heads(ref["k"], bt["k"].cpu(), 12, 64)
+    engine.finalize(covs, n_texts)
+    for v in ref.values():
+        O.cov_finalize(v, n_texts)
+    for k in covs:
+        assert rel(covs[k], ref[k]) < 1e-13, k
+    out, mask = engine.compress_layer(ad, 0, covs, keep)
+    margins = ad.report_selection_margins()
+    want = O.compress_layer_all({k: v.cpu() for k, v in w.items()}, ref, shape, keep, engine.RECIPE_RIDGES)
+    r_mlp, r = int(3072 * keep), O.qk_rank(64, keep, "opt")
+    assert (r_mlp, r) == (2457, 51) and out["up"].shape == (r_mlp, 768) and "gate" not in out
+    lam = float(torch.tensor(1e-4, dtype=torch.float32).double())
+    sc = ops.ridge_scores(covs["mlp"], lam)
+    assert rel(sc, O.ridge_scores(ref["mlp"], 1e-4)) < 1e-9
+    assert torch.equal(ops.select_smallest_sorted(sc, r_mlp).cpu(), want["aux"]["mlp"][0]), "MLP index set"
+    assert torch.equal(out["up"].cpu(), want["mlp"]["up"])
+    assert bf16_mismatch(out["down"], want["mlp"]["down"]) < 1e-3 and rel(out["down"], want["mlp"]["down"]) < 2 ** -7
+    assert torch.equal(out["q_proj"].cpu(), want["qk"]["q_proj"]) and torch.equal(out["k_proj"].cpu(), want["qk"]["k_proj"])
+    assert out["v_proj"].shape == (12 * r, 768) and out["o_proj"].shape == (768, 12 * r)
+    P = vo_products(out["v_proj"].cpu(), out["o_proj"].cpu(), 12, 12, r)
+    Pr = vo_products(want["vo"]["v_proj"], want["vo"]["o_proj"], 12, 12, r)
+    assert rel(P, Pr) < 3e-2
+    assert margins[0]["eps"] == (n_texts * 2048 / 4 + 4) * 2.0 ** -53      # (the fp64 route: the certificate is taken against its rounding bound)
+    print("OPT-125m layer: selection margin", margins[0])
+
+
 def test_run_modegpt_main_on_local_checkpoint(dev, tmp_path, monkeypatch):
     """The driver end to end, exactly as `python -m src.run_modegpt` runs it: a random-init Llama saved to a local
     directory with a toy tokenizer, dataset "synthetic" (no network), 30 % compression, checkpoint written in the
@@ -882,3 +1060,6 @@ def test_bench_line_contract():
     assert r["bound"] == "mfma" and r["unit"] == "TOP/s" and r["peak"] == 5000.0 and 0.2 < r["frac"] < 1.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5 and r["launches"] == 3 * 4 and r["routes"]["fallback_f64"] == 0
     assert "cpu_baseline" in d and len(lines[0]) < 4096
+    c = d["selection_certificate"]           # the MLP rank selections of the three timed layers: certified (or flagged) against eps
+    assert c["layers"] == 3 and 0 <= c["certified"] <= 3 and c["margin_min"] > 0 and 0 < c["eps"] < 2e-11 and c["score_bound_max"] > 0
+    assert r["i8_tolerance_factor"] == 1.0
