@@ -505,7 +505,8 @@ def main():
         planes_per_batch = []
         for b in batches:
             info = {}
-            planes_per_batch.append(ops.cov_accum_i8(replay, b["h"], mfma_stats=stats, route_info=info))
+            cls = ops.cov_accum_i8(replay, b["h"], mfma_stats=stats, route_info=info)
+            planes_per_batch.append(5 if (cls and info["exact"]) else cls)       # (the product kernel that ran: the exact route uses the five-plane one)
             bounds.append(info)
         ops.I8_STATS.update(routes_before)
         del replay
@@ -563,6 +564,7 @@ def main():
             "routes": ops.i8_route_counts(dev),
             "error_bound": {"guaranteed_max": max(b_["bound"] for b_ in bounds), "sq_max": max(b_["sq"] for b_ in bounds),
                             "x_max": max(b_["x"] for b_ in bounds), "planes": sorted(set(planes_per_batch)),
+                            "exact_route_batches": sum(1 for b_ in bounds if b_["exact"]),
                             "fp64_columns_per_batch_max": max(len(b_["columns"]) for b_ in bounds)}}
     if i8:
         out["roofline"]["i8_tolerance_factor"] = tol
@@ -825,9 +827,13 @@ def extra_leg(shape, adapter, ids, data, keep, n_texts, pipelined, dev, tokens):
     del scratch
     nl, _, msl = tg.summary()
     frac = st6["executed"] / st6["dense"] if st6.get("dense") else 1.0
+    used_class = used
+    if used and info.get("exact"):
+        used = 5                                             # (the exact route: the five-plane kernel on three dense planes + the remainder kernel)
     pairs = {5: 15, 6: 21}.get(used, 15)
     tops_dense = pairs * nl * tokens * f * (f + 1) / (msl * 1e-3) / 1e12
-    return {"value": len(ids) / sec, "ms_per_step": sec / len(ids) * 1e3, "steps": len(ids), "planes": used, "avg_launch_ms": msl / nl,
+    return {"value": len(ids) / sec, "ms_per_step": sec / len(ids) * 1e3, "steps": len(ids), "planes": used_class, "exact_route": bool(info.get("exact")),
+            "avg_launch_ms": msl / nl,
             "executed_fraction": frac, "achieved": tops_dense * frac, "frac": tops_dense * frac / INT8_MFMA_PEAK_TOPS,
             "routes": {k: after[k] - before[k] for k in after}, "error_bound": info.get("bound"), "fp64_columns_mlp": info.get("columns"),
             "selection_certificate": sel}

@@ -37,7 +37,8 @@ extern "C" {
                              8: mdg_cov_i8_set_tolerance / mdg_cov_i8_tolerance, mdg_nystrom_down_overlapped added;
                              9: the int8 route's tolerance factor is an ARGUMENT of mdg_cov_accum_i8 / mdg_cov_accum_i8_multi (the
                                 process-wide setter / getter of ABI 8 are gone: no accuracy state in the library);
-                                mdg_ridge_scores takes `sens`, mdg_select_margin added (certificate of the MLP rank selection) */
+                                mdg_ridge_scores takes `sens`, mdg_select_margin added (certificate of the MLP rank selection);
+                                the exact route of the int8 covariance (`flags`, route_counts[4], mdg_cov_accum_i8_route's `exact`) */
 
 enum mdg_status {
   MDG_OK = 0,
@@ -123,9 +124,10 @@ int mdg_cov_accum_multi(int n, const mdg_cov_problem* problems, int dtype, void*
  * The route is chosen ON THE DEVICE: the call enqueues the five-plane product, the six-plane product, the column kernel and the fp64
  * kernel back to back, and the launches the route does not select exit at once -- the call only enqueues and never waits for the host
  * (it can be captured in a hipGraph) when used_i8 is NULL.  Every decision is a function of integer sums: run-to-run bit-identical.
- * route_counts (DEVICE pointer to 4 ints, optional): [0] += 1 when five planes ran, [1] six planes, [2] the fp64 kernel for the whole
- *   statistic, [3] += the number of columns handed to the fp64 column kernel; the caller keeps it across calls and reads it whenever
- *   it likes (calibration reads it once, at the end).
+ * route_counts (DEVICE pointer to 5 ints, optional): [0] += 1 when five planes ran, [1] six planes, [2] the fp64 kernel for the whole
+ *   statistic, [3] += the number of columns handed to the fp64 column kernel, [4] += 1 when the exact route ran (see below; such a
+ *   call is also booked under [0] or [1], the class the route kernel gave it); the caller keeps it across calls and reads it
+ *   whenever it likes (calibration reads it once, at the end).
  * used_i8 (HOST pointer, optional; measurement and tests): receives the route of THIS call -- 5, 6, or 0 for the fp64 kernel --
  *   at the price of one stream synchronisation.
  * tolerance: the accuracy / speed dial of THIS call, one factor f in [1, 1e6] on both thresholds of the route (SQ_P <= f 1e-12,
@@ -137,10 +139,25 @@ int mdg_cov_accum_multi(int n, const mdg_cov_problem* problems, int dtype, void*
  * n_feat must be a multiple of 128, n_tokens < 2^28.  ws: mdg_cov_accum_i8_ws_bytes (about 6 bytes per element of x).
  * ev_start / ev_stop: optional hipEvent_t recorded on `stream` right before / after the two product launches (bench.py times
  * the dominant kernel alone with them); NULL otherwise. */
+/* THE EXACT ROUTE (default since ABI 9; flags & MDG_I8_NO_EXACT switches it off).  Planes 3 .. 5 are reached only by elements 17
+ * binades and more below their column's maximum -- 3e-5 of the elements of a Gaussian column, 0.5 % of a SiLU-gated one -- so the
+ * call lists those elements (token, column, low 24 bits) and, when every list fits (at most 3.1 % of any 32 columns x 2048 tokens),
+ * replaces the truncated product by an exact one:  X^T X = X_d^T X_d + X_lo^T X + X_d^T X_lo  with X_d the top three digit planes --
+ * all NINE of their plane pairs on the int8 matrix cores (the five-plane kernel with the deeper planes masked off) -- and the two
+ * remainder products as fp64 sums over the listed elements (i8_lo_product_kernel).  No plane pair is dropped: the error is fp64
+ * rounding (<= MDG_I8_EXACT_ROUNDING of sqrt(sigma_ii sigma_jj)) plus the bound's rho term for elements more than 38 binades under
+ * their column maximum, whatever `tolerance` says; 9 executed plane pairs instead of 9.4 (Gaussian) / 15.1 (SiLU-gated).  The route
+ * kernel's decisions are unchanged -- which columns leave for the fp64 column kernel, whether the whole statistic goes to
+ * mdg_cov_accum, five or six planes when a list does not fit -- and so is everything the call reports, plus: route_counts[4] += the
+ * statistics that took the exact route (they are also booked under the five- / six-plane class the route kernel gave them), and
+ * mdg_cov_accum_i8_route's `exact`. */
 #define MDG_I8_MAX_COLUMNS 32
+#define MDG_I8_NO_EXACT 1             /* flags: never the exact route (the truncated five- / six-plane product with its bound) */
+#define MDG_I8_EXACT_ROUNDING 5e-15   /* what mdg_cov_accum_i8_route reports beside the rho term for a call on the exact route */
 size_t mdg_cov_accum_i8_ws_bytes(int64_t n_tokens, int64_t n_feat);
 int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat, int64_t ld, double* sigma, int64_t ld_sigma, void* ws,
-                     size_t ws_bytes, double tolerance, int* used_i8, int* route_counts, void* ev_start, void* ev_stop, void* stream);
+                     size_t ws_bytes, double tolerance, int flags, int* used_i8, int* route_counts, void* ev_start, void* ev_stop,
+                     void* stream);
 /* v_mfma instructions the product kernel of the LAST mdg_cov_accum_i8 call on workspace `ws` executed (0 after a call that
  * fell back to mdg_cov_accum).  The split pass records, per k-step and 32-row group, which digit planes hold a nonzero
  * there; the product kernel neither loads nor multiplies planes that are all-zero over a tile panel, so the count is at
@@ -150,10 +167,11 @@ int mdg_cov_accum_i8_stats(const void* ws, int64_t n_tokens, int64_t n_feat, uns
 /* The route the LAST mdg_cov_accum_i8 / mdg_cov_accum_i8_multi call on workspace `ws` took for statistic `stat` of `problems` (the
  * array that call was given): *planes = 5, 6, or 0 (whole statistic through mdg_cov_accum); *n_columns and columns[MDG_I8_MAX_COLUMNS]
  * (-1 padded) = the columns the fp64 column kernel computed, in the order the route took them; bound[0] = SQ_P, bound[1] = X_P of
- * the columns that stayed (their sum bounds the entry-wise error relative to sqrt(sigma_ii sigma_jj) of this call's tokens).  Any
- * output pointer may be NULL.  Copies device -> host on `stream` and synchronises it: tests and measurements only. */
+ * the columns that stayed (their sum bounds the entry-wise error relative to sqrt(sigma_ii sigma_jj) of this call's tokens); *exact = 1
+ * when the call ran the exact route (then bound[0] = the rho term + MDG_I8_EXACT_ROUNDING, bound[1] = 0).  Any output pointer may be
+ * NULL.  Copies device -> host on `stream` and synchronises it: tests and measurements only. */
 int mdg_cov_accum_i8_route(int count, const mdg_cov_problem* problems, int stat, const void* ws, int* planes, int* n_columns,
-                           int* columns, double* bound, void* stream);
+                           int* columns, double* bound, int* exact, void* stream);
 /* Up to 4 statistics of ONE calibration batch (the four hooks of a layer) through the int8 digit-plane kernels with ONE
  * persistent product launch: the tiles of all statistics share one static tile schedule, so the small ones fill what the large
  * one's last round leaves idle instead of ending launches of their own, and one route -- the deepest any statistic on the int8 path
@@ -163,13 +181,13 @@ int mdg_cov_accum_i8_route(int count, const mdg_cov_problem* problems, int stat,
  * batch > 1: per-head Grams of an activation [n_tokens][batch * 128] -- n_feat must be 128, sigma contiguous
  * [batch][128][128] (ld_sigma 128, sigma_batch_stride 16384); only the diagonal tiles are computed.  Several statistics need a
  * 256-CU device (the schedule is cut for 8 XCDs x 32 CUs); otherwise call mdg_cov_accum_i8 per statistic.
- * tolerance / used_i8 / route_counts / ev_start / ev_stop as in mdg_cov_accum_i8 (route_counts += the number of statistics per route;
+ * tolerance / flags / used_i8 / route_counts / ev_start / ev_stop as in mdg_cov_accum_i8 (route_counts += the number of statistics per route;
  * used_i8 = 5 or 6, the planes of the statistics that stayed on the int8 path, 0 when all of them went to the fp64 kernel);
  * mdg_cov_accum_i8_stats(ws, 0, 0, ...) reads the executed-MFMA count of the whole launch.  mdg_cov_accum_i8 is this call with
  * one statistic. */
 size_t mdg_cov_accum_i8_multi_ws_bytes(int count, const mdg_cov_problem* problems);
-int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems, void* ws, size_t ws_bytes, double tolerance, int* used_i8,
-                           int* route_counts, void* ev_start, void* ev_stop, void* stream);
+int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems, void* ws, size_t ws_bytes, double tolerance, int flags,
+                           int* used_i8, int* route_counts, void* ev_start, void* ev_stop, void* stream);
 /* sigma[b] <- scale * sigma[b] on the lower triangle, mirrored into the upper.  scale = 1/(n_texts*2048)
  * reproduces calibration.py:141-146. */
 int mdg_cov_finalize(double* sigma, int64_t n, int64_t batch, int64_t ld_sigma, int64_t sigma_batch_stride,

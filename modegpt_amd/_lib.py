@@ -16,6 +16,7 @@ MDG_OK = 0
 MDG_ERR_BAD_ARG, MDG_ERR_HIP, MDG_ERR_NOT_PD, MDG_ERR_NO_CONVERGE, MDG_ERR_NO_DEVICE = -1, -2, -3, -4, -5
 MDG_BF16, MDG_F16, MDG_F32, MDG_F64 = 0, 1, 2, 3
 MDG_QK_ROPE_GROUPED, MDG_QK_ROPE_MHA, MDG_QK_OPT = 0, 1, 2
+MDG_I8_NO_EXACT = 1
 MDG_GEMM_LOWER_ONLY, MDG_GEMM_A_LOWER_TRI, MDG_GEMM_B_LOWER_TRI, MDG_GEMM_A_UPPER_TRI = 1, 2, 4, 8
 
 _i64, _i32, _f64, _ptr, _sz = C.c_int64, C.c_int, C.c_double, C.c_void_p, C.c_size_t
@@ -41,12 +42,12 @@ SIGNATURES = {
     "mdg_cov_accum_ws_bytes": (_sz, [_i64, _i64, _i64]),
     "mdg_cov_accum": (_i32, [_ptr, _i32, _i64, _i64, _i64, _i64, _i32, _ptr, _i64, _i64, _ptr, _sz, _ptr]),
     "mdg_cov_accum_i8_ws_bytes": (_sz, [_i64, _i64]),
-    "mdg_cov_accum_i8": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _i64, _ptr, _sz, _f64, C.POINTER(_i32), _ptr, _ptr, _ptr, _ptr]),
+    "mdg_cov_accum_i8": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _i64, _ptr, _sz, _f64, _i32, C.POINTER(_i32), _ptr, _ptr, _ptr, _ptr]),
     "mdg_cov_accum_i8_stats": (_i32, [_ptr, _i64, _i64, C.POINTER(C.c_ulonglong), _ptr]),
     "mdg_cov_accum_i8_route": (_i32, [_i32, C.POINTER(CovProblem), _i32, _ptr, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32),
-                                       C.POINTER(_f64), _ptr]),
+                                       C.POINTER(_f64), C.POINTER(_i32), _ptr]),
     "mdg_cov_accum_i8_multi_ws_bytes": (_sz, [_i32, C.POINTER(CovProblem)]),
-    "mdg_cov_accum_i8_multi": (_i32, [_i32, C.POINTER(CovProblem), _ptr, _sz, _f64, C.POINTER(_i32), _ptr, _ptr, _ptr, _ptr]),
+    "mdg_cov_accum_i8_multi": (_i32, [_i32, C.POINTER(CovProblem), _ptr, _sz, _f64, _i32, C.POINTER(_i32), _ptr, _ptr, _ptr, _ptr]),
     "mdg_cov_accum_multi_ws_bytes": (_sz, [_i32, C.POINTER(CovProblem), _i32]),
     "mdg_cov_accum_multi": (_i32, [_i32, C.POINTER(CovProblem), _i32, _ptr, _sz, _ptr]),
     "mdg_cov_finalize": (_i32, [_ptr, _i64, _i64, _i64, _i64, _f64, _ptr]),

@@ -380,6 +380,7 @@ struct RouteOut {                           // per statistic, in the workspace (
   int n_out;                                // columns handed to the fp64 column kernel
   int out[ROUTE_JMAX];                      // ... in the order they were taken
   double sq, x;                             // SQ_P, X_P of the columns that stay (the guaranteed bound is their sum)
+  double rho;                               // 2 R + R^2 alone: what is left of the bound when no plane pair is dropped (the exact route)
 };
 
 __device__ __forceinline__ void route_terms(const double (&A)[NVAL], int P, double& sq, double& x) {
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(ROUTE_THREADS) void i8_route_kernel(const unsigned 
   int n_out = 0;
   if (forced_total > ROUTE_JMAX) {      // too many: the whole statistic goes through the fp64 kernel
     if (tid == 0) {
-      out->planes = 0; out->n_out = 0; out->sq = out->x = 0.0;
+      out->planes = 0; out->n_out = 0; out->sq = out->x = out->rho = 0.0;
       atomicOr(flag, 2);
     }
     for (int j = tid; j < n; j += ROUTE_THREADS) emax[j] &= 255;
@@ -626,6 +627,7 @@ __global__ __launch_bounds__(ROUTE_THREADS) void i8_route_kernel(const unsigned 
           out->planes = P;
           out->n_out = n_out;
           route_terms(A, P, out->sq, out->x);
+          out->rho = 2.0 * A[6] + A[6] * A[6];
           if (P == 6) atomicOr(flag, 1);
           if (route_counts && n_out) atomicAdd(route_counts + 3, n_out);
           decision = 0;
@@ -667,7 +669,7 @@ __global__ __launch_bounds__(ROUTE_THREADS) void i8_route_kernel(const unsigned 
     }
   }
   if (tid == 0) {
-    out->planes = 0; out->n_out = 0; out->sq = out->x = 0.0;
+    out->planes = 0; out->n_out = 0; out->sq = out->x = out->rho = 0.0;
     atomicOr(flag, 2);
   }
   for (int j = tid; j < n; j += ROUTE_THREADS) emax[j] &= 255;
@@ -735,6 +737,7 @@ struct SyrkArgs {
   double* partial;                     // [slot][128][TJ] fp64 partial tiles of the k-split last round (zeroed per call; i8_tail_combine_kernel)
   const int4* tail;                    // [n_tail] {tile code, Q, first slot, 0}: the tiles of the split round
   int* xcd_arrive;                     // [8] arrival counters of the round barrier (zeroed per call)
+  const int* exact_state;              // nullptr: the exact route is not on offer for this call; else {overflow, ran} written by i8_extract_lo_kernel
 #ifdef MDG_I8_STAMPS
   unsigned long long* stamps;          // diagnostic build only: per (workgroup, wave) cycle sums of the k-step phases
 #endif
@@ -757,6 +760,22 @@ __device__ __forceinline__ int launch_route(const SyrkArgs& a, int& live, int& f
     }
   }
   return live ? six : -1;
+}
+
+// The EXACT route (section "exact route" below): the three top digit planes through the five-plane kernel with every deeper plane
+// masked off -- all nine plane pairs of the 24-bit part, nothing truncated -- and the remainder of the elements that have one
+// through the fp64 remainder kernel.  On offer when the remainder lists were built and none overflowed; it then serves the
+// statistics of BOTH legacy classes (five and six planes) of the launch.
+__device__ __forceinline__ bool exact_route(const SyrkArgs& a) {
+  return a.exact_state && a.exact_state[1] == 1 && a.exact_state[0] == 0;
+}
+// Does the P-plane product launch of this call do the work?  (0: no; 1: legacy route; 2: the exact route -- P = 5 only)
+template <int P>
+__device__ __forceinline__ int product_launch_runs(const SyrkArgs& a, int& live, int& fallbacks) {
+  const int route = launch_route(a, live, fallbacks);
+  if (route < 0) return 0;
+  if (exact_route(a)) return P == 5 ? 2 : 0;
+  return route == (P == 5 ? 0 : 1) ? 1 : 0;
 }
 
 #ifdef MDG_I8_STAMPS
@@ -814,7 +833,7 @@ constexpr int ring_depth(int planes) { return wide_tile(planes) ? RING5 : 4; }
 template <int P>
 __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProblem& pr, const int bi, const int bj, const int kb, const int ke, double* const fold,
                                              const int64_t fold_ld, const int fold_row0, const int fold_col0, unsigned char* lds,
-                                             unsigned& executed) {
+                                             unsigned& executed, const unsigned mask_and) {
   constexpr int WB = wide_tile(P) ? 2 : 1;         // 32-row blocks of a wave tile: 64 x 32, or 32 x 32 (96 accumulators at P = 6)
   constexpr int TJ = WB == 2 ? 128 : 64;           // tile columns (rows of the J operand); waves are laid out (128 / 32 WB) x (TJ / 32)
   constexpr int PB = TJ * KS;
@@ -935,8 +954,10 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
   const int64_t mgroups = pr.n / 32;
   auto load_masks = [&](int kt, unsigned& va, unsigned& vb) {
     const unsigned* z = (const unsigned*)(pr.zmask + (int64_t)kt * mgroups);   // n / 32 is a multiple of 4: dword-aligned rows
-    va = z[bi];                                                               // groups 4 bi .. 4 bi + 3
-    vb = TJ == 128 ? z[bj] : z[bj >> 1];   // groups 4 bj .. + 3; or 2 bj, 2 bj + 1 in one half of the dword (see b_half)
+    // mask_and: all ones, or 0x07070707 on the exact route -- planes 3 .. 5 are then "absent" everywhere: neither loaded nor
+    // multiplied here (the remainder kernel has them)
+    va = z[bi] & mask_and;                                                    // groups 4 bi .. 4 bi + 3
+    vb = (TJ == 128 ? z[bj] : z[bj >> 1]) & mask_and;   // groups 4 bj .. + 3; or 2 bj, 2 bj + 1 in one half of the dword (see b_half)
   };
   // 128 x 64 tiles: the B panel's two mask bytes are one half of the loaded dword
   auto b_half = [&](unsigned m) { return TJ == 128 ? m : (m >> ((bj & 1) * 16)) & 0xFFFFu; };
@@ -1153,12 +1174,24 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
   // The route is chosen on the DEVICE: mdg_cov_accum_i8 enqueues the five-plane product, the six-plane product and the fp64
   // kernel back to back, and each exits at once unless the depth statistic of this call (i8_depth_kernel) selects it -- the
   // host never waits for the flag.  The six-plane launch also books the fp64 fallback in the route counters.
+  unsigned mask_and = ~0u;
   {
     int live, fallbacks;
-    const int route = launch_route(a, live, fallbacks);
+    const int runs = product_launch_runs<P>(a, live, fallbacks);
     if (P == 6 && fallbacks && a.route_counts && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.route_counts + 2, fallbacks);
-    if (route != (P == 5 ? 0 : 1)) return;
-    if (a.route_counts && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.route_counts + (P == 5 ? 0 : 1), live);
+    if (!runs) return;
+    if (a.route_counts && blockIdx.x == 0 && threadIdx.x == 0) {
+      if (runs == 2) {   // the exact route serves both legacy classes: book them as the route kernel classed them, and the exact count
+        int six = 0;
+        for (int p = 0; p < a.nprob; p++) six += (a.route_flag[p] & 3) == 1;
+        if (live - six) atomicAdd(a.route_counts + 0, live - six);
+        if (six) atomicAdd(a.route_counts + 1, six);
+        atomicAdd(a.route_counts + 4, live);
+      } else {
+        atomicAdd(a.route_counts + (P == 5 ? 0 : 1), live);
+      }
+    }
+    if (runs == 2) mask_and = 0x07070707u;
   }
   unsigned executed = 0;
   const int lane = threadIdx.x & 63;
@@ -1173,11 +1206,11 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
       const SyrkProblem& pr = a.prob[code >> CODE_PROB];   // (uniform index into the kernel arguments: scalar loads)
       const int bi = (code >> CODE_BI) & ((1 << CODE_BI) - 1), bj = code & ((1 << CODE_BI) - 1);
       if (chunk == 0) {   // per-head statistics: the tile's columns start at the head's first feature
-        i8_syrk_tile<P>(a, pr, bi, bj, 0, a.nk, pr.sigma, pr.ld_sigma, 0, pr.block ? bi * TI : 0, lds, executed);
+        i8_syrk_tile<P>(a, pr, bi, bj, 0, a.nk, pr.sigma, pr.ld_sigma, 0, pr.block ? bi * TI : 0, lds, executed, mask_and);
       } else {   // the last round: k-chunk q of Q of this tile, folded into its own (zeroed) partial tile
         const int q = chunk & 31, Q = (chunk >> 5) & 31, pslot = chunk >> 10;
         const int kb = (int)((int64_t)a.nk * q / Q), ke = (int)((int64_t)a.nk * (q + 1) / Q);
-        if (kb < ke) i8_syrk_tile<P>(a, pr, bi, bj, kb, ke, a.partial + (int64_t)pslot * TI * TJ, TJ, bi * TI, bj * TJ, lds, executed);
+        if (kb < ke) i8_syrk_tile<P>(a, pr, bi, bj, kb, ke, a.partial + (int64_t)pslot * TI * TJ, TJ, bi * TI, bj * TJ, lds, executed, mask_and);
       }
     };
     // The schedule's groups are QUEUES, one per XCD (XCD x owns groups x, x + 8, ...): a workgroup pulls the next tile of its
@@ -1228,7 +1261,7 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
       bj = SJ * C + t_in % SJ;
     }
     if (bi >= a.prob[0].n / TI || bj * TJ > bi * TI + TI - 1) return;   // (one full-triangle statistic per launch on this path)
-    i8_syrk_tile<P>(a, a.prob[0], bi, bj, 0, a.nk, a.prob[0].sigma, a.prob[0].ld_sigma, 0, 0, lds, executed);
+    i8_syrk_tile<P>(a, a.prob[0], bi, bj, 0, a.nk, a.prob[0].sigma, a.prob[0].ld_sigma, 0, 0, lds, executed, mask_and);
   }
   if (a.mfma_count && lane == 0) atomicAdd(a.mfma_count, (unsigned long long)executed);
 #ifdef MDG_I8_WGTIMES
@@ -1247,7 +1280,7 @@ __global__ __launch_bounds__(256) void i8_tail_combine_kernel(SyrkArgs a, int n_
   constexpr int TJ = wide_tile(P) ? 128 : 64;
   constexpr int PARTS = TI * TJ / COMBINE_ELEMS;
   int live, fallbacks;
-  if (launch_route(a, live, fallbacks) != (P == 5 ? 0 : 1)) return;     // the product launch of the other route produced the partials, or none did
+  if (!product_launch_runs<P>(a, live, fallbacks)) return;     // the product launch of the other route produced the partials, or none did
   const int4 t = a.tail[blockIdx.x / PARTS];
   if (a.route_flag[t.x >> CODE_PROB] & 2) return;
   const SyrkProblem& pr = a.prob[t.x >> CODE_PROB];
@@ -1374,6 +1407,205 @@ __global__ __launch_bounds__(256) void i8_columns_reduce_kernel(ColArgs a, const
   for (int q = 0; q < COLK_CHUNKS; q++) v += a.part[((int64_t)k * COLK_CHUNKS + q) * a.n + c];   // chunk order: reproducible
   const int row = max(c, j), col = min(c, j);
   sigma[(int64_t)row * ld_sigma + col - (block ? row / block * block : 0)] += v;
+}
+
+
+// ---- the exact route: no plane pair is dropped.
+// An element's 48-bit integer N splits into its top three balanced digits and the rest, N = N_d + L with N_d = d_0 2^40 + d_1 2^32 +
+// d_2 2^24 and L = d_3 2^16 + d_4 2^8 + d_5 in [-8421504, 8355711]; X = X_d + X_lo accordingly.  On real activations L is zero for
+// almost every element: planes 3 .. 5 are reached only by elements 17 binades and more below their column's maximum -- 3e-5 of a
+// Gaussian column, 0.5 % of a SiLU-gated one (whose 1 KB pieces of plane 3 nevertheless hold a nonzero 95 % of the time, which is why
+// the truncated six-plane product spends 6 of its 15 plane pairs multiplying a 99.5 %-zero operand).  So
+//     X^T X = X_d^T X_d  +  X_lo^T X  +  X_d^T X_lo
+//   * X_d^T X_d: the NINE plane pairs of the top three planes, all of them (classes 0 .. 4) -- the five-plane product kernel with the
+//     planes below masked off (mask_and in i8_syrk_tile): exact int32 class sums as before, 9 instead of 9.4 / 15.1 executed pairs;
+//   * the two remainder products: every element with L != 0 is an EVENT (token, column, L), listed per 32-column group in token
+//     order by i8_extract_lo_kernel; i8_lo_product_kernel walks the lists of an output tile's row block (sigma[r][c] += x_lo(t, r)
+//     x(t, c), the partner x in full) and of its column block (+= x_d(t, r) x_lo(t, c), the partner's top three planes recomputed
+//     from x: x_d = 2^24 q floor(x / (2^24 q) + 8421504 / 2^24), the balanced digits' rounding), fp64 products of exact operands
+//     summed into a 128 x 128 fp64 tile in LDS, each accumulator owned by ONE wave that adds its events in list order -- run-to-run
+//     bit-identical -- and folded into sigma once.
+// Nothing is truncated: what is left is fp64 rounding (one rounding per fold of the class sums and per event sum) and the rho term
+// of the elements more than 38 binades under their column maximum, which the split rounds to an integer (RouteOut::sq keeps it).
+// The route kernel's decisions stay as they are -- which columns leave for the fp64 column kernel, whether the whole statistic
+// does -- and the exact route then REPLACES the truncated five- or six-plane product whenever every remainder list fits its
+// segment (LO_CAP events per 32 columns x 2048 tokens = 3.1 % of the elements; cubed Gaussians, Student-t: no -- the truncated
+// product with its bound takes those as before).  Cost at the sigma_mlp shape: extraction 0.2 ms, remainder product ~0.3 ms
+// (Gaussian) ... ~5 ms (SiLU-gated) against 0.4 x 2.3 ... 6.1 x 2.35 ms of plane-pair products saved.
+constexpr int LO_CHUNK_STEPS = 64;       // k-steps (2048 tokens) per segment of a group's event list
+constexpr int LO_CAP = 2048;             // events per segment
+constexpr int LO_TILE = 128, LO_PITCH = LO_TILE + 1;
+constexpr double LO_ROUND = 8421504.0 / 16777216.0;   // (128 (1 + 256 + 65536)) / 2^24: where the balanced digits d_3 d_4 d_5 round
+constexpr int EXACT_OVERFLOW = 16, EXACT_RAN = 17;    // ints of the workspace's shared block
+
+struct LoProblem {
+  const bf16_t* x;
+  int64_t ld;
+  const signed char* planes;
+  const unsigned char* zmask;
+  const int* emax;
+  unsigned long long* entries;     // [n / 32][nch][LO_CAP]: token (28 bits) | column in its group (5 bits) << 28 | L (25 bits, signed: the
+                                   // balanced digits reach -8421504 < -2^23) << 39
+  int* counts;                     // [n / 32][nch]
+  double* sigma;
+  int64_t ld_sigma;
+  int n, block, tile0;             // tile0: this statistic's first workgroup of the remainder-product grid
+};
+struct LoArgs {
+  LoProblem prob[MAX_PROBLEMS];
+  int nprob, nk, nch, tiles;
+  const int* route_flag;
+  int* state;                      // shared block of the workspace: [EXACT_OVERFLOW], [EXACT_RAN]
+};
+
+// One wave per (32-column group, segment of LO_CHUNK_STEPS k-steps): reads the pieces of planes 3 .. 5 the piece masks say are
+// there -- as the product kernel would -- and compacts the nonzero L into the segment in (k-step, token-in-half, lane) order.
+__global__ __launch_bounds__(64) void i8_extract_lo_kernel(LoArgs a) {
+  const LoProblem& pr = a.prob[blockIdx.z];
+  const int64_t groups = pr.n / 32;
+  const int G = blockIdx.x, ch = blockIdx.y, lane = threadIdx.x;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0) a.state[EXACT_RAN] = 1;
+  if (G >= groups || (a.route_flag[blockIdx.z] & 2)) return;     // (a statistic that went to the fp64 kernel has no lists)
+  unsigned long long* out = pr.entries + ((int64_t)G * a.nch + ch) * LO_CAP;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const unsigned long long mine = ((unsigned long long)(lane & 31)) << 28;
+  int count = 0;
+  const int kt1 = min(a.nk, (ch + 1) * LO_CHUNK_STEPS);
+  for (int kt = ch * LO_CHUNK_STEPS; kt < kt1; kt++) {
+    const unsigned m = pr.zmask[(int64_t)kt * groups + G];
+    if ((m >> 3) == 0) continue;
+    const i32x4 zero = (i32x4)0;
+    const i32x4 d3 = *((const i32x4*)(pr.planes + ((3 * groups + G) * (int64_t)a.nk + kt) * 1024) + lane);
+    const i32x4 d4 = (m >> 4) ? *((const i32x4*)(pr.planes + ((4 * groups + G) * (int64_t)a.nk + kt) * 1024) + lane) : zero;
+    const i32x4 d5 = (m >> 5) ? *((const i32x4*)(pr.planes + ((5 * groups + G) * (int64_t)a.nk + kt) * 1024) + lane) : zero;
+    const unsigned tok0 = (unsigned)kt * KS + (lane >> 5) * 16;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const int sh = 8 * (q & 3);
+      const int L = (int)(signed char)((unsigned)d3[q >> 2] >> sh) * 65536 + (int)(signed char)((unsigned)d4[q >> 2] >> sh) * 256 +
+                    (int)(signed char)((unsigned)d5[q >> 2] >> sh);
+      const unsigned long long b = __ballot(L != 0);
+      if (b == 0) continue;
+      if (L != 0) {
+        const int at = count + __builtin_popcountll(b & below);
+        if (at < LO_CAP) out[at] = (unsigned long long)(tok0 + q) | mine | ((unsigned long long)((unsigned)L & 0x1FFFFFFu) << 39);
+      }
+      count += __builtin_popcountll(b);
+    }
+  }
+  if (lane == 0) {
+    pr.counts[(int64_t)G * a.nch + ch] = min(count, LO_CAP);
+    if (count > LO_CAP) a.state[EXACT_OVERFLOW] = 1;
+  }
+}
+
+__device__ __forceinline__ void lds_add_f64(double* p, double v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_f64, returnless: issued in order per wave
+}
+
+// The events of one 32-column group, in list order, by ONE wave.  COLS = false: the group is row group `wave` of the tile's row
+// block -- acc[wave * 32 + r][c] += x_lo(t, r) x(t, c) for the 128 columns c of the tile's column block (lane: c and c + 64);
+// COLS = true: the group is column group `wave` of the column block -- acc[r][wave * 32 + c] += x_d(t, r) x_lo(t, c) for the 128
+// rows r of the row block (lane: r and r + 64).  partner0: first column of the partner block.
+template <bool COLS>
+__device__ __forceinline__ void lo_events(const LoProblem& pr, const int nch, const int G, const int partner0, const int wave,
+                                          const int lane, double* acc) {
+  const int e_mine = pr.emax[G * 32 + (lane & 31)] & 255;           // lane r: the exponent of the group's column r
+  const unsigned short* xs = (const unsigned short*)pr.x;
+  double qa = 1., qb = 1., ia = 1., ib = 1.;
+  if (COLS) {   // the partner rows' digit grid: 2^24 units of their own scale
+    qa = ldexp(1.0, (pr.emax[partner0 + lane] & 255) - 148);
+    qb = ldexp(1.0, (pr.emax[partner0 + 64 + lane] & 255) - 148);
+    ia = 1.0 / qa;
+    ib = 1.0 / qb;
+  }
+  constexpr int UN = 4;     // events whose partner loads are in flight together
+  for (int ch = 0; ch < nch; ch++) {
+    const int cnt = pr.counts[(int64_t)G * nch + ch];
+    const unsigned long long* list = pr.entries + ((int64_t)G * nch + ch) * LO_CAP;
+    for (int e0 = 0; e0 < cnt; e0 += 64) {
+      const unsigned long long ent = e0 + lane < cnt ? list[e0 + lane] : 0ull;
+      const int lim = min(64, cnt - e0);
+      for (int eb = 0; eb < lim; eb += UN) {
+        unsigned tok[UN];
+        int col[UN], L[UN];
+        unsigned short va[UN], vb[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+          const int e = min(eb + u, lim - 1);
+          const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)ent, e);
+          const int hi = __builtin_amdgcn_readlane((int)(unsigned)(ent >> 32), e);
+          tok[u] = lo & 0x0FFFFFFFu;
+          col[u] = (int)((lo >> 28) | (((unsigned)hi & 1u) << 4));
+          L[u] = eb + u < lim ? hi >> 7 : 0;                          // (a padding slot adds exact zeros)
+          const unsigned short* row = xs + (int64_t)tok[u] * pr.ld + partner0 + lane;
+          va[u] = row[0];
+          vb[u] = row[64];
+        }
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+          if (L[u] == 0) continue;
+          const int e_col = __builtin_amdgcn_readlane(e_mine, col[u]);
+          const double v = ldexp((double)L[u], e_col - 172);          // x_lo(t, col): exact
+          double pa = (double)__uint_as_float((unsigned)va[u] << 16), pb = (double)__uint_as_float((unsigned)vb[u] << 16);
+          if (COLS) {
+            pa = floor(pa * ia + LO_ROUND) * qa;                       // x_d of the partner rows: exact (powers of two, one floor)
+            pb = floor(pb * ib + LO_ROUND) * qb;
+            lds_add_f64(acc + lane * LO_PITCH + wave * 32 + col[u], v * pa);
+            lds_add_f64(acc + (lane + 64) * LO_PITCH + wave * 32 + col[u], v * pb);
+          } else {
+            lds_add_f64(acc + (wave * 32 + col[u]) * LO_PITCH + lane, v * pa);
+            lds_add_f64(acc + (wave * 32 + col[u]) * LO_PITCH + 64 + lane, v * pb);
+          }
+        }
+      }
+    }
+  }
+}
+
+// One workgroup of four waves per 128 x 128 tile of the lower triangle (per-head statistics: the diagonal tiles).
+__global__ __launch_bounds__(256) void i8_lo_product_kernel(LoArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double lo_acc[];     // [128][LO_PITCH]
+  if (a.state[EXACT_RAN] != 1 || a.state[EXACT_OVERFLOW] != 0) return;
+  int p = 0;
+  while (p + 1 < a.nprob && (int)blockIdx.x >= a.prob[p + 1].tile0) p++;
+  if (a.route_flag[p] & 2) return;
+  const LoProblem& pr = a.prob[p];
+  const int t = blockIdx.x - pr.tile0;
+  int bi, bj;
+  if (pr.block) {
+    bi = bj = t;
+  } else {
+    bi = (int)((sqrtf(8.f * t + 1.f) - 1.f) * 0.5f);
+    while ((bi + 1) * (bi + 2) / 2 <= t) bi++;
+    while (bi * (bi + 1) / 2 > t) bi--;
+    bj = t - bi * (bi + 1) / 2;
+  }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // anything to do?  (the lists of the tile's four row groups and four column groups)
+  int any = 0;
+  for (int i = tid; i < 8 * a.nch; i += 256) {
+    const int g = i / a.nch, ch = i % a.nch;
+    const int G = (g < 4 ? 4 * bi + g : 4 * bj + g - 4);
+    any |= pr.counts[(int64_t)G * a.nch + ch];
+  }
+  if (!__syncthreads_or(any)) return;
+  for (int i = tid; i < LO_TILE * LO_PITCH; i += 256) lo_acc[i] = 0.;
+  __syncthreads();
+  lo_events<false>(pr, a.nch, 4 * bi + wave, bj * LO_TILE, wave, lane, lo_acc);
+  __syncthreads();      // an accumulator changes owner between the two passes: row group's wave, then column group's wave
+  lo_events<true>(pr, a.nch, 4 * bj + wave, bi * LO_TILE, wave, lane, lo_acc);
+  __syncthreads();
+  for (int i = tid; i < LO_TILE * LO_TILE; i += 256) {
+    const int r = i / LO_TILE, c = i % LO_TILE;
+    const int row = bi * LO_TILE + r, col = bj * LO_TILE + c;
+    const double v = lo_acc[r * LO_PITCH + c];
+    if (col > row || v == 0.) continue;
+    if ((pr.emax[row] | pr.emax[col]) & EMAX_COLUMN_OUT) continue;    // rows / columns of the fp64 column kernel: not ours
+    double* s = pr.sigma + (int64_t)row * pr.ld_sigma + col - (pr.block ? row / pr.block * pr.block : 0);
+    *s += v;
+  }
 }
 
 // column maxima (n ints, padded to 8 bytes) + the [NSTAT][n] route statistics + the route kernel's ticket: zeroed together per call
@@ -1514,8 +1746,9 @@ const Schedule* schedule_for(const std::vector<std::pair<int, int>>& shapes, int
 // then the fp64 fallback's split-K space.
 constexpr size_t SHARED_BYTES = 256;
 struct ProblemWs {
-  size_t planes, ints, vals, route, colpart, zmask;   // byte offsets
+  size_t planes, ints, vals, route, colpart, zmask, lo_entries, lo_counts;   // byte offsets
 };
+int lo_chunks(int64_t T) { return (int)ceil_div(ceil_div(T, (int64_t)KS), (int64_t)LO_CHUNK_STEPS); }
 size_t layout(int count, const mdg_cov_problem* pr, ProblemWs* out, size_t* fallback_off) {
   size_t off = SHARED_BYTES + PARTIAL_BYTES, fb = 0;
   for (int i = 0; i < count; i++) {
@@ -1533,6 +1766,10 @@ size_t layout(int count, const mdg_cov_problem* pr, ProblemWs* out, size_t* fall
     off += align_up((size_t)ROUTE_JMAX * COLK_CHUNKS * (size_t)cols * sizeof(double), 256);
     w.zmask = off;
     off += zmask_bytes(pr[i].n_tokens, cols);
+    w.lo_entries = off = align_up(off, 256);     // the exact route's event lists: [cols / 32][chunks][LO_CAP] x 8 bytes, then the counts
+    off += (size_t)(cols / 32) * lo_chunks(pr[i].n_tokens) * LO_CAP * sizeof(unsigned long long);
+    w.lo_counts = off;
+    off += align_up((size_t)(cols / 32) * lo_chunks(pr[i].n_tokens) * sizeof(int), 256);
     if (out) out[i] = w;
     fb = std::max(fb, mdg_cov_accum_ws_bytes(pr[i].n_tokens, pr[i].n_feat, pr[i].batch));
   }
@@ -1579,12 +1816,14 @@ extern "C" size_t mdg_cov_accum_i8_multi_ws_bytes(int count, const mdg_cov_probl
   return layout(count, problems, nullptr, nullptr);
 }
 
-extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems, void* ws, size_t ws_bytes, double tolerance,
+extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems, void* ws, size_t ws_bytes, double tolerance, int flags,
                                       int* used_i8, int* route_counts, void* ev_start, void* ev_stop, void* stream) {
   MDG_CLEAR();
   if (used_i8) *used_i8 = 0;
   MDG_CHECK_ARG(tolerance >= 1.0 && tolerance <= 1e6, "mdg_cov_accum_i8_multi: tolerance factor %g outside [1, 1e6] (1 = guaranteed <= 1.1e-11)",
                 tolerance);
+  MDG_CHECK_ARG((flags & ~MDG_I8_NO_EXACT) == 0, "mdg_cov_accum_i8_multi: unknown flags 0x%x", flags);
+  const bool offer_exact = !(flags & MDG_I8_NO_EXACT);
   MDG_CHECK_ARG(problems_ok(count, problems),
                 "mdg_cov_accum_i8_multi: 1..%d statistics of the same token count; full ones need n_feat %% 128 == 0, per-head ones "
                 "head_dim 128 with contiguous [heads][128][128] sigma; leading dimensions at least the widths (use mdg_cov_accum)",
@@ -1650,6 +1889,38 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
   a.mfma_count = mfma_count;
   a.route_flag = pflag; a.route_counts = route_counts;
   a.xcd_arrive = flag + 4;
+  // the exact route: the remainder lists of every statistic (planes 3 .. 5, after the route's columns were cleared); the product
+  // launches below then read the outcome -- {overflow, ran} -- from the shared block
+  LoArgs lo;
+  a.exact_state = nullptr;
+  if (offer_exact) {
+    lo.nprob = count;
+    lo.nk = nk;
+    lo.nch = lo_chunks(n_tokens);
+    lo.route_flag = pflag;
+    lo.state = flag;
+    int tiles = 0, max_groups = 0;
+    for (int i = 0; i < count; i++) {
+      const mdg_cov_problem& q = problems[i];
+      const int n = (int)(q.n_feat * q.batch);
+      LoProblem& l = lo.prob[i];
+      l.x = (const bf16_t*)q.x; l.ld = q.ld;
+      l.planes = a.prob[i].planes; l.zmask = a.prob[i].zmask; l.emax = a.prob[i].emax;
+      l.entries = (unsigned long long*)((char*)ws + pw[i].lo_entries);
+      l.counts = (int*)((char*)ws + pw[i].lo_counts);
+      l.sigma = q.sigma; l.ld_sigma = q.ld_sigma;
+      l.n = n; l.block = q.batch > 1 ? TI : 0;
+      l.tile0 = tiles;
+      const int rbi = n / TI;
+      tiles += q.batch > 1 ? rbi : rbi * (rbi + 1) / 2;
+      max_groups = std::max(max_groups, n / 32);
+    }
+    for (int i = count; i < MAX_PROBLEMS; i++) lo.prob[i] = lo.prob[0];
+    lo.tiles = tiles;
+    hipLaunchKernelGGL(i8_extract_lo_kernel, dim3((unsigned)max_groups, (unsigned)lo.nch, (unsigned)count), dim3(64), 0, st, lo);
+    MDG_LAUNCH_CHECK();
+    a.exact_state = flag + EXACT_OVERFLOW;
+  }
 #ifdef MDG_I8_STAMPS
   static unsigned long long* stamps_dev = nullptr;
   const size_t stamps_n = (size_t)STAMP_WGS * NW * 8;
@@ -1715,6 +1986,12 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
     MDG_LAUNCH_CHECK();
   }
   if (ev_stop) MDG_HIP(hipEventRecord((hipEvent_t)ev_stop, st));
+  if (offer_exact) {   // the remainder products of the exact route (every workgroup exits at once when the truncated product ran instead)
+    const size_t lds = (size_t)LO_TILE * LO_PITCH * sizeof(double);
+    MDG_HIP(hipFuncSetAttribute((const void*)i8_lo_product_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(i8_lo_product_kernel, dim3((unsigned)lo.tiles), dim3(256), lds, st, lo);
+    MDG_LAUNCH_CHECK();
+  }
   // the columns the route took off the int8 path: their rows / columns of sigma from the fp64 column kernel (both launches exit at
   // once when there are none)
   for (int i = 0; i < count; i++) {
@@ -1818,7 +2095,7 @@ extern "C" size_t mdg_cov_accum_i8_ws_bytes(int64_t n_tokens, int64_t n_feat) {
 }
 
 extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat, int64_t ld, double* sigma, int64_t ld_sigma,
-                                void* ws, size_t ws_bytes, double tolerance, int* used_i8, int* route_counts, void* ev_start,
+                                void* ws, size_t ws_bytes, double tolerance, int flags, int* used_i8, int* route_counts, void* ev_start,
                                 void* ev_stop, void* stream) {
   MDG_CLEAR();
   if (used_i8) *used_i8 = 0;
@@ -1827,26 +2104,30 @@ extern "C" int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat,
   MDG_CHECK_ARG(n_feat % TI == 0, "mdg_cov_accum_i8: n_feat=%lld must be a multiple of %d (use mdg_cov_accum)",
                 (long long)n_feat, TI);
   const mdg_cov_problem q = single_problem(x, n_tokens, n_feat, ld, sigma, ld_sigma);
-  return mdg_cov_accum_i8_multi(1, &q, ws, ws_bytes, tolerance, used_i8, route_counts, ev_start, ev_stop, stream);
+  return mdg_cov_accum_i8_multi(1, &q, ws, ws_bytes, tolerance, flags, used_i8, route_counts, ev_start, ev_stop, stream);
 }
 
 extern "C" int mdg_cov_accum_i8_route(int count, const mdg_cov_problem* problems, int stat, const void* ws, int* planes, int* n_columns,
-                                      int* columns, double* bound, void* stream) {
+                                      int* columns, double* bound, int* exact, void* stream) {
   MDG_CLEAR();
   MDG_CHECK_ARG(problems_ok(count, problems) && stat >= 0 && stat < count && ws, "mdg_cov_accum_i8_route: bad arguments");
   ProblemWs pw[MAX_PROBLEMS];
   layout(count, problems, pw, nullptr);
   RouteOut r;
+  int state[2] = {0, 0};
   hipStream_t st = (hipStream_t)stream;
   MDG_HIP(hipMemcpyAsync(&r, (const char*)ws + pw[stat].route, sizeof(r), hipMemcpyDeviceToHost, st));
+  MDG_HIP(hipMemcpyAsync(state, (const int*)ws + EXACT_OVERFLOW, sizeof(state), hipMemcpyDeviceToHost, st));
   MDG_HIP(hipStreamSynchronize(st));
+  const bool was_exact = r.planes != 0 && state[1] == 1 && state[0] == 0;
+  if (exact) *exact = was_exact ? 1 : 0;
   if (planes) *planes = r.planes;
   if (n_columns) *n_columns = r.n_out;
   if (columns)
     for (int i = 0; i < MDG_I8_MAX_COLUMNS; i++) columns[i] = i < r.n_out ? r.out[i] : -1;
-  if (bound) {
-    bound[0] = r.sq;
-    bound[1] = r.x;
+  if (bound) {   // the exact route drops no plane pair: the rounded-element term and fp64 rounding are what is left
+    bound[0] = was_exact ? r.rho + MDG_I8_EXACT_ROUNDING : r.sq;
+    bound[1] = was_exact ? 0.0 : r.x;
   }
   return MDG_OK;
 }

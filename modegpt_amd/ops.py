@@ -117,7 +117,8 @@ def cov_accum_i8(sigma: torch.Tensor, x: torch.Tensor, events=None, mfma_stats: 
     report=False (the hooks: cov_accum_multi) only enqueues and returns None -- the per-device counters behind
     i8_route_counts() are updated by the kernels themselves in both modes.  Feature count must be a multiple of 128.
     route_info: optional dict, filled with {"planes", "columns" (those the fp64 column kernel computed), "sq", "x" (the two parts
-    of the bound for the columns that stayed), "bound" (their sum)} -- implies report.
+    of the bound for the columns that stayed), "bound" (their sum), "exact" (the call ran the exact route: no plane pair dropped,
+    the bound is the rounded-element term + fp64 rounding)} -- implies report.
     events: optional pair of torch.cuda.Event(enable_timing=True), each recorded once already, re-recorded around the product
     launches alone.  mfma_stats: optional dict; its "executed" entry is increased by the number of v_mfma instructions the
     product kernel issued (it skips digit planes that are all-zero over a tile panel) and "dense" by what a kernel without
@@ -140,18 +141,23 @@ def cov_accum_i8(sigma: torch.Tensor, x: torch.Tensor, events=None, mfma_stats: 
     used = C.c_int(0)
     with torch.cuda.device(x.device):
         check(lib.mdg_cov_accum_i8(x2.data_ptr(), x2.shape[0], n, x2.stride(0), sigma.data_ptr(), sigma.stride(0), wsp, nbytes,
-                                   i8_tolerance() if tolerance is None else float(tolerance), C.byref(used) if report else None, _route_counters(x.device).data_ptr(),
+                                   i8_tolerance() if tolerance is None else float(tolerance), _i8_flags(), C.byref(used) if report else None, _route_counters(x.device).data_ptr(),
                                    None if events is None else events[0].cuda_event,
                                    None if events is None else events[1].cuda_event, _stream(x)), "mdg_cov_accum_i8")
+        info = None
+        if route_info is not None or mfma_stats is not None:
+            arr = (_lib.CovProblem * 1)(_lib.CovProblem(x2.data_ptr(), x2.shape[0], n, 1, x2.stride(0), sigma.data_ptr(),
+                                                        sigma.stride(0), 0))
+            info = _read_route(lib, 1, arr, 0, wsp, _stream(x))
         if mfma_stats is not None and used.value in (5, 6):
             done = C.c_ulonglong(0)
             check(lib.mdg_cov_accum_i8_stats(wsp, x2.shape[0], n, C.byref(done), _stream(x)), "mdg_cov_accum_i8_stats")
+            ran = 5 if info["exact"] else used.value           # (the exact route runs the five-plane kernel, deeper planes masked off)
             mfma_stats["executed"] = mfma_stats.get("executed", 0) + done.value
-            mfma_stats["dense"] = mfma_stats.get("dense", 0) + i8_dense_mfma_count(x2.shape[0], n, used.value)
+            mfma_stats["dense"] = mfma_stats.get("dense", 0) + i8_dense_mfma_count(x2.shape[0], n, ran)
+            mfma_stats["planes_run"] = ran
         if route_info is not None:
-            arr = (_lib.CovProblem * 1)(_lib.CovProblem(x2.data_ptr(), x2.shape[0], n, 1, x2.stride(0), sigma.data_ptr(),
-                                                        sigma.stride(0), 0))
-            route_info.update(_read_route(lib, 1, arr, 0, wsp, _stream(x)))
+            route_info.update(info)
     if not report:
         return None
     I8_STATS[{5: "i8_5", 6: "i8_6"}.get(used.value, "fallback_f64")] += 1
@@ -159,13 +165,22 @@ def cov_accum_i8(sigma: torch.Tensor, x: torch.Tensor, events=None, mfma_stats: 
 
 
 def _read_route(lib, count, arr, stat, wsp, stream) -> dict:
-    planes, ncol = C.c_int(0), C.c_int(0)
+    planes, ncol, exact = C.c_int(0), C.c_int(0), C.c_int(0)
     cols = (C.c_int * 32)()
     bound = (C.c_double * 2)()
-    check(lib.mdg_cov_accum_i8_route(count, arr, stat, wsp, C.byref(planes), C.byref(ncol), cols, bound, stream),
+    check(lib.mdg_cov_accum_i8_route(count, arr, stat, wsp, C.byref(planes), C.byref(ncol), cols, bound, C.byref(exact), stream),
           "mdg_cov_accum_i8_route")
     return {"planes": planes.value, "columns": [cols[i] for i in range(ncol.value)], "sq": bound[0], "x": bound[1],
-            "bound": bound[0] + bound[1]}
+            "bound": bound[0] + bound[1], "exact": bool(exact.value)}
+
+
+# The exact route of the int8 covariance (include/modegpt_hip.h, "THE EXACT ROUTE"): on by default; MODEGPT_I8_EXACT=0 -- or
+# ops.I8_EXACT = False -- keeps every call on the truncated five- / six-plane product (MDG_I8_NO_EXACT).
+I8_EXACT = os.environ.get("MODEGPT_I8_EXACT", "1") != "0"
+
+
+def _i8_flags() -> int:
+    return 0 if I8_EXACT else _lib.MDG_I8_NO_EXACT
 
 
 def cov_accum_i8_multi(items, events=None, mfma_stats: Optional[dict] = None, report: bool = False,
@@ -208,17 +223,22 @@ def cov_accum_i8_multi(items, events=None, mfma_stats: Optional[dict] = None, re
     used = C.c_int(0)
     with torch.cuda.device(dev):
         check(lib.mdg_cov_accum_i8_multi(len(items), arr, wsp, nbytes, i8_tolerance() if tolerance is None else float(tolerance),
-                                         C.byref(used) if report else None,
+                                         _i8_flags(), C.byref(used) if report else None,
                                          _route_counters(dev).data_ptr(), None if events is None else events[0].cuda_event,
                                          None if events is None else events[1].cuda_event, _stream(keep[0])),
               "mdg_cov_accum_i8_multi")
+        infos = None
+        if route_info is not None or mfma_stats is not None:
+            infos = [_read_route(lib, len(items), arr, i, wsp, _stream(keep[0])) for i in range(len(items))]
         if mfma_stats is not None and used.value in (5, 6):
             done = C.c_ulonglong(0)
             check(lib.mdg_cov_accum_i8_stats(wsp, 0, 0, C.byref(done), _stream(keep[0])), "mdg_cov_accum_i8_stats")
+            ran = 5 if any(i_["exact"] for i_ in infos) else used.value
             mfma_stats["executed"] = mfma_stats.get("executed", 0) + done.value
-            mfma_stats["dense"] = mfma_stats.get("dense", 0) + sum(i8_dense_mfma_count(t, f, used.value, h) for t, f, h in dense_shapes)
+            mfma_stats["dense"] = mfma_stats.get("dense", 0) + sum(i8_dense_mfma_count(t, f, ran, h) for t, f, h in dense_shapes)
+            mfma_stats["planes_run"] = ran
         if route_info is not None:
-            route_info.extend(_read_route(lib, len(items), arr, i, wsp, _stream(keep[0])) for i in range(len(items)))
+            route_info.extend(infos)
     if not report:
         return None
     I8_STATS[{5: "i8_5", 6: "i8_6"}.get(used.value, "fallback_f64")] += len(items)
@@ -229,12 +249,12 @@ _ROUTE_COUNTERS = {}
 
 
 def _route_counters(device) -> torch.Tensor:
-    """Per-device int32[4] the kernels bump: [five planes, six planes, fp64 fallback of a whole statistic, columns handed to the
-    fp64 column kernel] (mdg_cov_accum_i8 route_counts)."""
+    """Per-device int32[5] the kernels bump: [five planes, six planes, fp64 fallback of a whole statistic, columns handed to the
+    fp64 column kernel, statistics on the exact route] (mdg_cov_accum_i8 route_counts)."""
     dev = torch.device(device)
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     if key not in _ROUTE_COUNTERS:
-        _ROUTE_COUNTERS[key] = torch.zeros(4, dtype=torch.int32, device=torch.device("cuda", key))
+        _ROUTE_COUNTERS[key] = torch.zeros(5, dtype=torch.int32, device=torch.device("cuda", key))
     return _ROUTE_COUNTERS[key]
 
 
@@ -285,14 +305,16 @@ def i8_tolerance_scope(factor: float):
 
 def i8_route_counts(device=None, reset: bool = False) -> dict:
     """How the int8-route requests on `device` (default: the current one) were served so far, counted on the device by the
-    kernels that ran: {"i8_5", "i8_6", "fallback_f64"} count statistics, "fp64_columns" the single columns the route handed to
-    the fp64 column kernel.  One small device -> host copy; calibration reads it once, at the end."""
+    kernels that ran: {"i8_5", "i8_6", "fallback_f64"} count statistics (by the class the route kernel gave them), "fp64_columns"
+    the single columns the route handed to the fp64 column kernel, "exact" how many of the i8_5 / i8_6 statistics ran the exact
+    route (nine plane pairs + the fp64 remainder products) instead of the truncated product.  One small device -> host copy;
+    calibration reads it once, at the end."""
     key = torch.cuda.current_device() if device is None else (torch.device(device).index or 0)
     t = _route_counters(torch.device("cuda", key))
     v = t.cpu().tolist()
     if reset:
         t.zero_()
-    return {"i8_5": v[0], "i8_6": v[1], "fallback_f64": v[2], "fp64_columns": v[3]}
+    return {"i8_5": v[0], "i8_6": v[1], "fallback_f64": v[2], "fp64_columns": v[3], "exact": v[4]}
 
 
 def i8_dense_mfma_count(n_tokens: int, n: int, planes: int, n_heads: int = 1) -> int:

@@ -16,7 +16,12 @@ TYPICAL -- an EMPIRICAL figure: <= 1e-12 (times the factor) on the distribution 
 """
 GUARANTEED = 1.1e-11
 TYPICAL = 1e-12
-ROUNDING = 1e-15   # fp64 rounding of the reference sum the error is measured against
+# What the REFERENCE contributes to a measured difference: the fp64 sums these tests compare with (torch's CPU matmul in the oracle,
+# the v_mfma_f64 kernel) round at every addition -- 4e-14 .. 2e-13 of sqrt(sigma_ii sigma_jj) at the sizes used here -- while a call
+# on the exact route (integer class sums + a handful of fp64 additions) is closer to the true sum than they are, and its own bound
+# (the rounded-element term + 5e-15) lies far below that.  The hard assertion therefore allows the reference its rounding; the
+# exact route's own accuracy is pinned against an EXACT integer reference in test_exact_route_against_exact_integer_arithmetic.
+REFERENCE_ROUNDING = 3e-13
 
 # the families of scripts/probes/i8_fuzz.py (kinds 0-8), the bench generator, and the shapes of the full-width tests
 MEASURED_FAMILIES = {
@@ -39,7 +44,7 @@ def check_i8_error(err, bound=None, family=None, tolerance=1.0, ctx=None):
     when the test did not read it back.  family: one of MEASURED_FAMILIES to ALSO assert the empirical 1e-12 figure."""
     limit = GUARANTEED * tolerance if bound is None else bound
     assert limit <= GUARANTEED * tolerance * (1 + 1e-12), ("the call's own bound exceeds the guarantee", bound, tolerance, ctx)
-    assert err <= limit + ROUNDING, ("GUARANTEED part violated: error above the call's bound", err, bound, tolerance, ctx)
+    assert err <= limit + REFERENCE_ROUNDING, ("GUARANTEED part violated: error above the call's bound", err, bound, tolerance, ctx)
     if family is not None:
         assert family in MEASURED_FAMILIES, family
         assert err < TYPICAL * tolerance, (f"EMPIRICAL figure exceeded on family {family!r} (typical <= {TYPICAL * tolerance:g}; "

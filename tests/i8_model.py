@@ -158,16 +158,49 @@ def product(d, E, P):
     return acc * sc[:, None] * sc[None, :]
 
 
-def route_of(X, chunk=1024, tolerance=1.0):
+LO_CHUNK_TOKENS, LO_CAP, EXACT_ROUNDING = 64 * 32, 2048, 5e-15      # cov_i8.hip: LO_CHUNK_STEPS x KS, LO_CAP; modegpt_hip.h: MDG_I8_EXACT_ROUNDING
+
+
+def remainder_counts(d):
+    """[T / 2048 segments, n / 32 groups]: elements with a nonzero digit in planes 3 .. 5 (L != 0) per (2048-token segment, 32-column
+    group) -- the event lists of the exact route (i8_extract_lo_kernel)."""
+    lo = (d[3] != 0) | (d[4] != 0) | (d[5] != 0)
+    T, n = lo.shape
+    pad = (-T) % LO_CHUNK_TOKENS
+    if pad:
+        lo = np.concatenate([lo, np.zeros((pad, n), bool)])
+    return lo.reshape(-1, LO_CHUNK_TOKENS, n // 32, 32).sum(axis=(1, 3))
+
+
+def route_of(X, chunk=1024, tolerance=1.0, offer_exact=True):
     """Route of a whole bf16 activation matrix (torch CPU tensor [T, n]): the statistics are taken in column chunks (int64
     temporaries of a 32768 x 14336 batch would not fit), the decision over all columns.  -> dict like ops.cov_accum_i8's
-    route_info: planes, columns (in the order the greedy took them), sq, x, bound."""
-    qs, rs, ns = [], [], []
+    route_info: planes, columns (in the order the greedy took them), sq, x, bound, exact.  exact (the exact route: nine plane
+    pairs + the fp64 remainder products, cov_i8.hip "the exact route"): the route kernel's decision stands, and when no event list
+    of the columns that stayed overflows its segment the truncated product is replaced -- the bound is then the rounded-element
+    term 2 R + R^2 plus fp64 rounding."""
+    qs, rs, ns, lo = [], [], [], []
     for c0 in range(0, X.shape[1], chunk):
         d, _, _, rounded, nnz = digits(X[:, c0:c0 + chunk].contiguous())
         st = column_stats(d, rounded, nnz)
         qs.append(st["q"]); rs.append(st["rounded"]); ns.append(st["nnz"])
+        lo.append((d[3] != 0) | (d[4] != 0) | (d[5] != 0))
     st = {"q": np.concatenate(qs, axis=1), "rounded": np.concatenate(rs), "nnz": np.concatenate(ns)}
     nz = st["nnz"][st["nnz"] > 0]
     planes, cols, (sq, x) = route(st, sort=False, tokens=min(X.shape[0], int(nz.min()) if nz.size else X.shape[0]), tolerance=tolerance)
-    return {"planes": planes, "columns": cols, "sq": sq, "x": x, "bound": sq + x, "stats": st}
+    exact = False
+    if planes and offer_exact and X.shape[1] % 32 == 0:
+        lo = np.concatenate(lo, axis=1)
+        lo[:, cols] = False                            # the digits of the columns that left are cleared before the lists are made
+        T, n = lo.shape
+        pad = (-T) % LO_CHUNK_TOKENS
+        if pad:
+            lo = np.concatenate([lo, np.zeros((pad, n), bool)])
+        exact = bool(lo.reshape(-1, LO_CHUNK_TOKENS, n // 32, 32).sum(axis=(1, 3)).max() <= LO_CAP)
+        if exact:
+            _, rho = alphas(st)
+            live = np.ones(n, bool)
+            live[cols] = False
+            R = float(rho[live].max()) if live.any() else 0.0
+            sq, x = 2.0 * R + R * R + EXACT_ROUNDING, 0.0
+    return {"planes": planes, "columns": cols, "sq": sq, "x": x, "bound": sq + x, "exact": exact, "stats": st}

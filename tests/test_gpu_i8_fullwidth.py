@@ -33,6 +33,16 @@ def ops(dev):
     return _ops
 
 
+@pytest.fixture(params=["exact", "truncated"])
+def i8_route(request, monkeypatch):
+    """Both products behind the int8 covariance: the exact route (the default: the top three digit planes' nine plane pairs + the fp64
+    remainder products, wherever the remainder lists fit -- they do on both data kinds here) and the truncated five- / six-plane
+    product with its bound (MDG_I8_NO_EXACT)."""
+    from modegpt_amd import ops as _ops
+    monkeypatch.setattr(_ops, "I8_EXACT", request.param == "exact")
+    return request.param
+
+
 def gaussian(dev, tokens, feat, seed):
     """bench.py's generator: z * c_j, c_j log-uniform[0.05, 2]."""
     g = torch.Generator(device=dev).manual_seed(seed)
@@ -93,13 +103,16 @@ def spot_and_trace(S, X, step):
 
 @pytest.mark.parametrize("kind,planes", [("gaussian", 5), ("silu_gated", 6)])
 @pytest.mark.parametrize("n", WIDTHS)
-def test_i8_route_at_product_widths(ops, dev, n, kind, planes):
+def test_i8_route_at_product_widths(ops, dev, n, kind, planes, i8_route):
     X = (gaussian if kind == "gaussian" else silu_gated)(dev, T_BATCH, n, 100 + n)
     S8 = torch.zeros(n, n, dtype=F64, device=dev)
     S64 = torch.zeros_like(S8)
     stats, info = {}, {}
     assert ops.cov_accum_i8(S8, X, mfma_stats=stats, route_info=info) == planes
     assert 0 < stats["executed"] <= stats["dense"]
+    assert info["exact"] == (i8_route == "exact"), info
+    if info["exact"]:    # the five-plane kernel on three dense planes: exactly 9 of its 15 plane pairs, whatever class the data has
+        assert stats["planes_run"] == 5 and stats["executed"] * 15 == stats["dense"] * 9 and info["bound"] < 1e-14, (stats, info)
     ops.cov_accum(S64, X)
     check_i8_error(entrywise_err(S8, S64), info["bound"], family=kind, ctx=(n, info))
     spot, trace = spot_and_trace(S8, X, n)
@@ -120,7 +133,7 @@ def test_i8_route_at_product_widths(ops, dev, n, kind, planes):
 
 
 @pytest.mark.parametrize("kind,planes", [("gaussian", 5), ("silu_gated", 6)])
-def test_i8_route_across_the_int32_fold_with_super_blocks(ops, dev, kind, planes):
+def test_i8_route_across_the_int32_fold_with_super_blocks(ops, dev, kind, planes, i8_route):
     """n = 4096 (32 row blocks -> 16 x 16 super-block rows on 8 XCDs) with 65504 + 4000 tokens: the int32 classes are folded
     into sigma once inside the launch and once at its end."""
     n, T = 4096, 65504 + 4000
@@ -163,7 +176,7 @@ def test_mlp_rank_selection_is_identical_on_both_routes(ops, dev, kind):
                                       (12416, 2100, "silu_gated"), (8192, 33, "gaussian"),
                                       (4096, 100, "gaussian"), (4096, 33, "silu_gated"), (2944, 5000, "gaussian"),
                                       (3328, 5 * 65504 + 3000, "gaussian"), (3712, 5 * 65504 + 3000, "silu_gated")])
-def test_persistent_launch_shapes(ops, dev, n, T, kind):
+def test_persistent_launch_shapes(ops, dev, n, T, kind, i8_route):
     """Statistics of 2048 features and more run as the persistent launch (one workgroup per CU working through static tile
     lists): the int32 fold boundary inside a tile list (65504 tokens), row-block counts that leave ragged groups along the
     diagonal (65 and 97 blocks), and a call shorter than the LDS ring is deep.  The tiles of the last, partly filled round are
@@ -223,7 +236,7 @@ def _check_against(S, R, bound=None, family="gaussian"):
     ([14336, 4096], [32, 8], 32768, "silu_gated", 6),
     ([3328], [3], 2 * 65504 + 100, "gaussian", 5),          # across two int32 folds
 ])
-def test_fused_int8_launch_of_a_layers_statistics(ops, dev, widths, heads, T, kind, planes):
+def test_fused_int8_launch_of_a_layers_statistics(ops, dev, widths, heads, T, kind, planes, i8_route):
     """mdg_cov_accum_i8_multi: sigma_mlp, sigma_x and the per-head sigma_q / sigma_k (head_dim 128: diagonal tiles only) of one
     batch in ONE persistent launch over a shared tile schedule, one route for all.  Every statistic against the v_mfma_f64
     kernel entry-wise (within its own bound), a second call doubling the result, and the device route counters advancing by the number of
@@ -239,7 +252,11 @@ def test_fused_int8_launch_of_a_layers_statistics(ops, dev, widths, heads, T, ki
     for (S, _, _), R, i_, f_ in zip(items, refs, info, fam):
         _check_against(S, 2 * R, i_["bound"], f_)
     counts = ops.i8_route_counts(dev, reset=True)
-    assert counts[{5: "i8_5", 6: "i8_6"}[planes]] == 2 * len(items) and counts["i8_5"] + counts["i8_6"] + counts["fallback_f64"] == 2 * len(items)
+    assert counts["i8_5"] + counts["i8_6"] + counts["fallback_f64"] == 2 * len(items) and counts["fallback_f64"] == 0
+    if i8_route == "truncated":     # one route for the launch: the deepest any statistic asks for
+        assert counts[{5: "i8_5", 6: "i8_6"}[planes]] == 2 * len(items) and counts["exact"] == 0
+    else:                           # the exact route serves both classes: every statistic is booked under its own
+        assert counts["exact"] == 2 * len(items) and all(i_["exact"] for i_ in info), (counts, info)
     assert counts["fp64_columns"] == 0 or T < 10240        # (short calls: the cross-term threshold is tighter, columns may leave)
 
 
@@ -261,7 +278,7 @@ def test_fused_int8_launch_lets_columns_and_statistics_leave_alone(ops, dev):
     info = []
     assert ops.cov_accum_i8_multi(items, report=True, route_info=info) == 5
     assert [i["columns"] for i in info] == [[], [17], [2 * 128 + 5]] and all(i["planes"] == 5 for i in info)
-    assert ops.i8_route_counts(dev, reset=True) == {"i8_5": 3, "i8_6": 0, "fallback_f64": 0, "fp64_columns": 2}
+    assert ops.i8_route_counts(dev, reset=True) == {"i8_5": 3, "i8_6": 0, "fallback_f64": 0, "fp64_columns": 2, "exact": 3}
     refs = []
     for S, X, nh in items:
         R = torch.zeros_like(S)
@@ -276,7 +293,7 @@ def test_fused_int8_launch_lets_columns_and_statistics_leave_alone(ops, dev):
     ops.cov_accum(Rh, Xh)
     mixed = [(torch.zeros(2048, 2048, dtype=F64, device=dev), Xa, 1), (torch.zeros(2048, 2048, dtype=F64, device=dev), Xh, 1)]
     assert ops.cov_accum_i8_multi(mixed, report=True) == 5
-    assert ops.i8_route_counts(dev, reset=True) == {"i8_5": 1, "i8_6": 0, "fallback_f64": 1, "fp64_columns": 0}
+    assert ops.i8_route_counts(dev, reset=True) == {"i8_5": 1, "i8_6": 0, "fallback_f64": 1, "fp64_columns": 0, "exact": 1}
     assert torch.equal(mixed[1][0], Rh)
     _check_against(mixed[0][0], refs[0])
     both = [(torch.zeros(2048, 2048, dtype=F64, device=dev), Xh, 1), (torch.zeros(2048, 2048, dtype=F64, device=dev), Xh, 1)]
@@ -344,7 +361,8 @@ def test_device_route_equals_the_host_model_at_sigma_x_width(ops, dev):
         info = {}
         ops.cov_accum_i8(S8, X, route_info=info)
         want = M.route_of(X.cpu())
-        assert (info["planes"], info["columns"]) == (want["planes"], want["columns"]), (kind, cols, info, want["planes"], want["columns"])
+        assert (info["planes"], info["columns"], info["exact"]) == (want["planes"], want["columns"], want["exact"]), \
+            (kind, cols, info, want["planes"], want["columns"], want["exact"])
         assert abs(info["sq"] - want["sq"]) <= 1e-9 * want["sq"] and abs(info["x"] - want["x"]) <= 1e-9 * want["x"]
         ops.cov_accum(S64, X)
         check_i8_error(entrywise_err(S8, S64), info["bound"], family="outliers" if cols else kind, ctx=(kind, cols, info))
@@ -367,7 +385,8 @@ def test_cov_accum_multi_routes_a_llama_layer(ops, dev, monkeypatch):
 
     fused, c1 = run(True)
     apart, c0 = run(False)
-    assert c1 == {"i8_5": 3, "i8_6": 1, "fallback_f64": 0, "fp64_columns": 0}   # sigma_mlp alone on six planes; x, q, k share a five-plane launch
-    assert c0 == {"i8_5": 1, "i8_6": 1, "fallback_f64": 0, "fp64_columns": 0}   # separate launches: sigma_mlp six planes, sigma_x five, heads fp64
+    # sigma_mlp alone (six-plane class); x, q, k share a launch (five-plane class); every int8 statistic on the exact route
+    assert c1 == {"i8_5": 3, "i8_6": 1, "fallback_f64": 0, "fp64_columns": 0, "exact": 4}
+    assert c0 == {"i8_5": 1, "i8_6": 1, "fallback_f64": 0, "fp64_columns": 0, "exact": 2}   # separate launches: sigma_mlp, sigma_x; heads fp64
     for i, (a, b) in enumerate(zip(fused, apart)):
         _check_against(a, b, None, "silu_gated" if i == 0 else "gaussian")

@@ -666,22 +666,35 @@ def entry_err(S, ref):
 
 def check_route(info, X, tolerance=1.0):
     """The device's route decision against the host model (tests/i8_model.py) on the same bf16 data: planes, the columns handed
-    to the fp64 column kernel IN THE ORDER the greedy took them, and both parts of the bound."""
+    to the fp64 column kernel IN THE ORDER the greedy took them, whether the exact route replaced the truncated product (every
+    remainder list fits), and both parts of the bound."""
+    from modegpt_amd import ops as _ops
     from tests import i8_model as M
-    want = M.route_of(X.cpu(), tolerance=tolerance)
-    assert (info["planes"], info["columns"]) == (want["planes"], want["columns"]), (info, {k: want[k] for k in ("planes", "columns", "sq", "x")})
+    want = M.route_of(X.cpu(), tolerance=tolerance, offer_exact=_ops.I8_EXACT)
+    assert (info["planes"], info["columns"], info["exact"]) == (want["planes"], want["columns"], want["exact"]), \
+        (info, {k: want[k] for k in ("planes", "columns", "sq", "x", "exact")})
     if want["planes"]:
         assert abs(info["sq"] - want["sq"]) <= 1e-9 * want["sq"] + 1e-300 and abs(info["x"] - want["x"]) <= 1e-9 * want["x"] + 1e-300
     return want
 
 
-def test_cov_i8_tolerance_is_an_argument_of_the_call(ops, dev):
+@pytest.fixture(params=["exact", "truncated"])
+def i8_route(request, monkeypatch):
+    """Both products behind the int8 covariance: the exact route (default: nine plane pairs + the fp64 remainder products wherever
+    the remainder lists fit) and the truncated five- / six-plane product with its bound (MDG_I8_NO_EXACT)."""
+    from modegpt_amd import ops as _ops
+    monkeypatch.setattr(_ops, "I8_EXACT", request.param == "exact")
+    return request.param
+
+
+def test_cov_i8_tolerance_is_an_argument_of_the_call(ops, dev, monkeypatch):
     """ABI 9: the route's tolerance factor travels with each call (mdg_cov_accum_i8's `tolerance`); the library keeps no accuracy
     state.  SiLU-gated columns need six planes at factor 1 and take five at 64 (fewer plane pairs, a looser but still COMPUTED and
     respected bound); the device's decision equals the host model's at that factor.  Two host threads with different factors, calling
     at the same time, each get the route of their OWN factor -- through the explicit argument and through the thread's default
     (ops.i8_tolerance_scope); the process default (ops.set_i8_tolerance) is Python-side only and untouched by either."""
     import threading
+    monkeypatch.setattr(ops, "I8_EXACT", False)       # (the truncated product: on the exact route the factor changes nothing but the class)
     gen = torch.Generator().manual_seed(31)
     T, n = 24576, 256
     X = (torch.nn.functional.silu(torch.randn(T, n, generator=gen)) * torch.randn(T, n, generator=gen)).to(torch.bfloat16)
@@ -741,12 +754,12 @@ def test_cov_i8_tolerance_is_an_argument_of_the_call(ops, dev):
         ws = torch.empty(lib.mdg_cov_accum_i8_ws_bytes(T, n), dtype=torch.uint8, device=dev)
         S = torch.zeros(n, n, dtype=F64, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(lib.mdg_cov_accum_i8(Xd.data_ptr(), T, n, n, S.data_ptr(), n, ws.data_ptr(), ws.numel(), 0.5, None, None, None, None,
+            _lib.check(lib.mdg_cov_accum_i8(Xd.data_ptr(), T, n, n, S.data_ptr(), n, ws.data_ptr(), ws.numel(), 0.5, 0, None, None, None, None,
                                             torch.cuda.current_stream(dev).cuda_stream), "mdg_cov_accum_i8")
 
 
 @pytest.mark.parametrize("tokens,feat", [(777, 256), (4096, 128), (33, 384), (20000, 256), (65504 + 3000, 128)])
-def test_cov_i8_matches_the_fp64_oracle(ops, dev, tokens, feat):
+def test_cov_i8_matches_the_fp64_oracle(ops, dev, tokens, feat, i8_route):
     """The int8 route (error-free split, truncated product) against the oracle's fp64 X^T X, entry-wise over sqrt(s_ii s_jj):
     below the bound the call itself computed (guaranteed) and below 1e-12 (the empirical figure of this family); the route equals the host model's; a second call accumulates;
     68504 tokens cross the int32 fold boundary (2047 k-steps = 65504 tokens, scripts/probes/i8_int32_bound.py)."""
@@ -765,7 +778,7 @@ def test_cov_i8_matches_the_fp64_oracle(ops, dev, tokens, feat):
     check_i8_error(entry_err(S, ref), family="gaussian")      # (two calls: each within its own bound of the accumulated diagonal)
 
 
-def test_cov_i8_agrees_with_the_fp64_kernel_and_is_deterministic(ops, dev):
+def test_cov_i8_agrees_with_the_fp64_kernel_and_is_deterministic(ops, dev, i8_route):
     gen = torch.Generator().manual_seed(5)
     X = acts(gen, 5000, 512).to(dev)
     S8 = torch.zeros(512, 512, dtype=F64, device=dev)
@@ -779,7 +792,7 @@ def test_cov_i8_agrees_with_the_fp64_kernel_and_is_deterministic(ops, dev):
     assert torch.equal(S8, S8.T)
 
 
-def test_cov_i8_hands_outlier_columns_to_the_fp64_column_kernel(ops, dev):
+def test_cov_i8_hands_outlier_columns_to_the_fp64_column_kernel(ops, dev, i8_route):
     """Columns whose bulk sits far below a few massive activations (the BOS-token dimensions of a Llama residual stream) leave
     the int8 path ALONE: the launch stays on five planes, the fold skips their rows and columns, and the fp64 column kernel
     computes those -- plain fp64 arithmetic, so they agree with the oracle to rounding."""
@@ -795,7 +808,8 @@ def test_cov_i8_hands_outlier_columns_to_the_fp64_column_kernel(ops, dev):
     assert ops.cov_accum_i8(S, X.to(dev), route_info=info) == 5
     assert sorted(info["columns"]) == [40, 131]
     check_route(info, X)
-    assert ops.i8_route_counts(dev, reset=True) == {"i8_5": 1, "i8_6": 0, "fallback_f64": 0, "fp64_columns": 2}
+    assert ops.i8_route_counts(dev, reset=True) == {"i8_5": 1, "i8_6": 0, "fallback_f64": 0, "fp64_columns": 2, "exact": int(i8_route == "exact")}
+    assert info["exact"] == (i8_route == "exact")       # (with the two columns gone the remainder lists are nearly empty)
     check_i8_error(entry_err(S, ref), info["bound"], family="outliers", ctx=info)
     low = torch.tril(S).cpu()
     full = low + torch.tril(low, -1).T
@@ -819,7 +833,7 @@ def test_cov_i8_hands_outlier_columns_to_the_fp64_column_kernel(ops, dev):
 
 
 @pytest.mark.parametrize("kind", ["silu_gated", "laplace", "relu", "cubed", "student_t"])
-def test_cov_i8_route_follows_the_error_bound(ops, dev, kind):
+def test_cov_i8_route_follows_the_error_bound(ops, dev, kind, i8_route):
     """The route is derived from the per-call bound (Cauchy-Schwarz on the plane energies): light tails -> five planes,
     SiLU-gated products (the MLP statistic of a real Llama) -> six, heavier tails -> columns leave for the fp64 column kernel
     or, when 32 are not enough, the whole statistic goes to the fp64 kernel.  Whatever is chosen must equal the host model's
@@ -838,6 +852,10 @@ def test_cov_i8_route_follows_the_error_bound(ops, dev, kind):
     want = check_route(info, X)
     assert planes == want["planes"]
     assert planes == {"silu_gated": 6, "relu": 5}.get(kind, planes)
+    if i8_route == "exact" and kind in ("silu_gated", "laplace", "relu"):
+        assert info["exact"] and info["bound"] < 1e-14, info        # sparse remainders: the exact route, nothing but rounding left
+    if i8_route == "truncated":
+        assert not info["exact"]
     err = entry_err(S, ref)
     if planes:
         check_i8_error(err, info["bound"], family={"relu": "one_signed"}.get(kind, kind), ctx=info)
@@ -951,6 +969,109 @@ def test_cov_i8_randomised_shapes_and_scales(ops, dev):
     assert routes & {5, 6}, routes
 
 
+def _exact_sigma(X):
+    """X^T X of a bf16 matrix in EXACT integer arithmetic (tests/i8_model.digits: x = N 2^(E - 172)): list of rows of Fractions."""
+    from fractions import Fraction
+    from tests import i8_model as M
+    d, E, N, rounded, _ = M.digits(X)
+    assert int(rounded.sum()) == 0                       # (no element more than 38 binades under its column maximum here)
+    hi, lo = N >> 24, N & 0xFFFFFF                       # N = hi 2^24 + lo: the three int64 products below cannot overflow
+    assert np.abs(hi).max() < 2 ** 24 and X.shape[0] < 4096
+    hh, hl, ll = hi.T @ hi, hi.T @ lo, lo.T @ lo
+    n = X.shape[1]
+    out = []
+    for i in range(n):
+        row = []
+        for j in range(n):
+            v = (int(hh[i, j]) << 48) + ((int(hl[i, j]) + int(hl[j, i])) << 24) + int(ll[i, j])
+            row.append(Fraction(v) * Fraction(2) ** int(E[i] + E[j] - 344))
+        out.append(row)
+    return out
+
+
+def test_exact_route_against_exact_integer_arithmetic(ops, dev, monkeypatch):
+    """The default product of the int8 covariance drops no plane pair (cov_i8.hip, "the exact route"): X^T X = X_d^T X_d (nine plane
+    pairs on the matrix cores) + X_lo^T X + X_d^T X_lo (fp64 sums over the listed remainder elements).  Checked against the EXACT
+    sum in integer arithmetic -- not against an fp64 reference, which is less accurate than the thing under test: SiLU-gated columns
+    with deep elements of both signs, elements whose low 24 bits are exactly the rounding tie of the balanced digits (and the value
+    next to it on both sides), a 900-token call and a 3000-token one accumulated on top.  Entry-wise error <= 5e-15 of
+    sqrt(sigma_ii sigma_jj) (MDG_I8_EXACT_ROUNDING; the truncated six-plane product is 6e-14 here, the fp64 kernel 1e-13); the
+    workspace is handed over poisoned, results are bit-identical from run to run, and the call says it was exact."""
+    from fractions import Fraction
+    real_ws = ops._ws
+
+    def poisoned(nbytes, device):
+        t, p = real_ws(nbytes, device)
+        if t is not None:
+            t.fill_(0x55)
+        return t, p
+    monkeypatch.setattr(ops, "_ws", poisoned)
+    gen = torch.Generator().manual_seed(77)
+    n = 128
+
+    def make(T):
+        g, u = torch.randn(T, n, generator=gen), torch.randn(T, n, generator=gen)
+        top = 8.0                                                           # every column's maximum: 8 (E = 130), the products clamped under it
+        X = (torch.nn.functional.silu(g) * u).clamp(-7.9, 7.9).to(torch.bfloat16)
+        X[0, :] = top
+        X[5, 3], X[6, 3], X[7, 3] = top * 129 * 2.0 ** -22, -top * 129 * 2.0 ** -22, top * 2.0 ** -30   # N = 129 2^23: low 24 bits 0x800000, the tie
+        X[8, 4], X[9, 4] = top * 255 * 2.0 ** -23, -top * 255 * 2.0 ** -23  # just under it
+        X[10, 5], X[11, 5] = top * 131 * 2.0 ** -23, -top * 2.0 ** -37      # just over it; nearly the deepest exact element
+        X[12, 6], X[13, 6] = top * 255 * 2.0 ** -30, -top * 255 * 2.0 ** -30  # N = 255 2^15: digits (.., 1, -128, -128, -128) -> L = -8421376 < -2^23
+        return X
+    S = torch.zeros(n, n, dtype=F64, device=dev)
+    S2 = torch.zeros_like(S)
+    total = [[Fraction(0)] * n for _ in range(n)]
+    worst = 0.0
+    for T in (900, 3000):
+        X = make(T)
+        info = {}
+        assert ops.cov_accum_i8(S, X.to(dev), route_info=info) == 6 and info["exact"] and info["columns"] == [], info
+        assert info["x"] == 0.0 and info["bound"] == 5e-15                  # (nothing rounded to an integer: the rho term is zero)
+        ops.cov_accum_i8(S2, X.to(dev))
+        ex = _exact_sigma(X)
+        total = [[a + b for a, b in zip(ra, rb)] for ra, rb in zip(total, ex)]
+        got = S.cpu()
+        diag = [float(total[i][i]) ** 0.5 for i in range(n)]
+        for i in range(n):
+            for j in range(i + 1):
+                worst = max(worst, abs(float(Fraction(got[i, j].item()) - total[i][j])) / (diag[i] * diag[j]))
+    assert torch.equal(S, S2), "integer class sums, remainder events added in list order: bit-identical from run to run"
+    assert worst <= 5e-15, worst
+    # the truncated product on the same data, for scale: within ITS bound, and visibly less exact
+    monkeypatch.setattr(ops, "I8_EXACT", False)
+    St = torch.zeros(n, n, dtype=F64, device=dev)
+    info_t = {}
+    X = make(3000)
+    assert ops.cov_accum_i8(St, X.to(dev), route_info=info_t) == 6 and not info_t["exact"]
+    ex = _exact_sigma(X)
+    got = St.cpu()
+    diag = [float(ex[i][i]) ** 0.5 for i in range(n)]
+    worst_t = max(abs(float(Fraction(got[i, j].item()) - ex[i][j])) / (diag[i] * diag[j]) for i in range(n) for j in range(i + 1))
+    assert worst_t <= info_t["bound"] and worst_t > 10 * worst, (worst_t, worst, info_t)
+
+
+def test_exact_route_gives_way_when_a_remainder_list_does_not_fit(ops, dev):
+    """The exact route is an optimisation of the route kernel's decision, never a different answer: where one 32-column x 2048-token
+    segment holds more remainder elements than its list takes (2048 = 3.1 %) the call runs the truncated product it would have run
+    anyway -- same planes, same columns, the bound of that product -- and the host model predicts which."""
+    gen = torch.Generator().manual_seed(5)
+    T, n = 6144, 256
+    ref_err = {}
+    for deep_rows, want_exact in ((60, True), (70, False)):
+        X = acts(gen, T, n)
+        X[2048:2048 + deep_rows, 64:96] = (X[2048:2048 + deep_rows, 64:96].float() * 2.0 ** -20).to(torch.bfloat16)   # 32 x deep_rows deep elements in ONE segment
+        S = torch.zeros(n, n, dtype=F64, device=dev)
+        info = {}
+        planes = ops.cov_accum_i8(S, X.to(dev), route_info=info)
+        want = check_route(info, X)
+        assert planes in (5, 6) and info["exact"] == want_exact == want["exact"], (deep_rows, info)
+        ref = torch.zeros(n, n, dtype=F64)
+        O.cov_accum_tokens(ref, X)
+        check_i8_error(entry_err(S, ref), info["bound"], family="gaussian", ctx=(deep_rows, info))
+        assert (info["bound"] < 1e-14) == want_exact
+
+
 def test_cov_accum_multi_side_stream_overlap_changes_nothing(ops, dev, monkeypatch):
     """In "i8" mode the small per-head fp64 problems run on a side stream beside the last int8 problem
     (ops.COV_OVERLAP_SMALL); results must be bit-identical to the one-stream order, call after call, and later work on
@@ -981,6 +1102,7 @@ def test_cov_accum_multi_side_stream_overlap_changes_nothing(ops, dev, monkeypat
 
 
 def test_cov_i8_zero_plane_skipping_is_exact(ops, dev, monkeypatch):
+    monkeypatch.setattr(ops, "I8_EXACT", False)       # (this is about the TRUNCATED product kernels' piece-mask skipping)
     """The product kernel skips digit planes that are all-zero over a tile panel in a k-step (piece masks written by the
     split pass), and the split pass does not even WRITE all-zero pieces of planes 4 and 5: the workspace is handed over
     poisoned (0x55 in every byte), so a piece that is read without having been written shows up in the result.  Data built so that the plane depth differs between row groups, between k-steps and between the two panels
@@ -1081,7 +1203,8 @@ def test_cov_i8_route_is_chosen_and_counted_on_the_device(ops, dev):
         assert {5: "i8_5", 6: "i8_6", 0: "fallback_f64"}[planes] == route
         assert torch.equal(S0, S1)
         counts = ops.i8_route_counts(dev)
-        assert counts[route] == 2 and sum(v for r, v in counts.items() if r != "fp64_columns") == 2 * (k + 1), counts
+        assert counts[route] == 2 and sum(v for r, v in counts.items() if r not in ("fp64_columns", "exact")) == 2 * (k + 1), counts
+        assert counts["exact"] == 2 * min(k + 1, 2)       # (the five- and the six-plane class both ran the exact route; the fallback did not)
     S64 = torch.zeros(n, n, dtype=F64, device=dev)
     ops.cov_accum(S64, data["fallback_f64"].to(dev))
     assert torch.equal(S1, S64)                                        # the whole-statistic fallback IS the fp64 kernel

@@ -120,3 +120,33 @@ def test_tolerance_factor_trades_planes_for_a_looser_but_still_kept_bound():
     keep = np.ones(N, bool)
     keep[loose[1]] = False
     assert measured(X, d, E, 5)[np.ix_(keep, keep)].max() <= sq + x + 4e-16
+
+
+def test_exact_route_decomposition_is_an_identity_in_integer_arithmetic():
+    """cov_i8.hip, "the exact route": N = N_d + L with N_d the top three balanced digits and L = d_3 2^16 + d_4 2^8 + d_5, and
+        sum_t N_ti N_tj  =  sum_t N_d,ti N_d,tj  +  sum_t L_ti N_tj  +  sum_t N_d,ti L_tj        (nothing dropped)
+    in exact integer arithmetic, for data with deep elements of both signs; the remainder kernel's partner value x_d, recomputed from
+    the bf16 value as 2^24 q floor(x / (2^24 q) + 8421504 / 2^24), IS N_d (the balanced digits' rounding, ties included); L lies in
+    [-8421504, 8355711]; and the event lists the device builds hold exactly the elements with L != 0 (remainder_counts)."""
+    torch.manual_seed(3)
+    T, n = 700, 64
+    g, u = torch.randn(T, n), torch.randn(T, n)
+    X = (torch.nn.functional.silu(g) * u * torch.exp(2 * torch.randn(T, 1))).clamp(-60, 60).to(torch.bfloat16)
+    X[0] = 64.0
+    X[1, 0], X[2, 0] = 64.0 * 129 * 2.0 ** -22, -64.0 * 129 * 2.0 ** -22          # the rounding tie of the low three digits, both signs
+    d, E, N, rounded, _ = M.digits(X)
+    assert int(rounded.sum()) == 0 and int(N[1, 0]) & 0xFFFFFF == 0x800000
+    L = d[3] * 65536 + d[4] * 256 + d[5]
+    Nd = N - L
+    assert np.array_equal(Nd, (d[0] << 40) + (d[1] << 32) + (d[2] << 24)) and L.min() >= -8421504 and L.max() <= 8355711
+    x = X.double().numpy()
+    q = np.ldexp(1.0, (E - 148).astype(np.int64))
+    assert np.array_equal(np.floor(x / q + 8421504.0 / 16777216.0) * q, np.ldexp(Nd.astype(np.float64), (E - 172).astype(np.int64)))
+    as_int = lambda a: a.astype(object)                     # noqa: E731  (Python integers: exact)
+    full = as_int(N).T @ as_int(N)
+    parts = as_int(Nd).T @ as_int(Nd) + as_int(L).T @ as_int(N) + as_int(Nd).T @ as_int(L)
+    assert (full == parts).all()
+    assert int((L != 0).sum()) == int(M.remainder_counts(d).sum()) > 0
+    r = M.route_of(X)
+    assert r["planes"] in (5, 6) and r["exact"] and r["x"] == 0.0 and r["sq"] == M.EXACT_ROUNDING
+    assert not M.route_of(X, offer_exact=False)["exact"]
