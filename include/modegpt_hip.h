@@ -139,7 +139,9 @@ int mdg_cov_accum_multi(int n, const mdg_cov_problem* problems, int dtype, void*
  * n_feat must be a multiple of 128, n_tokens < 2^28.  ws: mdg_cov_accum_i8_ws_bytes (about 6 bytes per element of x).
  * ev_start / ev_stop: optional hipEvent_t recorded on `stream` right before / after the two product launches (bench.py times
  * the dominant kernel alone with them); NULL otherwise. */
-/* THE EXACT ROUTE (default since ABI 9; flags & MDG_I8_NO_EXACT switches it off).  Planes 3 .. 5 are reached only by elements 17
+/* THE EXACT ROUTE (since ABI 9.  flags = 0: taken where it is the faster product -- launches the route kernel classes as six planes,
+ * i.e. SiLU- / GELU-gated MLP activations; MDG_I8_EXACT_ALWAYS: for five-plane launches too (+3 % of the call for an error at fp64
+ * rounding level instead of the truncated product's bound); MDG_I8_NO_EXACT: never).  Planes 3 .. 5 are reached only by elements 17
  * binades and more below their column's maximum -- 3e-5 of the elements of a Gaussian column, 0.5 % of a SiLU-gated one -- so the
  * call lists those elements (token, column, low 24 bits) and, when every list fits (at most 3.1 % of any 32 columns x 2048 tokens),
  * replaces the truncated product by an exact one:  X^T X = X_d^T X_d + X_lo^T X + X_d^T X_lo  with X_d the top three digit planes --
@@ -153,6 +155,7 @@ int mdg_cov_accum_multi(int n, const mdg_cov_problem* problems, int dtype, void*
  * mdg_cov_accum_i8_route's `exact`. */
 #define MDG_I8_MAX_COLUMNS 32
 #define MDG_I8_NO_EXACT 1             /* flags: never the exact route (the truncated five- / six-plane product with its bound) */
+#define MDG_I8_EXACT_ALWAYS 2         /* flags: the exact route wherever the remainder lists fit, also for launches of the five-plane class */
 #define MDG_I8_EXACT_ROUNDING 5e-15   /* what mdg_cov_accum_i8_route reports beside the rho term for a call on the exact route */
 size_t mdg_cov_accum_i8_ws_bytes(int64_t n_tokens, int64_t n_feat);
 int mdg_cov_accum_i8(const void* x, int64_t n_tokens, int64_t n_feat, int64_t ld, double* sigma, int64_t ld_sigma, void* ws,

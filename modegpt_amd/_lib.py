@@ -16,7 +16,7 @@ MDG_OK = 0
 MDG_ERR_BAD_ARG, MDG_ERR_HIP, MDG_ERR_NOT_PD, MDG_ERR_NO_CONVERGE, MDG_ERR_NO_DEVICE = -1, -2, -3, -4, -5
 MDG_BF16, MDG_F16, MDG_F32, MDG_F64 = 0, 1, 2, 3
 MDG_QK_ROPE_GROUPED, MDG_QK_ROPE_MHA, MDG_QK_OPT = 0, 1, 2
-MDG_I8_NO_EXACT = 1
+MDG_I8_NO_EXACT, MDG_I8_EXACT_ALWAYS = 1, 2
 MDG_GEMM_LOWER_ONLY, MDG_GEMM_A_LOWER_TRI, MDG_GEMM_B_LOWER_TRI, MDG_GEMM_A_UPPER_TRI = 1, 2, 4, 8
 
 _i64, _i32, _f64, _ptr, _sz = C.c_int64, C.c_int, C.c_double, C.c_void_p, C.c_size_t

@@ -954,13 +954,15 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
   const int64_t mgroups = pr.n / 32;
   auto load_masks = [&](int kt, unsigned& va, unsigned& vb) {
     const unsigned* z = (const unsigned*)(pr.zmask + (int64_t)kt * mgroups);   // n / 32 is a multiple of 4: dword-aligned rows
-    // mask_and: all ones, or 0x07070707 on the exact route -- planes 3 .. 5 are then "absent" everywhere: neither loaded nor
-    // multiplied here (the remainder kernel has them)
-    va = z[bi] & mask_and;                                                    // groups 4 bi .. 4 bi + 3
-    vb = (TJ == 128 ? z[bj] : z[bj >> 1]) & mask_and;   // groups 4 bj .. + 3; or 2 bj, 2 bj + 1 in one half of the dword (see b_half)
+    va = z[bi];                                                               // groups 4 bi .. 4 bi + 3
+    vb = TJ == 128 ? z[bj] : z[bj >> 1];   // groups 4 bj .. + 3; or 2 bj, 2 bj + 1 in one half of the dword (see b_half)
   };
   // 128 x 64 tiles: the B panel's two mask bytes are one half of the loaded dword
   auto b_half = [&](unsigned m) { return TJ == 128 ? m : (m >> ((bj & 1) * 16)) & 0xFFFFu; };
+  // mask_and: all ones, or 0x07070707 on the exact route -- planes 3 .. 5 are then "absent" everywhere: neither loaded nor multiplied
+  // here (the remainder kernel has them).  Applied where a loaded mask dword is USED, a k-step after its load was issued -- an
+  // operation on the freshly loaded value would make hipcc wait for it at once (vmcnt(0) in front of the LDS-DMA issue: 22.5 ->
+  // 28.7 ms per sigma_mlp launch when the clamp first sat in load_masks)
   auto wait_loads = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
   // masks of the stages kt (being multiplied) .. kt + D (the one this step issues) -- SGPRs; vA / vB: the loaded dwords of the
@@ -974,8 +976,8 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
     if (kb + i < ke) {
       unsigned t0, t1;
       load_masks(kb + i, t0, t1);
-      mA[i] = __builtin_amdgcn_readfirstlane(t0);
-      mB[i] = b_half(__builtin_amdgcn_readfirstlane(t1));
+      mA[i] = __builtin_amdgcn_readfirstlane(t0) & mask_and;
+      mB[i] = b_half(__builtin_amdgcn_readfirstlane(t1)) & mask_and;
     }
   if (ke - kb > D) load_masks(kb + D, vA, vB);
 #pragma unroll
@@ -1064,8 +1066,8 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
       if (loads_first) wait_loads();  // this wave's loads of the previous step
       __builtin_amdgcn_s_barrier();   // stage kt (PREFETCH: kt + 1 too) complete in LDS, stage kt - 1 no longer read
       auto refill = [&]() {           // stage kt + D into the buffer stage kt - 1 just left; masks of the stage after it behind it
-        mA[D] = __builtin_amdgcn_readfirstlane(vA);
-        mB[D] = b_half(__builtin_amdgcn_readfirstlane(vB));
+        mA[D] = __builtin_amdgcn_readfirstlane(vA) & mask_and;
+        mB[D] = b_half(__builtin_amdgcn_readfirstlane(vB)) & mask_and;
         if (kt + D < ke) issue_stage(kt + D, ahead(D), mA[D], mB[D]);
         if (kt + D + 1 < ke) load_masks(kt + D + 1, vA, vB);
       };
@@ -1429,47 +1431,69 @@ __global__ __launch_bounds__(256) void i8_columns_reduce_kernel(ColArgs a, const
 // of the elements more than 38 binades under their column maximum, which the split rounds to an integer (RouteOut::sq keeps it).
 // The route kernel's decisions stay as they are -- which columns leave for the fp64 column kernel, whether the whole statistic
 // does -- and the exact route then REPLACES the truncated five- or six-plane product whenever every remainder list fits its
-// segment (LO_CAP events per 32 columns x 2048 tokens = 3.1 % of the elements; cubed Gaussians, Student-t: no -- the truncated
+// list (LO_CAP events per 8 columns x 2048 tokens = 3.1 % of the elements; cubed Gaussians, Student-t: no -- the truncated
 // product with its bound takes those as before).  Cost at the sigma_mlp shape: extraction 0.2 ms, remainder product ~0.3 ms
 // (Gaussian) ... ~5 ms (SiLU-gated) against 0.4 x 2.3 ... 6.1 x 2.35 ms of plane-pair products saved.
-constexpr int LO_CHUNK_STEPS = 64;       // k-steps (2048 tokens) per segment of a group's event list
-constexpr int LO_CAP = 2048;             // events per segment
+constexpr int LO_CHUNK_STEPS = 64;       // k-steps (2048 tokens) per segment of a group's event lists
+constexpr int LO_SUB = 4;                // lists per (group, segment): one per residue of the column index mod 4 -- one per wave of the
+                                         // remainder kernel that owns those accumulator rows (columns) exclusively
+constexpr int LO_CAP = 512;              // events per list: 4 x 512 = 3.1 % of a segment's 65536 elements
 constexpr int LO_TILE = 128, LO_PITCH = LO_TILE + 1;
 constexpr double LO_ROUND = 8421504.0 / 16777216.0;   // (128 (1 + 256 + 65536)) / 2^24: where the balanced digits d_3 d_4 d_5 round
 constexpr int EXACT_OVERFLOW = 16, EXACT_RAN = 17;    // ints of the workspace's shared block
 
+struct __attribute__((aligned(16))) LoEntry {
+  double v;                        // x_lo(token, column) = L 2^(E_column - 172): exact (|L| < 2^24)
+  unsigned tok, col;               // token; column within its 32-column group
+};
 struct LoProblem {
   const bf16_t* x;
   int64_t ld;
   const signed char* planes;
   const unsigned char* zmask;
   const int* emax;
-  unsigned long long* entries;     // [n / 32][nch][LO_CAP]: token (28 bits) | column in its group (5 bits) << 28 | L (25 bits, signed: the
-                                   // balanced digits reach -8421504 < -2^23) << 39
-  int* counts;                     // [n / 32][nch]
+  LoEntry* entries;                // [n / 32][LO_SUB][nch][LO_CAP]: written per segment by i8_extract_lo_kernel, then closed up to one contiguous
+                                   // list per (group, residue) by i8_compact_lo_kernel
+  int* counts;                     // [n / 32][LO_SUB][nch] segment lengths, then [n / 32][LO_SUB] list lengths (totals)
   double* sigma;
   int64_t ld_sigma;
   int n, block, tile0;             // tile0: this statistic's first workgroup of the remainder-product grid
+  int pairs;                       // rows of x are 4-byte addressable: a lane fetches two neighbouring columns with one load
 };
 struct LoArgs {
   LoProblem prob[MAX_PROBLEMS];
   int nprob, nk, nch, tiles;
+  int always;                      // MDG_I8_EXACT_ALWAYS: the exact route for launches of the five-plane class too
   const int* route_flag;
   int* state;                      // shared block of the workspace: [EXACT_OVERFLOW], [EXACT_RAN]
 };
+__device__ __forceinline__ int* lo_totals(const LoProblem& pr, int nch) { return pr.counts + (int64_t)(pr.n / 32) * LO_SUB * nch; }
+// Is the exact route on offer for this launch?  Always when the caller asks for it; by default where it is the faster product:
+// launches of the six-plane class (9 executed plane pairs + the remainder kernel against 15.1; a five-plane launch executes 9.4
+// and would pay the remainder kernel's fixed cost for an accuracy nobody asked for).
+__device__ __forceinline__ bool lo_offered(const LoArgs& a) {
+  if (a.always) return true;
+  for (int p = 0; p < a.nprob; p++)
+    if ((a.route_flag[p] & 3) == 1) return true;
+  return false;
+}
 
 // One wave per (32-column group, segment of LO_CHUNK_STEPS k-steps): reads the pieces of planes 3 .. 5 the piece masks say are
-// there -- as the product kernel would -- and compacts the nonzero L into the segment in (k-step, token-in-half, lane) order.
+// there -- as the product kernel would -- and compacts the elements with L != 0 into the segment's four lists in (k-step,
+// token-in-half, lane) order.
 __global__ __launch_bounds__(64) void i8_extract_lo_kernel(LoArgs a) {
   const LoProblem& pr = a.prob[blockIdx.z];
   const int64_t groups = pr.n / 32;
   const int G = blockIdx.x, ch = blockIdx.y, lane = threadIdx.x;
+  if (!lo_offered(a)) return;
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0) a.state[EXACT_RAN] = 1;
   if (G >= groups || (a.route_flag[blockIdx.z] & 2)) return;     // (a statistic that went to the fp64 kernel has no lists)
-  unsigned long long* out = pr.entries + ((int64_t)G * a.nch + ch) * LO_CAP;
+  const int sub = lane & (LO_SUB - 1);
+  LoEntry* out = pr.entries + (((int64_t)G * LO_SUB + sub) * a.nch + ch) * LO_CAP;
   const unsigned long long below = (1ull << lane) - 1ull;
-  const unsigned long long mine = ((unsigned long long)(lane & 31)) << 28;
-  int count = 0;
+  const unsigned long long every4 = 0x1111111111111111ull;
+  const int e_col = pr.emax[G * 32 + (lane & 31)] & 255;
+  int count[LO_SUB] = {0, 0, 0, 0};
   const int kt1 = min(a.nk, (ch + 1) * LO_CHUNK_STEPS);
   for (int kt = ch * LO_CHUNK_STEPS; kt < kt1; kt++) {
     const unsigned m = pr.zmask[(int64_t)kt * groups + G];
@@ -1487,84 +1511,147 @@ __global__ __launch_bounds__(64) void i8_extract_lo_kernel(LoArgs a) {
       const unsigned long long b = __ballot(L != 0);
       if (b == 0) continue;
       if (L != 0) {
-        const int at = count + __builtin_popcountll(b & below);
-        if (at < LO_CAP) out[at] = (unsigned long long)(tok0 + q) | mine | ((unsigned long long)((unsigned)L & 0x1FFFFFFu) << 39);
+        const int at = count[sub] + __builtin_popcountll(b & below & (every4 << sub));
+        if (at < LO_CAP) out[at] = LoEntry{ldexp((double)L, e_col - 172), tok0 + q, (unsigned)(lane & 31)};
       }
-      count += __builtin_popcountll(b);
+#pragma unroll
+      for (int k = 0; k < LO_SUB; k++) count[k] += __builtin_popcountll(b & (every4 << k));
     }
   }
-  if (lane == 0) {
-    pr.counts[(int64_t)G * a.nch + ch] = min(count, LO_CAP);
-    if (count > LO_CAP) a.state[EXACT_OVERFLOW] = 1;
+  if (lane < LO_SUB) {
+    int mine = count[0];
+#pragma unroll
+    for (int k = 1; k < LO_SUB; k++) mine = lane == k ? count[k] : mine;
+    pr.counts[((int64_t)G * LO_SUB + lane) * a.nch + ch] = min(mine, LO_CAP);
+    if (mine > LO_CAP) a.state[EXACT_OVERFLOW] = 1;
   }
+}
+
+// One wave per list (32-column group, residue): closes the segments up into one contiguous list, in place (a segment only ever
+// moves towards the front, and the wave copies in order), and leaves its length in lo_totals.  The remainder kernel then walks
+// full batches whatever the density (a Gaussian column has a handful of events per segment).
+__global__ __launch_bounds__(64) void i8_compact_lo_kernel(LoArgs a) {
+  if (!lo_offered(a) || a.state[EXACT_OVERFLOW] != 0) return;
+  const LoProblem& pr = a.prob[blockIdx.y];
+  const int list = blockIdx.x, lane = threadIdx.x;
+  if (list >= pr.n / 32 * LO_SUB || (a.route_flag[blockIdx.y] & 2)) return;
+  const int* counts = pr.counts + (int64_t)list * a.nch;
+  LoEntry* base = pr.entries + (int64_t)list * a.nch * LO_CAP;
+  int total = 0;
+  for (int ch = 0; ch < a.nch; ch++) {
+    const int cnt = counts[ch];
+    const LoEntry* src = base + (int64_t)ch * LO_CAP;
+    if (total != ch * LO_CAP)
+      for (int i = 0; i < cnt; i += 64) {
+        LoEntry e = LoEntry{0., 0u, 0u};
+        if (i + lane < cnt) e = src[i + lane];
+        if (i + lane < cnt) base[total + i + lane] = e;      // (the 64 loads of a round are complete before its stores: same wave, in order)
+      }
+    total += cnt;
+  }
+  if (lane == 0) lo_totals(pr, a.nch)[list] = total;
 }
 
 __device__ __forceinline__ void lds_add_f64(double* p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_f64, returnless: issued in order per wave
 }
+__device__ __forceinline__ double bf16_to_f64(unsigned bits16) { return (double)__uint_as_float(bits16 << 16); }
+// Where row (column) i of the tile sits in the LDS accumulator: even indices in the first half, odd ones in the second.  A lane
+// fetches two NEIGHBOURING partner columns with one load; stored side by side its two ds_add_f64 would put the 64 lanes on a 16-byte
+// stride -- four lanes per bank pair, a four-way conflict on every atomic of the kernel (the walk was bound by exactly that:
+// 10.6 ms at the sigma_mlp shape on SiLU-gated data).  Permuted, the lanes of an atomic cover 512 contiguous bytes (row-event) or
+// one 8-byte word per 1032-byte row (column-event): the two passes a 64-lane fp64 access needs anyway.
+__device__ __forceinline__ int lo_perm(int i) { return (i >> 1) + 64 * (i & 1); }
 
-// The events of one 32-column group, in list order, by ONE wave.  COLS = false: the group is row group `wave` of the tile's row
-// block -- acc[wave * 32 + r][c] += x_lo(t, r) x(t, c) for the 128 columns c of the tile's column block (lane: c and c + 64);
-// COLS = true: the group is column group `wave` of the column block -- acc[r][wave * 32 + c] += x_d(t, r) x_lo(t, c) for the 128
-// rows r of the row block (lane: r and r + 64).  partner0: first column of the partner block.
+// The events of ONE list -- 32-column group G, columns with (column mod 4) == sub -- in list order, by ONE wave, which thereby owns
+// the accumulators they touch.  COLS = false: G is row group g of the tile's row block: acc[g 32 + r][c] += x_lo(t, r) x(t, c) for
+// the 128 columns c of the tile's column block (lane: c = 2 lane, 2 lane + 1).  COLS = true: G is column group g of the column
+// block: acc[r][g 32 + c] += x_d(t, r) x_lo(t, c) for the 128 rows r of the row block (lane: r = 2 lane, 2 lane + 1), x_d the
+// partner's top three digit planes -- which IS x for every element within 14 binades of its column maximum (no digit below plane
+// 2), so the rounding is taken only when a lane meets a deeper one.  partner0: first column of the partner block.
+// The walk is bound by the latency of the partner loads (one 4-byte load per event and lane, rows scattered over the tokens) and
+// by the VALU (7 - 14 operations per event): the events go in batches of LO_UN whose loads are all issued before the previous
+// batch is multiplied (two batches in flight per wave, sixteen waves per CU).
+constexpr int LO_UN = 32;
 template <bool COLS>
-__device__ __forceinline__ void lo_events(const LoProblem& pr, const int nch, const int G, const int partner0, const int wave,
+__device__ __forceinline__ void lo_events(const LoProblem& pr, const int nch, const int G, const int sub, const int partner0, const int g,
                                           const int lane, double* acc) {
-  const int e_mine = pr.emax[G * 32 + (lane & 31)] & 255;           // lane r: the exponent of the group's column r
   const unsigned short* xs = (const unsigned short*)pr.x;
+  unsigned lim_a = 0, lim_b = 0;
   double qa = 1., qb = 1., ia = 1., ib = 1.;
   if (COLS) {   // the partner rows' digit grid: 2^24 units of their own scale
-    qa = ldexp(1.0, (pr.emax[partner0 + lane] & 255) - 148);
-    qb = ldexp(1.0, (pr.emax[partner0 + 64 + lane] & 255) - 148);
+    const int ea = pr.emax[partner0 + 2 * lane] & 255, eb = pr.emax[partner0 + 2 * lane + 1] & 255;
+    qa = ldexp(1.0, ea - 148);
+    qb = ldexp(1.0, eb - 148);
     ia = 1.0 / qa;
     ib = 1.0 / qb;
+    // an element has a digit below plane 2 iff its exponent field is below E - 14 (and it is not zero): 0 < |bits| < (E - 14) << 7
+    lim_a = (unsigned)max(ea - 14, 1) << 7;
+    lim_b = (unsigned)max(eb - 14, 1) << 7;
   }
-  constexpr int UN = 4;     // events whose partner loads are in flight together
-  for (int ch = 0; ch < nch; ch++) {
-    const int cnt = pr.counts[(int64_t)G * nch + ch];
-    const unsigned long long* list = pr.entries + ((int64_t)G * nch + ch) * LO_CAP;
-    for (int e0 = 0; e0 < cnt; e0 += 64) {
-      const unsigned long long ent = e0 + lane < cnt ? list[e0 + lane] : 0ull;
-      const int lim = min(64, cnt - e0);
-      for (int eb = 0; eb < lim; eb += UN) {
-        unsigned tok[UN];
-        int col[UN], L[UN];
-        unsigned short va[UN], vb[UN];
+  const int list_id = G * LO_SUB + sub;
+  const int cnt = lo_totals(pr, nch)[list_id];
+  const LoEntry* list = pr.entries + (int64_t)list_id * nch * LO_CAP;
+  // batch k: events [k LO_UN, ...) -- one entry per lane (lanes beyond the list's end: the last entry's token, v = 0: exact zeros)
+  auto fetch = [&](int k, LoEntry& m) {
+    m = list[min(k * LO_UN + (lane & (LO_UN - 1)), cnt - 1)];
+    if (k * LO_UN + (lane & (LO_UN - 1)) >= cnt) m.v = 0.;
+  };
+  auto issue = [&](const LoEntry& m, unsigned (&xv)[LO_UN]) {
 #pragma unroll
-        for (int u = 0; u < UN; u++) {
-          const int e = min(eb + u, lim - 1);
-          const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)ent, e);
-          const int hi = __builtin_amdgcn_readlane((int)(unsigned)(ent >> 32), e);
-          tok[u] = lo & 0x0FFFFFFFu;
-          col[u] = (int)((lo >> 28) | (((unsigned)hi & 1u) << 4));
-          L[u] = eb + u < lim ? hi >> 7 : 0;                          // (a padding slot adds exact zeros)
-          const unsigned short* row = xs + (int64_t)tok[u] * pr.ld + partner0 + lane;
-          va[u] = row[0];
-          vb[u] = row[64];
-        }
+    for (int u = 0; u < LO_UN; u++) {
+      const unsigned tok = (unsigned)__builtin_amdgcn_readlane((int)m.tok, u);
+      const unsigned short* row = xs + (int64_t)tok * pr.ld + partner0 + 2 * lane;
+      xv[u] = pr.pairs ? *(const unsigned*)row : ((unsigned)row[0] | ((unsigned)row[1] << 16));
+    }
+  };
+  auto multiply = [&](const LoEntry& m, const unsigned (&xv)[LO_UN]) {
 #pragma unroll
-        for (int u = 0; u < UN; u++) {
-          if (L[u] == 0) continue;
-          const int e_col = __builtin_amdgcn_readlane(e_mine, col[u]);
-          const double v = ldexp((double)L[u], e_col - 172);          // x_lo(t, col): exact
-          double pa = (double)__uint_as_float((unsigned)va[u] << 16), pb = (double)__uint_as_float((unsigned)vb[u] << 16);
-          if (COLS) {
-            pa = floor(pa * ia + LO_ROUND) * qa;                       // x_d of the partner rows: exact (powers of two, one floor)
-            pb = floor(pb * ib + LO_ROUND) * qb;
-            lds_add_f64(acc + lane * LO_PITCH + wave * 32 + col[u], v * pa);
-            lds_add_f64(acc + (lane + 64) * LO_PITCH + wave * 32 + col[u], v * pb);
-          } else {
-            lds_add_f64(acc + (wave * 32 + col[u]) * LO_PITCH + lane, v * pa);
-            lds_add_f64(acc + (wave * 32 + col[u]) * LO_PITCH + 64 + lane, v * pb);
-          }
+    for (int u = 0; u < LO_UN; u++) {
+      const double v = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(m.v), u), __builtin_amdgcn_readlane(__double2loint(m.v), u));
+      const int col = __builtin_amdgcn_readlane((int)m.col, u);
+      double pa = bf16_to_f64(xv[u] & 0xFFFFu), pb = bf16_to_f64(xv[u] >> 16);
+      if (COLS) {
+        const bool deep = ((xv[u] & 0x7FFFu) - 1u < lim_a - 1u) || (((xv[u] >> 16) & 0x7FFFu) - 1u < lim_b - 1u);
+        if (__ballot(deep)) {
+          pa = floor(pa * ia + LO_ROUND) * qa;                             // exact (powers of two, one floor)
+          pb = floor(pb * ib + LO_ROUND) * qb;
         }
+        lds_add_f64(acc + lane * LO_PITCH + lo_perm(g * 32 + col), v * pa);            // rows 2 lane, 2 lane + 1
+        lds_add_f64(acc + (64 + lane) * LO_PITCH + lo_perm(g * 32 + col), v * pb);
+      } else {
+        lds_add_f64(acc + lo_perm(g * 32 + col) * LO_PITCH + lane, v * pa);            // columns 2 lane, 2 lane + 1
+        lds_add_f64(acc + lo_perm(g * 32 + col) * LO_PITCH + 64 + lane, v * pb);
       }
     }
+  };
+  if (cnt == 0) return;
+  const int nb = (cnt + LO_UN - 1) / LO_UN;
+  LoEntry mA, mB;
+  unsigned xA[LO_UN], xB[LO_UN];
+  fetch(0, mA);
+  issue(mA, xA);
+  for (int k = 0; k < nb; k += 2) {
+    if (k + 1 < nb) {
+      fetch(k + 1, mB);
+      issue(mB, xB);
+    }
+    __builtin_amdgcn_sched_barrier(0);    // (batch B's loads are out before batch A's are waited for: hipcc would sink each load to its use)
+    multiply(mA, xA);
+    if (k + 1 >= nb) break;
+    if (k + 2 < nb) {
+      fetch(k + 2, mA);
+      issue(mA, xA);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(mB, xB);
   }
 }
 
-// One workgroup of four waves per 128 x 128 tile of the lower triangle (per-head statistics: the diagonal tiles).
-__global__ __launch_bounds__(256) void i8_lo_product_kernel(LoArgs a) {
+// One workgroup of sixteen waves per 128 x 128 tile of the lower triangle (per-head statistics: the diagonal tiles): wave (g, sub)
+// takes the list `sub` of row group g, then of column group g.
+constexpr int LO_THREADS = 1024;
+__global__ __launch_bounds__(LO_THREADS) void i8_lo_product_kernel(LoArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lo_acc[];     // [128][LO_PITCH]
   if (a.state[EXACT_RAN] != 1 || a.state[EXACT_OVERFLOW] != 0) return;
   int p = 0;
@@ -1583,24 +1670,21 @@ __global__ __launch_bounds__(256) void i8_lo_product_kernel(LoArgs a) {
   }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wave & 3, sub = wave >> 2;
   // anything to do?  (the lists of the tile's four row groups and four column groups)
   int any = 0;
-  for (int i = tid; i < 8 * a.nch; i += 256) {
-    const int g = i / a.nch, ch = i % a.nch;
-    const int G = (g < 4 ? 4 * bi + g : 4 * bj + g - 4);
-    any |= pr.counts[(int64_t)G * a.nch + ch];
-  }
+  if (tid < 8 * LO_SUB) any = lo_totals(pr, a.nch)[(tid < 4 * LO_SUB ? 4 * bi * LO_SUB : 4 * bj * LO_SUB - 4 * LO_SUB) + tid];
   if (!__syncthreads_or(any)) return;
-  for (int i = tid; i < LO_TILE * LO_PITCH; i += 256) lo_acc[i] = 0.;
+  for (int i = tid; i < LO_TILE * LO_PITCH; i += LO_THREADS) lo_acc[i] = 0.;
   __syncthreads();
-  lo_events<false>(pr, a.nch, 4 * bi + wave, bj * LO_TILE, wave, lane, lo_acc);
-  __syncthreads();      // an accumulator changes owner between the two passes: row group's wave, then column group's wave
-  lo_events<true>(pr, a.nch, 4 * bj + wave, bi * LO_TILE, wave, lane, lo_acc);
+  lo_events<false>(pr, a.nch, 4 * bi + g, sub, bj * LO_TILE, g, lane, lo_acc);
+  __syncthreads();      // an accumulator changes owner between the two passes: the wave of its row, then the wave of its column
+  lo_events<true>(pr, a.nch, 4 * bj + g, sub, bi * LO_TILE, g, lane, lo_acc);
   __syncthreads();
-  for (int i = tid; i < LO_TILE * LO_TILE; i += 256) {
+  for (int i = tid; i < LO_TILE * LO_TILE; i += LO_THREADS) {
     const int r = i / LO_TILE, c = i % LO_TILE;
     const int row = bi * LO_TILE + r, col = bj * LO_TILE + c;
-    const double v = lo_acc[r * LO_PITCH + c];
+    const double v = lo_acc[lo_perm(r) * LO_PITCH + lo_perm(c)];
     if (col > row || v == 0.) continue;
     if ((pr.emax[row] | pr.emax[col]) & EMAX_COLUMN_OUT) continue;    // rows / columns of the fp64 column kernel: not ours
     double* s = pr.sigma + (int64_t)row * pr.ld_sigma + col - (pr.block ? row / pr.block * pr.block : 0);
@@ -1767,9 +1851,9 @@ size_t layout(int count, const mdg_cov_problem* pr, ProblemWs* out, size_t* fall
     w.zmask = off;
     off += zmask_bytes(pr[i].n_tokens, cols);
     w.lo_entries = off = align_up(off, 256);     // the exact route's event lists: [cols / 32][chunks][LO_CAP] x 8 bytes, then the counts
-    off += (size_t)(cols / 32) * lo_chunks(pr[i].n_tokens) * LO_CAP * sizeof(unsigned long long);
+    off += (size_t)(cols / 32) * lo_chunks(pr[i].n_tokens) * LO_SUB * LO_CAP * sizeof(LoEntry);
     w.lo_counts = off;
-    off += align_up((size_t)(cols / 32) * lo_chunks(pr[i].n_tokens) * sizeof(int), 256);
+    off += align_up((size_t)(cols / 32) * LO_SUB * (lo_chunks(pr[i].n_tokens) + 1) * sizeof(int), 256);
     if (out) out[i] = w;
     fb = std::max(fb, mdg_cov_accum_ws_bytes(pr[i].n_tokens, pr[i].n_feat, pr[i].batch));
   }
@@ -1822,7 +1906,8 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
   if (used_i8) *used_i8 = 0;
   MDG_CHECK_ARG(tolerance >= 1.0 && tolerance <= 1e6, "mdg_cov_accum_i8_multi: tolerance factor %g outside [1, 1e6] (1 = guaranteed <= 1.1e-11)",
                 tolerance);
-  MDG_CHECK_ARG((flags & ~MDG_I8_NO_EXACT) == 0, "mdg_cov_accum_i8_multi: unknown flags 0x%x", flags);
+  MDG_CHECK_ARG((flags & ~(MDG_I8_NO_EXACT | MDG_I8_EXACT_ALWAYS)) == 0 && flags != (MDG_I8_NO_EXACT | MDG_I8_EXACT_ALWAYS),
+                "mdg_cov_accum_i8_multi: bad flags 0x%x", flags);
   const bool offer_exact = !(flags & MDG_I8_NO_EXACT);
   MDG_CHECK_ARG(problems_ok(count, problems),
                 "mdg_cov_accum_i8_multi: 1..%d statistics of the same token count; full ones need n_feat %% 128 == 0, per-head ones "
@@ -1899,6 +1984,7 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
     lo.nch = lo_chunks(n_tokens);
     lo.route_flag = pflag;
     lo.state = flag;
+    lo.always = (flags & MDG_I8_EXACT_ALWAYS) ? 1 : 0;
     int tiles = 0, max_groups = 0;
     for (int i = 0; i < count; i++) {
       const mdg_cov_problem& q = problems[i];
@@ -1906,7 +1992,8 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
       LoProblem& l = lo.prob[i];
       l.x = (const bf16_t*)q.x; l.ld = q.ld;
       l.planes = a.prob[i].planes; l.zmask = a.prob[i].zmask; l.emax = a.prob[i].emax;
-      l.entries = (unsigned long long*)((char*)ws + pw[i].lo_entries);
+      l.entries = (LoEntry*)((char*)ws + pw[i].lo_entries);
+      l.pairs = ((uintptr_t)q.x % 4 == 0) && (q.ld % 2 == 0);
       l.counts = (int*)((char*)ws + pw[i].lo_counts);
       l.sigma = q.sigma; l.ld_sigma = q.ld_sigma;
       l.n = n; l.block = q.batch > 1 ? TI : 0;
@@ -1918,6 +2005,7 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
     for (int i = count; i < MAX_PROBLEMS; i++) lo.prob[i] = lo.prob[0];
     lo.tiles = tiles;
     hipLaunchKernelGGL(i8_extract_lo_kernel, dim3((unsigned)max_groups, (unsigned)lo.nch, (unsigned)count), dim3(64), 0, st, lo);
+    hipLaunchKernelGGL(i8_compact_lo_kernel, dim3((unsigned)(max_groups * LO_SUB), (unsigned)count), dim3(64), 0, st, lo);
     MDG_LAUNCH_CHECK();
     a.exact_state = flag + EXACT_OVERFLOW;
   }
@@ -1989,7 +2077,7 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
   if (offer_exact) {   // the remainder products of the exact route (every workgroup exits at once when the truncated product ran instead)
     const size_t lds = (size_t)LO_TILE * LO_PITCH * sizeof(double);
     MDG_HIP(hipFuncSetAttribute((const void*)i8_lo_product_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(i8_lo_product_kernel, dim3((unsigned)lo.tiles), dim3(256), lds, st, lo);
+    hipLaunchKernelGGL(i8_lo_product_kernel, dim3((unsigned)lo.tiles), dim3(LO_THREADS), lds, st, lo);
     MDG_LAUNCH_CHECK();
   }
   // the columns the route took off the int8 path: their rows / columns of sigma from the fp64 column kernel (both launches exit at

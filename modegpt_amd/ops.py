@@ -174,13 +174,15 @@ def _read_route(lib, count, arr, stat, wsp, stream) -> dict:
             "bound": bound[0] + bound[1], "exact": bool(exact.value)}
 
 
-# The exact route of the int8 covariance (include/modegpt_hip.h, "THE EXACT ROUTE"): on by default; MODEGPT_I8_EXACT=0 -- or
-# ops.I8_EXACT = False -- keeps every call on the truncated five- / six-plane product (MDG_I8_NO_EXACT).
-I8_EXACT = os.environ.get("MODEGPT_I8_EXACT", "1") != "0"
+# The exact route of the int8 covariance (include/modegpt_hip.h, "THE EXACT ROUTE"): "auto" (default) takes it where it is the
+# faster product -- launches of the six-plane class: the MLP statistic of a gated model; "always" (True) wherever the remainder lists
+# fit (fp64-rounding accuracy for every int8 statistic, +3 % on a five-plane call); "never" (False) keeps every call on the
+# truncated five- / six-plane product with its bound.  Environment: MODEGPT_I8_EXACT=auto|1|0.
+I8_EXACT = {"1": True, "always": True, "0": False, "never": False}.get(os.environ.get("MODEGPT_I8_EXACT", "auto").lower(), "auto")
 
 
 def _i8_flags() -> int:
-    return 0 if I8_EXACT else _lib.MDG_I8_NO_EXACT
+    return {True: _lib.MDG_I8_EXACT_ALWAYS, False: _lib.MDG_I8_NO_EXACT}.get(I8_EXACT, 0)
 
 
 def cov_accum_i8_multi(items, events=None, mfma_stats: Optional[dict] = None, report: bool = False,

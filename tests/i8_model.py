@@ -158,18 +158,22 @@ def product(d, E, P):
     return acc * sc[:, None] * sc[None, :]
 
 
-LO_CHUNK_TOKENS, LO_CAP, EXACT_ROUNDING = 64 * 32, 2048, 5e-15      # cov_i8.hip: LO_CHUNK_STEPS x KS, LO_CAP; modegpt_hip.h: MDG_I8_EXACT_ROUNDING
+LO_CHUNK_TOKENS, LO_SUB, LO_CAP, EXACT_ROUNDING = 64 * 32, 4, 512, 5e-15      # cov_i8.hip: LO_CHUNK_STEPS x KS, LO_SUB, LO_CAP; modegpt_hip.h: MDG_I8_EXACT_ROUNDING
 
 
-def remainder_counts(d):
-    """[T / 2048 segments, n / 32 groups]: elements with a nonzero digit in planes 3 .. 5 (L != 0) per (2048-token segment, 32-column
-    group) -- the event lists of the exact route (i8_extract_lo_kernel)."""
-    lo = (d[3] != 0) | (d[4] != 0) | (d[5] != 0)
+def list_counts(lo):
+    """lo [T, n] bool (element has L != 0) -> [segments, n / 32 groups, 4]: the lengths of the exact route's event lists -- one per
+    (2048-token segment, 32-column group, column index mod 4) (i8_extract_lo_kernel)."""
     T, n = lo.shape
     pad = (-T) % LO_CHUNK_TOKENS
     if pad:
         lo = np.concatenate([lo, np.zeros((pad, n), bool)])
-    return lo.reshape(-1, LO_CHUNK_TOKENS, n // 32, 32).sum(axis=(1, 3))
+    return lo.reshape(-1, LO_CHUNK_TOKENS, n // 32, 32 // LO_SUB, LO_SUB).sum(axis=(1, 3))
+
+
+def remainder_counts(d):
+    """Lengths of the event lists of the digits d [6, T, n]: elements with a nonzero digit in planes 3 .. 5."""
+    return list_counts((d[3] != 0) | (d[4] != 0) | (d[5] != 0))
 
 
 def route_of(X, chunk=1024, tolerance=1.0, offer_exact=True):
@@ -178,7 +182,8 @@ def route_of(X, chunk=1024, tolerance=1.0, offer_exact=True):
     route_info: planes, columns (in the order the greedy took them), sq, x, bound, exact.  exact (the exact route: nine plane
     pairs + the fp64 remainder products, cov_i8.hip "the exact route"): the route kernel's decision stands, and when no event list
     of the columns that stayed overflows its segment the truncated product is replaced -- the bound is then the rounded-element
-    term 2 R + R^2 plus fp64 rounding."""
+    term 2 R + R^2 plus fp64 rounding.  offer_exact: True (MDG_I8_EXACT_ALWAYS), False (MDG_I8_NO_EXACT) or "auto" (flags 0: only
+    for the six-plane class)."""
     qs, rs, ns, lo = [], [], [], []
     for c0 in range(0, X.shape[1], chunk):
         d, _, _, rounded, nnz = digits(X[:, c0:c0 + chunk].contiguous())
@@ -189,14 +194,13 @@ def route_of(X, chunk=1024, tolerance=1.0, offer_exact=True):
     nz = st["nnz"][st["nnz"] > 0]
     planes, cols, (sq, x) = route(st, sort=False, tokens=min(X.shape[0], int(nz.min()) if nz.size else X.shape[0]), tolerance=tolerance)
     exact = False
+    if offer_exact == "auto":          # the library's default: the exact route where it is the faster product -- the six-plane class
+        offer_exact = planes == 6
     if planes and offer_exact and X.shape[1] % 32 == 0:
         lo = np.concatenate(lo, axis=1)
         lo[:, cols] = False                            # the digits of the columns that left are cleared before the lists are made
-        T, n = lo.shape
-        pad = (-T) % LO_CHUNK_TOKENS
-        if pad:
-            lo = np.concatenate([lo, np.zeros((pad, n), bool)])
-        exact = bool(lo.reshape(-1, LO_CHUNK_TOKENS, n // 32, 32).sum(axis=(1, 3)).max() <= LO_CAP)
+        n = lo.shape[1]
+        exact = bool(list_counts(lo).max() <= LO_CAP)
         if exact:
             _, rho = alphas(st)
             live = np.ones(n, bool)

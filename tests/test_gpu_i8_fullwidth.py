@@ -35,9 +35,9 @@ def ops(dev):
 
 @pytest.fixture(params=["exact", "truncated"])
 def i8_route(request, monkeypatch):
-    """Both products behind the int8 covariance: the exact route (the default: the top three digit planes' nine plane pairs + the fp64
-    remainder products, wherever the remainder lists fit -- they do on both data kinds here) and the truncated five- / six-plane
-    product with its bound (MDG_I8_NO_EXACT)."""
+    """Both products behind the int8 covariance: the exact route (MDG_I8_EXACT_ALWAYS: the top three digit planes' nine plane pairs +
+    the fp64 remainder products, wherever the remainder lists fit -- they do on both data kinds here; the default takes it for the
+    six-plane class only) and the truncated five- / six-plane product with its bound (MDG_I8_NO_EXACT)."""
     from modegpt_amd import ops as _ops
     monkeypatch.setattr(_ops, "I8_EXACT", request.param == "exact")
     return request.param
@@ -278,7 +278,7 @@ def test_fused_int8_launch_lets_columns_and_statistics_leave_alone(ops, dev):
     info = []
     assert ops.cov_accum_i8_multi(items, report=True, route_info=info) == 5
     assert [i["columns"] for i in info] == [[], [17], [2 * 128 + 5]] and all(i["planes"] == 5 for i in info)
-    assert ops.i8_route_counts(dev, reset=True) == {"i8_5": 3, "i8_6": 0, "fallback_f64": 0, "fp64_columns": 2, "exact": 3}
+    assert ops.i8_route_counts(dev, reset=True) == {"i8_5": 3, "i8_6": 0, "fallback_f64": 0, "fp64_columns": 2, "exact": 0}
     refs = []
     for S, X, nh in items:
         R = torch.zeros_like(S)
@@ -293,7 +293,7 @@ def test_fused_int8_launch_lets_columns_and_statistics_leave_alone(ops, dev):
     ops.cov_accum(Rh, Xh)
     mixed = [(torch.zeros(2048, 2048, dtype=F64, device=dev), Xa, 1), (torch.zeros(2048, 2048, dtype=F64, device=dev), Xh, 1)]
     assert ops.cov_accum_i8_multi(mixed, report=True) == 5
-    assert ops.i8_route_counts(dev, reset=True) == {"i8_5": 1, "i8_6": 0, "fallback_f64": 1, "fp64_columns": 0, "exact": 1}
+    assert ops.i8_route_counts(dev, reset=True) == {"i8_5": 1, "i8_6": 0, "fallback_f64": 1, "fp64_columns": 0, "exact": 0}
     assert torch.equal(mixed[1][0], Rh)
     _check_against(mixed[0][0], refs[0])
     both = [(torch.zeros(2048, 2048, dtype=F64, device=dev), Xh, 1), (torch.zeros(2048, 2048, dtype=F64, device=dev), Xh, 1)]
@@ -360,7 +360,7 @@ def test_device_route_equals_the_host_model_at_sigma_x_width(ops, dev):
         S64 = torch.zeros_like(S8)
         info = {}
         ops.cov_accum_i8(S8, X, route_info=info)
-        want = M.route_of(X.cpu())
+        want = M.route_of(X.cpu(), offer_exact=ops.I8_EXACT)
         assert (info["planes"], info["columns"], info["exact"]) == (want["planes"], want["columns"], want["exact"]), \
             (kind, cols, info, want["planes"], want["columns"], want["exact"])
         assert abs(info["sq"] - want["sq"]) <= 1e-9 * want["sq"] and abs(info["x"] - want["x"]) <= 1e-9 * want["x"]
@@ -385,8 +385,8 @@ def test_cov_accum_multi_routes_a_llama_layer(ops, dev, monkeypatch):
 
     fused, c1 = run(True)
     apart, c0 = run(False)
-    # sigma_mlp alone (six-plane class); x, q, k share a launch (five-plane class); every int8 statistic on the exact route
-    assert c1 == {"i8_5": 3, "i8_6": 1, "fallback_f64": 0, "fp64_columns": 0, "exact": 4}
-    assert c0 == {"i8_5": 1, "i8_6": 1, "fallback_f64": 0, "fp64_columns": 0, "exact": 2}   # separate launches: sigma_mlp, sigma_x; heads fp64
+    # sigma_mlp alone (six-plane class: the exact route, the faster product there); x, q, k share a truncated five-plane launch
+    assert c1 == {"i8_5": 3, "i8_6": 1, "fallback_f64": 0, "fp64_columns": 0, "exact": 1}
+    assert c0 == {"i8_5": 1, "i8_6": 1, "fallback_f64": 0, "fp64_columns": 0, "exact": 1}   # separate launches: sigma_mlp, sigma_x; heads fp64
     for i, (a, b) in enumerate(zip(fused, apart)):
         _check_against(a, b, None, "silu_gated" if i == 0 else "gaussian")

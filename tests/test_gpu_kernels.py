@@ -680,8 +680,9 @@ def check_route(info, X, tolerance=1.0):
 
 @pytest.fixture(params=["exact", "truncated"])
 def i8_route(request, monkeypatch):
-    """Both products behind the int8 covariance: the exact route (default: nine plane pairs + the fp64 remainder products wherever
-    the remainder lists fit) and the truncated five- / six-plane product with its bound (MDG_I8_NO_EXACT)."""
+    """Both products behind the int8 covariance: the exact route (MDG_I8_EXACT_ALWAYS: nine plane pairs + the fp64 remainder products
+    wherever the remainder lists fit; the default takes it for the six-plane class only) and the truncated five- / six-plane product
+    with its bound (MDG_I8_NO_EXACT)."""
     from modegpt_amd import ops as _ops
     monkeypatch.setattr(_ops, "I8_EXACT", request.param == "exact")
     return request.param
@@ -1053,7 +1054,7 @@ def test_exact_route_against_exact_integer_arithmetic(ops, dev, monkeypatch):
 
 def test_exact_route_gives_way_when_a_remainder_list_does_not_fit(ops, dev):
     """The exact route is an optimisation of the route kernel's decision, never a different answer: where one 32-column x 2048-token
-    segment holds more remainder elements than its list takes (2048 = 3.1 %) the call runs the truncated product it would have run
+    segment holds more remainder elements than its lists take (4 x 512 = 3.1 %) the call runs the truncated product it would have run
     anyway -- same planes, same columns, the bound of that product -- and the host model predicts which."""
     gen = torch.Generator().manual_seed(5)
     T, n = 6144, 256
@@ -1204,7 +1205,7 @@ def test_cov_i8_route_is_chosen_and_counted_on_the_device(ops, dev):
         assert torch.equal(S0, S1)
         counts = ops.i8_route_counts(dev)
         assert counts[route] == 2 and sum(v for r, v in counts.items() if r not in ("fp64_columns", "exact")) == 2 * (k + 1), counts
-        assert counts["exact"] == 2 * min(k + 1, 2)       # (the five- and the six-plane class both ran the exact route; the fallback did not)
+        assert counts["exact"] == (2 if k >= 1 else 0)    # (by default the six-plane class runs the exact route: the faster product there)
     S64 = torch.zeros(n, n, dtype=F64, device=dev)
     ops.cov_accum(S64, data["fallback_f64"].to(dev))
     assert torch.equal(S1, S64)                                        # the whole-statistic fallback IS the fp64 kernel
