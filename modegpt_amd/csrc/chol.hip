@@ -34,12 +34,10 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // X21 = -X22 (L21 X11), T = L21 X11 written over L21.  Panel solve, trailing update and both doubling products run as
 // 16 x 16 tiles on v_mfma_f64_16x16x4_f64 straight out of the LDS block (round 1 did them on the VALU, two LDS reads per
 // FMA, T through global memory: 157 us per block, of which the 8 serial 16 x 16 factorisations are ~36).
-__global__ __launch_bounds__(1024) void potrf_diag_kernel(double* A, int64_t lda, int nb, int64_t k0, double* inv,
-                                                          int* info) {
+// (a, xd, dinv: the workgroup's LDS -- NB * DP, NB and 16 * 17 doubles; 1024 threads)
+__device__ __forceinline__ void potrf_diag_block(double* A, int64_t lda, int nb, int64_t k0, double* inv, int* info, double* a, double* xd,
+                                                 double* dinv) {
   constexpr int PT = 1024, SB = 16;
-  __shared__ double a[NB * DP];        // lower: A then L;  strict upper: inv(L) transposed (X[i][j] at a[j][i])
-  __shared__ double xd[NB];            // diagonal of inv(L)
-  __shared__ double dinv[SB * (SB + 1)];  // inverse of the current 16x16 diagonal sub-block
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mi = lane & 15, kq = lane >> 4;   // v_mfma_f64_16x16x4_f64: A[mi][kq], B[kq][mi], D[kq + 4 reg][mi]
@@ -175,6 +173,13 @@ __global__ __launch_bounds__(1024) void potrf_diag_kernel(double* A, int64_t lda
   }
 }
 
+__global__ __launch_bounds__(1024) void potrf_diag_kernel(double* A, int64_t lda, int nb, int64_t k0, double* inv, int* info) {
+  __shared__ double a[NB * DP];        // lower: A then L;  strict upper: inv(L) transposed (X[i][j] at a[j][i])
+  __shared__ double xd[NB];            // diagonal of inv(L)
+  __shared__ double dinv[16 * 17];     // inverse of the current 16x16 diagonal sub-block
+  potrf_diag_block(A, lda, nb, k0, inv, info, a, xd, dinv);
+}
+
 // The two short products of an inner step, as LDS-resident 128 x 128 x 128 tiles (K = the 128 columns of block k):
 //   MODE 0, panel solve   L(i, k) = A(i, k) inv(L_kk)^T                         one workgroup per 128-row tile i, in place
 //   MODE 1, rank-128 update   A(i, c) -= L(i, k) L(c, k)^T   for the panel's remaining columns c    one workgroup per tile (i, c)
@@ -183,11 +188,18 @@ __global__ __launch_bounds__(1024) void potrf_diag_kernel(double* A, int64_t lda
 // general GEMM's tile code, bit for bit (scripts/probes/potrf_bits.py) -- but that kernel walks K in 8 serial 16-deep stages
 // behind an offset-table prologue: 38 us for the panel solve and 60 - 100 us for the update whatever their size, 2 x 191
 // launches on a layer's critical path.
+// MODE 1, look-ahead: the workgroup of the FIRST tile -- (k + 1, k + 1), the next diagonal block, which has all its updates once
+// this one is applied -- goes on to factorise and invert it (potrf_diag_block, the same arithmetic as the stand-alone kernel)
+// while the other tiles of the step are still being updated: next_nb > 0 says so, next_inv / info are the diagonal kernel's
+// outputs.  The 71 us of the 1-workgroup diagonal kernel leave the critical path wherever the update has more than one round of
+// tiles to work through (the caller then skips that launch).
 template <int MODE>
 __global__ __launch_bounds__(1024) void potrf_tile_kernel(double* A, int64_t lda, int64_t r0, int64_t nrows, int64_t k0, int64_t c0,
-                                                          int64_t ncols, const double* inv) {
+                                                          int64_t ncols, const double* inv, int next_nb, double* next_inv, int* info) {
   constexpr int PT = 1024, SB = 16;
   __shared__ double a[NB * DP];
+  __shared__ double la_xd[MODE == 1 ? NB : 1];
+  __shared__ double la_dinv[MODE == 1 ? 16 * 17 : 1];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mi = lane & 15, kq = lane >> 4;
@@ -253,6 +265,10 @@ __global__ __launch_bounds__(1024) void potrf_tile_kernel(double* A, int64_t lda
         const int row = (rt0 + t) * SB + kq + 4 * reg;
         if (row < nr && bcol < nc) C[(int64_t)row * lda + bcol] = -1.0 * acc[t][reg] + 1.0 * cold[t][reg];
       }
+    if (next_nb > 0 && blockIdx.x == 0) {   // tile (k + 1, k + 1) is final: factorise it here (uniform per workgroup)
+      __syncthreads();                      // every thread's part of the tile is in memory (and `a` is free again)
+      potrf_diag_block(A + row0 * lda + col0, lda, next_nb, row0, next_inv, info, a, la_xd, la_dinv);
+    }
   }
 }
 
@@ -342,6 +358,9 @@ __global__ __launch_bounds__(256) void lower_abs_rowsum_kernel(const double* X, 
 #ifndef MDG_CHOL_TILE_KERNELS
 #define MDG_CHOL_TILE_KERNELS 1   // panel solve and rank-128 update as LDS-resident 128^3 tiles (potrf_tile_kernel) instead of the general GEMM
 #endif
+#ifndef MDG_CHOL_LOOKAHEAD
+#define MDG_CHOL_LOOKAHEAD 1      // the update launch of step k factorises diagonal block k + 1 in its first workgroup (see potrf_tile_kernel)
+#endif
 #ifndef MDG_CHOL_NBO
 #define MDG_CHOL_NBO 1024   // (512: 63.0 + 72.2 ms for the ridge scores + Nystrom solve of a Llama-3-8B layer; 1024: 62.5 + 69.7; 256: 66.4 + 76.3)
 #endif
@@ -353,10 +372,12 @@ int potrf_lower(double* A, int64_t n, int64_t lda, double* inv_diag, hipStream_t
   MDG_HIP(hipMemsetAsync(dflag, 0, sizeof(int), st));
   for (int64_t J0 = 0; J0 < n; J0 += NBO) {
     const int64_t Jend = J0 + NBO < n ? J0 + NBO : n;
+    bool diag_done = false;     // block k0 was factorised by the previous step's update launch (look-ahead)
     for (int64_t k0 = J0; k0 < Jend; k0 += NB) {
       const int nb = (int)(n - k0 < NB ? n - k0 : NB);
       double* inv = inv_diag + (k0 / NB) * NB * NB;
-      hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(1024), 0, st, A + k0 * lda + k0, lda, nb, k0, inv, dflag);
+      if (!diag_done) hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(1024), 0, st, A + k0 * lda + k0, lda, nb, k0, inv, dflag);
+      diag_done = false;
       MDG_LAUNCH_CHECK();
       const int64_t rest = n - k0 - nb;
       if (rest <= 0) break;
@@ -366,10 +387,13 @@ int potrf_lower(double* A, int64_t n, int64_t lda, double* inv_diag, hipStream_t
       // L21 = A21 * inv(L11)^T, then the rank-128 update of the remaining columns of this outer panel only (nb == 128 here: a
       // ragged block is the last one and has nothing below it)
       hipLaunchKernelGGL(potrf_tile_kernel<0>, dim3((unsigned)ceil_div(rest, NB)), dim3(1024), 0, st, A, lda, k0 + nb, rest, k0,
-                         (int64_t)0, (int64_t)0, inv);
-      if (w > 0)
+                         (int64_t)0, (int64_t)0, inv, 0, (double*)nullptr, (int*)nullptr);
+      if (w > 0) {   // (then k0 + nb < Jend: the next block belongs to this outer panel and is final after this update)
+        const int next_nb = (int)(n - (k0 + nb) < NB ? n - (k0 + nb) : NB);
         hipLaunchKernelGGL(potrf_tile_kernel<1>, dim3((unsigned)(ceil_div(rest, NB) * ceil_div(w, NB))), dim3(1024), 0, st, A, lda,
-                           k0 + nb, rest, k0, k0 + nb, w, inv);
+                           k0 + nb, rest, k0, k0 + nb, w, inv, MDG_CHOL_LOOKAHEAD ? next_nb : 0, inv + NB * NB, dflag);
+        diag_done = MDG_CHOL_LOOKAHEAD != 0;
+      }
       MDG_LAUNCH_CHECK();
 #else
       // L21 = A21 * inv(L11)^T  (in place: one tile column, each workgroup reads only its own rows)
