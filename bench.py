@@ -82,7 +82,7 @@ class LaunchTimer:
         for i, (cnt, e0, e1) in enumerate(self.pairs):
             p = planes_per_batch[i % nb]
             if p:
-                priced.append((cnt * (p * (p + 1) // 2), e0, e1))
+                priced.append((cnt * {3: 9, 5: 15, 6: 21}[p], e0, e1))
         self.pairs = priced
 
     def run_decomposition(self, flops, fn):
@@ -506,7 +506,7 @@ def main():
         for b in batches:
             info = {}
             cls = ops.cov_accum_i8(replay, b["h"], mfma_stats=stats, route_info=info)
-            planes_per_batch.append(5 if (cls and info["exact"]) else cls)       # (the product kernel that ran: the exact route uses the five-plane one)
+            planes_per_batch.append(3 if (cls and info["exact"]) else cls)       # (the product kernel that ran: 3 = the exact route's nine-pair launch)
             bounds.append(info)
         ops.I8_STATS.update(routes_before)
         del replay
@@ -677,14 +677,21 @@ def main():
                 gated.append({"h": g.to(torch.bfloat16), "x": bt["x"], "q": bt["q"], "k": bt["k"]})
                 del g
             out["value_gated"] = extra_leg(shape, adapter, leg_ids, gated, a.keep, n_texts, pipelined, dev, tokens)
-            # (2b) the same data with the route's tolerance factor at 64 x the headline's (an argument of every call, ABI 9; here the
-            #      thread's default for the block): what a caller who accepts 64x the guarantee gets -- five planes, the bound the
-            #      calls then compute and keep.  The scope ends with the block: every other leg runs at the headline's factor.
-            with ops.i8_tolerance_scope(64.0 * tol):
-                loose = extra_leg(shape, adapter, leg_ids[:max(1, len(leg_ids) // 2)], gated, a.keep, n_texts, pipelined, dev, tokens)
-            out["value_gated"]["tolerance_x64"] = {k: loose[k] for k in ("value", "ms_per_step", "steps", "planes", "avg_launch_ms", "error_bound")}
-            out["value_gated"]["tolerance_x64"]["factor"] = 64.0 * tol
-            out["value_gated"]["tolerance_x64"]["fp64_columns_mlp"] = len(loose["fp64_columns_mlp"] or [])
+            # (2b) the same data on the TRUNCATED product (MDG_I8_NO_EXACT: six planes, 15.1 executed plane pairs, the bound of round 3) --
+            #      what the exact route replaced -- and that product with the tolerance factor at 64 (five planes + two columns on the
+            #      fp64 column kernel; the factor does nothing on the exact route, which drops no plane pair)
+            exact_before = ops.I8_EXACT
+            ops.I8_EXACT = False
+            try:
+                half = leg_ids[:max(1, len(leg_ids) // 2)]
+                trunc = extra_leg(shape, adapter, half, gated, a.keep, n_texts, pipelined, dev, tokens)
+                with ops.i8_tolerance_scope(64.0 * tol):
+                    loose = extra_leg(shape, adapter, half, gated, a.keep, n_texts, pipelined, dev, tokens)
+            finally:
+                ops.I8_EXACT = exact_before
+            keys = ("value", "ms_per_step", "steps", "planes", "avg_launch_ms", "whole_call_ms", "error_bound")
+            out["value_gated"]["truncated_product"] = {k: trunc[k] for k in keys}
+            out["value_gated"]["truncated_product"]["tolerance_x64"] = {k: loose[k] for k in keys}
             del gated
             # (3) massive activations: four BOS-like columns (bulk 12-15 binades under three spikes per batch) in the residual
             #     stream statistic AND in the MLP statistic -- they leave the int8 launch alone, through the fp64 column kernel
@@ -837,8 +844,8 @@ def extra_leg(shape, adapter, ids, data, keep, n_texts, pipelined, dev, tokens):
     frac = st6["executed"] / st6["dense"] if st6.get("dense") else 1.0
     used_class = used
     if used and info.get("exact"):
-        used = 5                                             # (the exact route: the five-plane kernel on three dense planes + the remainder kernel)
-    pairs = {5: 15, 6: 21}.get(used, 15)
+        used = 3                                             # (the exact route: the nine-pair launch of the three top planes + the remainder kernel)
+    pairs = {3: 9, 5: 15, 6: 21}.get(used, 15)
     tops_dense = pairs * nl * tokens * f * (f + 1) / (msl * 1e-3) / 1e12
     return {"value": len(ids) / sec, "ms_per_step": sec / len(ids) * 1e3, "steps": len(ids), "planes": used_class, "exact_route": bool(info.get("exact")),
             "avg_launch_ms": msl / nl, "whole_call_ms": whole_call_ms,

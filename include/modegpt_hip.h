@@ -140,12 +140,12 @@ int mdg_cov_accum_multi(int n, const mdg_cov_problem* problems, int dtype, void*
  * ev_start / ev_stop: optional hipEvent_t recorded on `stream` right before / after the two product launches (bench.py times
  * the dominant kernel alone with them); NULL otherwise. */
 /* THE EXACT ROUTE (since ABI 9.  flags = 0: taken where it is the faster product -- launches the route kernel classes as six planes,
- * i.e. SiLU- / GELU-gated MLP activations; MDG_I8_EXACT_ALWAYS: for five-plane launches too (+3 % of the call for an error at fp64
- * rounding level instead of the truncated product's bound); MDG_I8_NO_EXACT: never).  Planes 3 .. 5 are reached only by elements 17
+ * i.e. SiLU- / GELU-gated MLP activations, and five-plane launches whose first statistic has >= 8192 features; MDG_I8_EXACT_ALWAYS:
+ * wherever the remainder lists fit; MDG_I8_NO_EXACT: never).  Planes 3 .. 5 are reached only by elements 17
  * binades and more below their column's maximum -- 3e-5 of the elements of a Gaussian column, 0.5 % of a SiLU-gated one -- so the
  * call lists those elements (token, column, low 24 bits) and, when every list fits (at most 3.1 % of any 32 columns x 2048 tokens),
  * replaces the truncated product by an exact one:  X^T X = X_d^T X_d + X_lo^T X + X_d^T X_lo  with X_d the top three digit planes --
- * all NINE of their plane pairs on the int8 matrix cores (the five-plane kernel with the deeper planes masked off) -- and the two
+ * all NINE of their plane pairs on the int8 matrix cores (a product launch of its own: three planes, no piece masks) -- and the two
  * remainder products as fp64 sums over the listed elements (i8_lo_product_kernel).  No plane pair is dropped: the error is fp64
  * rounding (<= MDG_I8_EXACT_ROUNDING of sqrt(sigma_ii sigma_jj)) plus the bound's rho term for elements more than 38 binades under
  * their column maximum, whatever `tolerance` says; 9 executed plane pairs instead of 9.4 (Gaussian) / 15.1 (SiLU-gated).  The route

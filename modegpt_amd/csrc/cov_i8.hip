@@ -769,12 +769,14 @@ __device__ __forceinline__ int launch_route(const SyrkArgs& a, int& live, int& f
 __device__ __forceinline__ bool exact_route(const SyrkArgs& a) {
   return a.exact_state && a.exact_state[1] == 1 && a.exact_state[0] == 0;
 }
-// Does the P-plane product launch of this call do the work?  (0: no; 1: legacy route; 2: the exact route -- P = 5 only)
+// Does the P-plane product launch of this call do the work?  (0: no; 1: the truncated product of P planes; 2: the exact route --
+// P = 3: the launch of the three top planes, all nine pairs)
 template <int P>
 __device__ __forceinline__ int product_launch_runs(const SyrkArgs& a, int& live, int& fallbacks) {
   const int route = launch_route(a, live, fallbacks);
   if (route < 0) return 0;
-  if (exact_route(a)) return P == 5 ? 2 : 0;
+  if (exact_route(a)) return P == 3 ? 2 : 0;
+  if (P == 3) return 0;
   return route == (P == 5 ? 0 : 1) ? 1 : 0;
 }
 
@@ -823,8 +825,24 @@ constexpr int PERSISTENT_MIN_ROWS = 16;   // statistics of at least this many 12
 constexpr int DEFER5 = 4;             // MFMAs a loads-first wave of the five-plane kernel holds back across the barrier (0: 25.3, 2: 26.0, 3: 24.9, 4: 24.6, 5: 25.0, 6: 27.8 ms per call)
 constexpr int NW = 8;                 // waves per workgroup
 constexpr int RING5 = 3;              // LDS stages of the five-plane kernel (six planes: 4)
-constexpr bool wide_tile(int planes) { return planes == 5; }   // 128 x 128 tiles (six planes: 128 x 64)
-constexpr int ring_depth(int planes) { return wide_tile(planes) ? RING5 : 4; }
+// (measured at the sigma_mlp shape, Gaussian / SiLU-gated columns, product launch alone: three stages without fragment prefetch
+//  19.5 / 20.3 ms; four stages 19.6 / 20.4; fragment prefetch with four, five or six stages 39 - 40 ms -- hipcc then keeps two sets
+//  of fragments beside the 160 accumulators and spills inside the loop.  The five-plane kernel with the deeper planes masked off,
+//  which this instantiation replaced: 20.6 / 21.5 ms; the truncated five- / six-plane products: 21.4 / 35.5 ms.)
+#ifndef MDG_I8_RING3
+#define MDG_I8_RING3 3
+#endif
+#ifndef MDG_I8_PREFETCH3
+#define MDG_I8_PREFETCH3 0
+#endif
+constexpr int RING3 = MDG_I8_RING3;   // LDS stages of the three-plane (exact route) kernel: 24 KB each
+constexpr bool wide_tile(int planes) { return planes != 6; }   // 128 x 128 tiles (six planes: 128 x 64)
+constexpr int ring_depth(int planes) { return planes == 3 ? RING3 : wide_tile(planes) ? RING5 : 4; }
+// fragments of the next k-step read right behind this step's MFMAs (needs a stage that is complete a barrier early: RING >= 4)
+constexpr bool prefetch_frags(int planes) { return planes == 3 ? (MDG_I8_PREFETCH3 != 0 && RING3 >= 4) : !wide_tile(planes); }
+// P = 3 is the product of the EXACT route: planes 0 .. 2 only, ALL nine plane pairs (classes 0 .. 4), no piece masks -- the same tile
+// code with nothing conditional left in the k-step (24 KB stages, 36 fragment registers beside the 160 accumulators)
+constexpr int classes_of(int planes) { return planes == 3 ? 5 : planes; }
 
 // One output tile (bi, bj) of the lower region: bi = 128-row block, bj = TJ-row block (bj <= bi for 128 x 128 tiles, bj <= 2 bi + 1
 // for 128 x 64); the k-steps [kb, ke), then the fold: element (row, col) of the statistic goes to
@@ -842,7 +860,8 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
   constexpr int STAGE_BYTES = P * (PA + PB);       // 40 KB (P = 5, 128 x 128) / 36 KB (P = 6, 128 x 64)
   constexpr int PIECES = (GA + GB) * P;            // 1 KB pieces per stage
   constexpr int RING = ring_depth(P);              // LDS stages
-  constexpr bool PREFETCH = !wide_tile(P);         // the next step's fragments are read before the barrier (needs RING = 4)
+  constexpr bool PREFETCH = prefetch_frags(P);     // the next step's fragments are read before the barrier (needs RING >= 4)
+  constexpr int NCLS = classes_of(P);              // digit classes s + t kept: 0 .. NCLS - 1
   // the wave index through readfirstlane: hipcc then knows it is wave-uniform and the staging code becomes scalar (SGPR piece
   // addresses, s_cbranch on the piece tests, M0 from SGPRs) instead of exec-masked branches with a v_readfirstlane per piece
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -854,7 +873,7 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
   // staging: (GA + GB) P pieces of 1 KB per stage (A: P planes x 4 row groups, B: P planes x 2 or 4); wave w issues pieces w, w + NW, ...
   // mA / mB: piece masks of the stage's A and B row groups, one byte per 32-row group; planes at or beyond a group's depth
   // (group_depth below) are all-zero there in this k-step and are neither loaded nor multiplied
-  constexpr int MIN_DEPTH = P - 2;   // planes below this are always staged and multiplied (3 of five, 4 of six)
+  constexpr int MIN_DEPTH = P == 3 ? 3 : P - 2;   // planes below this are always staged and multiplied (3 of five, 4 of six; all three of three)
   static_assert(MIN_DEPTH <= ALWAYS_WRITTEN_PLANES, "the split pass leaves all-zero pieces of the deeper planes unwritten");
   auto group_depth = [&](unsigned m, int g) {   // 1 + deepest plane with a nonzero in group g, but at least MIN_DEPTH
     const unsigned byte = (m >> (8 * g)) & 0xFFu;
@@ -901,9 +920,9 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
     }
   };
 
-  i32x16 acc[P][WB];
+  i32x16 acc[NCLS][WB];
 #pragma unroll
-  for (int k = 0; k < P; k++)
+  for (int k = 0; k < NCLS; k++)
 #pragma unroll
     for (int b = 0; b < WB; b++) acc[k][b] = (i32x16)0;
 
@@ -936,14 +955,14 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
         const int off = (reg & 3) + 8 * (reg >> 2);
         double v = 0.;
 #pragma unroll
-        for (int k = P - 1; k >= 0; k--) v += ldexp((double)acc[k][b][reg], 80 - 8 * k);
+        for (int k = NCLS - 1; k >= 0; k--) v += ldexp((double)acc[k][b][reg], 80 - 8 * k);
         // rows and columns the route handed to the fp64 column kernel are not ours: their digit products are computed and dropped
         if (col <= row0 + b * 32 + off && !((e_col | er[reg]) & EMAX_COLUMN_OUT))
           p[(int64_t)off * fold_ld] = old[reg] + v * sc_j * ldexp(1.0, (er[reg] & 255) - 172);
       }
     }
 #pragma unroll
-    for (int k = 0; k < P; k++)
+    for (int k = 0; k < NCLS; k++)
 #pragma unroll
       for (int b = 0; b < WB; b++) acc[k][b] = (i32x16)0;
     // the stores above share the VM counter with the LDS-DMA loads: drain, so that the loop's waits see stage loads only
@@ -953,6 +972,7 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
   // piece masks: uniform-address loads; issued together with a stage's loads, for the stage after it
   const int64_t mgroups = pr.n / 32;
   auto load_masks = [&](int kt, unsigned& va, unsigned& vb) {
+    if (P == 3) return;                      // (every piece of the three planes is staged: no masks)
     const unsigned* z = (const unsigned*)(pr.zmask + (int64_t)kt * mgroups);   // n / 32 is a multiple of 4: dword-aligned rows
     va = z[bi];                                                               // groups 4 bi .. 4 bi + 3
     vb = TJ == 128 ? z[bj] : z[bj >> 1];   // groups 4 bj .. + 3; or 2 bj, 2 bj + 1 in one half of the dword (see b_half)
@@ -1036,7 +1056,7 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
     }
     executed += deep_mfmas;
   };
-  constexpr int UNCOND_PAIRS = P == 5 ? 9 : (MIN_DEPTH == 4 ? 15 : 21);   // pairs (s, t), s, t < MIN_DEPTH, s + t < P
+  constexpr int UNCOND_PAIRS = P == 6 ? 15 : 9;   // pairs (s, t), s, t < MIN_DEPTH, s + t < NCLS
   constexpr int N_UNCOND = UNCOND_PAIRS * WB;                               // unconditional MFMAs per wave and k-step
   // of them, held back across the barrier by the loads-first waves (six planes: none -- 37.2 ms per call without, 55 ms with 3 - 5
   // deferred: the loads-first waves then lose their fragment prefetch)
@@ -1079,7 +1099,7 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
         for (int s = 0; s < MIN_DEPTH; s++)
 #pragma unroll
           for (int t = 0; t < MIN_DEPTH; t++)
-            if (s + t < P) {
+            if (s + t < NCLS) {
 #pragma unroll
               for (int b = 0; b < WB; b++) {
                 if (idx >= lo && idx < hi) acc[s + t][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s][b], fb[t], acc[s + t][b], 0, 0, 0);
@@ -1128,7 +1148,7 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
       for (int s = 0, idx = 0; s < MIN_DEPTH; s++)
 #pragma unroll
         for (int t = 0; t < MIN_DEPTH; t++)
-          if (s + t < P) {
+          if (s + t < NCLS) {
 #pragma unroll
             for (int b = 0; b < WB; b++) {
               if (idx >= N_UNCOND - DEFER) acc[s + t][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s][b], fb[t], acc[s + t][b], 0, 0, 0);
@@ -1171,7 +1191,7 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
   constexpr int STAGE_BYTES = P * (PA + PB);       // 40 KB (P = 5, 128 x 128) / 36 KB (P = 6, 128 x 64)
   constexpr int PIECES = (GA + GB) * P;            // 1 KB pieces per stage
   constexpr int RING = ring_depth(P);              // LDS stages
-  constexpr bool PREFETCH = !wide_tile(P);         // the next step's fragments are read before the barrier (needs RING = 4)
+  constexpr bool PREFETCH = prefetch_frags(P);     // the next step's fragments are read before the barrier (needs RING >= 4)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   // The route is chosen on the DEVICE: mdg_cov_accum_i8 enqueues the five-plane product, the six-plane product and the fp64
   // kernel back to back, and each exits at once unless the depth statistic of this call (i8_depth_kernel) selects it -- the
@@ -1193,7 +1213,6 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
         atomicAdd(a.route_counts + (P == 5 ? 0 : 1), live);
       }
     }
-    if (runs == 2) mask_and = 0x07070707u;
   }
   unsigned executed = 0;
   const int lane = threadIdx.x & 63;
@@ -1248,7 +1267,7 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
     // each distinct panel row through that L2 once.  Super-blocks (R, C), C <= R, cover the lower region; tiles of a diagonal
     // super-block that lie above it exit at once.
     int bi, bj;
-    constexpr int SI = P == 5 ? SB5 : SB6;   // super-block: SI x SI (or SI x 2 SI) tiles
+    constexpr int SI = P == 6 ? SB6 : SB5;   // super-block: SI x SI (or SI x 2 SI) tiles
     {
       constexpr int TPS = TJ == 128 ? SI * SI : SI * 2 * SI;   // tiles per super-block
       constexpr int SJ = TJ == 128 ? SI : 2 * SI;              // tile columns of a super-block
@@ -1469,10 +1488,14 @@ struct LoArgs {
 };
 __device__ __forceinline__ int* lo_totals(const LoProblem& pr, int nch) { return pr.counts + (int64_t)(pr.n / 32) * LO_SUB * nch; }
 // Is the exact route on offer for this launch?  Always when the caller asks for it; by default where it is the faster product:
-// launches of the six-plane class (9 executed plane pairs + the remainder kernel against 15.1; a five-plane launch executes 9.4
-// and would pay the remainder kernel's fixed cost for an accuracy nobody asked for).
+// launches of the six-plane class (9 executed plane pairs + the remainder kernel against 15.1), and five-plane launches of a large
+// statistic (9 against 9.4 pairs on a kernel without masks or conditional blocks: 21.6 against 22.2 ms per sigma_mlp call on
+// Gaussian columns) -- below LO_AUTO_MIN_N features the remainder kernel's fixed costs (a workgroup per tile, two list walks, one
+// fold) outweigh 0.4 plane pairs.
+constexpr int LO_AUTO_MIN_N = 8192;
 __device__ __forceinline__ bool lo_offered(const LoArgs& a) {
   if (a.always) return true;
+  if (a.prob[0].n >= LO_AUTO_MIN_N && !a.prob[0].block) return true;
   for (int p = 0; p < a.nprob; p++)
     if ((a.route_flag[p] & 3) == 1) return true;
   return false;
@@ -2044,11 +2067,12 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
   }
   a.partial = partial;
   if (ev_start) MDG_HIP(hipEventRecord((hipEvent_t)ev_start, st));
-  for (int planes_used = 5; planes_used <= 6; planes_used++) {
+  for (int planes_used : {3, 5, 6}) {       // 3: the exact route's product (the three top planes, all nine pairs)
+    if (planes_used == 3 && !offer_exact) continue;
     const bool wide = wide_tile(planes_used);                                  // 128 x 128 tiles; six planes: 128 x 64
     const int tj = wide ? 128 : 64;
     const size_t lds = (size_t)ring_depth(planes_used) * planes_used * (PA + tj * KS);
-    const int si = planes_used == 5 ? SB5 : SB6;                               // super-block rows (see the kernel)
+    const int si = planes_used == 6 ? SB6 : SB5;                               // super-block rows (see the kernel)
     const int sr = (rb + si - 1) / si, nsb = sr * (sr + 1) / 2;                // super-block rows, super-blocks
     const int tps = wide ? si * si : 2 * si * si;                              // tiles per super-block
     dim3 grid((unsigned)((nsb + 7) / 8 * 8 * tps));
@@ -2062,7 +2086,11 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
       a.ngroups = sch->ngroups;
       grid = dim3(256);
     }
-    if (planes_used == 6) {
+    if (planes_used == 3) {
+      MDG_HIP(hipFuncSetAttribute((const void*)i8_syrk_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((i8_syrk_kernel<3>), grid, dim3(64 * NW), lds, st, a);
+      if (sch && sch->n_tail) hipLaunchKernelGGL((i8_tail_combine_kernel<3>), dim3(sch->n_tail * (TI * tj / COMBINE_ELEMS)), dim3(256), 0, st, a, sch->n_tail);
+    } else if (planes_used == 6) {
       MDG_HIP(hipFuncSetAttribute((const void*)i8_syrk_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL((i8_syrk_kernel<6>), grid, dim3(64 * NW), lds, st, a);
       if (sch && sch->n_tail) hipLaunchKernelGGL((i8_tail_combine_kernel<6>), dim3(sch->n_tail * (TI * tj / COMBINE_ELEMS)), dim3(256), 0, st, a, sch->n_tail);

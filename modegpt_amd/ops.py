@@ -152,7 +152,7 @@ def cov_accum_i8(sigma: torch.Tensor, x: torch.Tensor, events=None, mfma_stats: 
         if mfma_stats is not None and used.value in (5, 6):
             done = C.c_ulonglong(0)
             check(lib.mdg_cov_accum_i8_stats(wsp, x2.shape[0], n, C.byref(done), _stream(x)), "mdg_cov_accum_i8_stats")
-            ran = 5 if info["exact"] else used.value           # (the exact route runs the five-plane kernel, deeper planes masked off)
+            ran = 3 if info["exact"] else used.value           # (the exact route: the three-plane product launch, all nine pairs)
             mfma_stats["executed"] = mfma_stats.get("executed", 0) + done.value
             mfma_stats["dense"] = mfma_stats.get("dense", 0) + i8_dense_mfma_count(x2.shape[0], n, ran)
             mfma_stats["planes_run"] = ran
@@ -175,9 +175,9 @@ def _read_route(lib, count, arr, stat, wsp, stream) -> dict:
 
 
 # The exact route of the int8 covariance (include/modegpt_hip.h, "THE EXACT ROUTE"): "auto" (default) takes it where it is the
-# faster product -- launches of the six-plane class: the MLP statistic of a gated model; "always" (True) wherever the remainder lists
-# fit (fp64-rounding accuracy for every int8 statistic, +3 % on a five-plane call); "never" (False) keeps every call on the
-# truncated five- / six-plane product with its bound.  Environment: MODEGPT_I8_EXACT=auto|1|0.
+# faster product -- launches of the six-plane class (the MLP statistic of a gated model) and five-plane launches of a statistic of
+# 8192 features and more; "always" (True) wherever the remainder lists fit (fp64-rounding accuracy for every int8 statistic);
+# "never" (False) keeps every call on the truncated five- / six-plane product with its bound.  MODEGPT_I8_EXACT=auto|1|0.
 I8_EXACT = {"1": True, "always": True, "0": False, "never": False}.get(os.environ.get("MODEGPT_I8_EXACT", "auto").lower(), "auto")
 
 
@@ -235,7 +235,7 @@ def cov_accum_i8_multi(items, events=None, mfma_stats: Optional[dict] = None, re
         if mfma_stats is not None and used.value in (5, 6):
             done = C.c_ulonglong(0)
             check(lib.mdg_cov_accum_i8_stats(wsp, 0, 0, C.byref(done), _stream(keep[0])), "mdg_cov_accum_i8_stats")
-            ran = 5 if any(i_["exact"] for i_ in infos) else used.value
+            ran = 3 if any(i_["exact"] for i_ in infos) else used.value
             mfma_stats["executed"] = mfma_stats.get("executed", 0) + done.value
             mfma_stats["dense"] = mfma_stats.get("dense", 0) + sum(i8_dense_mfma_count(t, f, ran, h) for t, f, h in dense_shapes)
             mfma_stats["planes_run"] = ran
@@ -328,8 +328,8 @@ def i8_dense_mfma_count(n_tokens: int, n: int, planes: int, n_heads: int = 1) ->
     if n_heads > 1:
         blocks = n_heads * 16
     else:
-        blocks = rb * (rb + 1) // 2 * 16 if planes == 5 else rb * (rb + 1) * 8
-    return blocks * nk * (planes * (planes + 1) // 2)
+        blocks = rb * (rb + 1) * 8 if planes == 6 else rb * (rb + 1) // 2 * 16
+    return blocks * nk * {3: 9, 5: 15, 6: 21}[planes]       # (3: the exact route's product -- three planes, all nine pairs)
 
 
 # Which matrix cores accumulate the large covariances of a layer: "f64" (v_mfma_f64, the accumulation order of the

@@ -35,4 +35,4 @@ for name, X in (("gaussian", gaussian(1)), ("silu_gated", gated(2))):
         e1.record(); torch.cuda.synchronize()
         # (the product-launch events hold the LAST call's; time that one alone as well)
         print(f"{name:11s} exact={exact!s:5s} class {cls} exact_ran={info['exact']!s:5s} whole call {e0.elapsed_time(e1) / reps:7.3f} ms   "
-              f"product launches (last call) {k0.elapsed_time(k1):7.3f} ms   executed/dense {st['executed'] / st['dense']:.3f} of {st['planes_run']}-plane pairs   bound {info['bound']:.2e}")
+              f"product launches (last call) {k0.elapsed_time(k1):7.3f} ms   executed/dense {st['executed'] / st['dense']:.3f} of the {st['planes_run']}-plane launch's pairs   bound {info['bound']:.2e}")
