@@ -518,7 +518,7 @@ def main():
     # HBM bytes per launch come from a separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run of the same kernel on the
     # same launch shape (PMC passes cannot ride along a timed run); only valid for the default workload.
     traffic, tfile = None, None
-    for cand in (("r03_cov_i8_hbm_traffic.json", "r02_cov_i8_hbm_traffic.json") if i8 else ("r01_cov_hbm_traffic.json",)):
+    for cand in (("r04_cov_i8_hbm_traffic.json", "r03_cov_i8_hbm_traffic.json") if i8 else ("r01_cov_hbm_traffic.json",)):
         tpath = os.path.join(ROOT, "profiles", cand)
         if os.path.exists(tpath) and a.model == "llama-3-8b" and a.batch_size == 16:
             with open(tpath) as f:
@@ -568,6 +568,9 @@ def main():
                             "fp64_columns_per_batch_max": max(len(b_["columns"]) for b_ in bounds)}}
     if i8:
         out["roofline"]["i8_tolerance_factor"] = tol
+        if bounds and all(b_["exact"] for b_ in bounds):     # the headline's sigma_mlp calls ran the exact route: no plane pair dropped
+            out["dtype"] = ("f64 from int8 MFMA digit planes, exact route: nine plane pairs + fp64 remainder sums, nothing truncated "
+                            f"(error <= {max(b_['bound'] for b_ in bounds):.1g} per call: fp64 rounding)")
     if selection:
         out["selection_certificate"] = summarise_selection(selection)
     if not pipelined:          # (beside the covariance its events also time the waits for CUs: reported from the sequential leg below instead)
