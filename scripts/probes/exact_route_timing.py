@@ -1,5 +1,5 @@
 """Whole-call time of the int8 covariance at the sigma_mlp shape (32768 x 14336), exact route against the truncated product,
-Gaussian and SiLU-gated columns.    python scripts/probes/exact_route_timing.py [n=14336] [tokens=32768]"""
+Gaussian and SiLU-gated columns.    python scripts/probes/exact_route_timing.py [n=14336] [tokens=32768] [gaussian|silu_gated] [exact|truncated]"""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -16,8 +16,13 @@ def gated(seed):
     a = torch.nn.functional.silu(torch.randn(T, n, device=dev, generator=g)); a.mul_(torch.randn(T, n, device=dev, generator=g))
     return a.to(torch.bfloat16)
 S = torch.zeros(n, n, dtype=F64, device=dev)
-for name, X in (("gaussian", gaussian(1)), ("silu_gated", gated(2))):
-    for exact in (True, False):
+only = sys.argv[3] if len(sys.argv) > 3 else None
+routes = {"exact": (True,), "truncated": (False,)}.get(sys.argv[4] if len(sys.argv) > 4 else None, (True, False))
+for name, make, seed in (("gaussian", gaussian, 1), ("silu_gated", gated, 2)):
+    if only not in (None, name):
+        continue
+    X = make(seed)
+    for exact in routes:
         ops.I8_EXACT = exact
         info, st = {}, {}
         cls = ops.cov_accum_i8(S, X, route_info=info, mfma_stats=st)
