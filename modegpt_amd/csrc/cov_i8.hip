@@ -835,7 +835,20 @@ constexpr int RING5 = 3;              // LDS stages of the five-plane kernel (si
 #ifndef MDG_I8_PREFETCH3
 #define MDG_I8_PREFETCH3 0
 #endif
-constexpr int RING3 = MDG_I8_RING3;   // LDS stages of the three-plane (exact route) kernel: 24 KB each
+constexpr int RING3 = MDG_I8_RING3;   // LDS stages of the three-plane (exact route) kernel: 24 KB per k-step each
+// k-steps per LDS stage, i.e. per workgroup barrier (three planes only: nothing in that k-step is conditional).  The loads of a stage
+// are the same 1 KB pieces, twice as many per issue; what halves is the number of barriers and role switches per MFMA.
+// Measured at the sigma_mlp shape, Gaussian columns, product launch alone, one box (scripts/probes/p3_variants.sh,
+// profiles/r04_p3_variants.log): one k-step per stage (ring of 3, 4 deferred MFMAs) 19.37 ms; two k-steps (ring of 3 x 48 KB) with
+// 0 / 2 / 4 / 6 / 8 / 10 / 12 / 14+ deferred 19.47 / 19.21 / 18.98 / 18.73 / 18.56 / 20.2 / 21.3 / 23.2; three k-steps in a ring of
+// two 20.04.
+#ifndef MDG_I8_KSS3
+#define MDG_I8_KSS3 2
+#endif
+#ifndef MDG_I8_DEFER3
+#define MDG_I8_DEFER3 8     // MFMAs a loads-first wave of the three-plane kernel holds back across the barrier (see DEFER5)
+#endif
+constexpr int steps_per_stage(int planes) { return planes == 3 ? MDG_I8_KSS3 : 1; }
 constexpr bool wide_tile(int planes) { return planes != 6; }   // 128 x 128 tiles (six planes: 128 x 64)
 constexpr int ring_depth(int planes) { return planes == 3 ? RING3 : wide_tile(planes) ? RING5 : 4; }
 // fragments of the next k-step read right behind this step's MFMAs (needs a stage that is complete a barrier early: RING >= 4)
@@ -857,10 +870,13 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
   constexpr int PB = TJ * KS;
   constexpr int GA = TI / 32, GB = TJ / 32;        // 32-row groups (1 KB pieces per plane and stage) of the two operands
   constexpr int WCOLS = TJ / 32;
-  constexpr int STAGE_BYTES = P * (PA + PB);       // 40 KB (P = 5, 128 x 128) / 36 KB (P = 6, 128 x 64)
-  constexpr int PIECES = (GA + GB) * P;            // 1 KB pieces per stage
+  constexpr int KSS = steps_per_stage(P);          // k-steps per stage (per barrier)
+  constexpr int STEP_BYTES = P * (PA + PB);        // 40 KB (P = 5, 128 x 128) / 36 KB (P = 6, 128 x 64) / 24 KB (P = 3)
+  constexpr int STAGE_BYTES = KSS * STEP_BYTES;
+  constexpr int PIECES = (GA + GB) * P;            // 1 KB pieces per k-step
   constexpr int RING = ring_depth(P);              // LDS stages
   constexpr bool PREFETCH = prefetch_frags(P);     // the next step's fragments are read before the barrier (needs RING >= 4)
+  static_assert(KSS == 1 || (P == 3 && !PREFETCH), "several k-steps per stage: the unconditional three-plane k-step only");
   constexpr int NCLS = classes_of(P);              // digit classes s + t kept: 0 .. NCLS - 1
   // the wave index through readfirstlane: hipcc then knows it is wave-uniform and the staging code becomes scalar (SGPR piece
   // addresses, s_cbranch on the piece tests, M0 from SGPRs) instead of exec-masked branches with a v_readfirstlane per piece
@@ -909,14 +925,18 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
   auto issue_stage = [&](int kt, int buf, unsigned mA, unsigned mB) {
     const unsigned long long m64 = ((unsigned long long)mB << 32) | mA;
     const unsigned lbase = __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_BYTES);   // (wave-uniform; says so to the compiler)
-    const unsigned voff = lane16 + (unsigned)kt * 1024u;
 #pragma unroll
-    for (int q = 0; q < NQ; q++) {
-      if (!pc_valid[q]) continue;
-      const unsigned present = ((unsigned)(m64 >> pc_shift[q]) & pc_cmask[q]) | pc_force[q];
-      if (present)   // (an all-zero piece is not loaded: nothing will read it)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lbase + pc_loff[q]), "v"(voff), "s"(pc_base[q])
-                     : "memory");   // (M0 is written; nothing the compiler emits in this kernel reads it)
+    for (int kk = 0; kk < KSS; kk++) {
+      if (KSS > 1 && kt + kk >= ke) break;   // (the last stage of a tile or k-chunk may hold fewer k-steps)
+      const unsigned voff = lane16 + (unsigned)(kt + kk) * 1024u;
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        if (!pc_valid[q]) continue;
+        const unsigned present = ((unsigned)(m64 >> pc_shift[q]) & pc_cmask[q]) | pc_force[q];
+        if (present)   // (an all-zero piece is not loaded: nothing will read it)
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lbase + kk * STEP_BYTES + pc_loff[q]), "v"(voff), "s"(pc_base[q])
+                       : "memory");   // (M0 is written; nothing the compiler emits in this kernel reads it)
+      }
     }
   };
 
@@ -993,16 +1013,16 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
   for (int i = 0; i <= D; i++) mA[i] = mB[i] = ~0u;
 #pragma unroll
   for (int i = 0; i < D; i++)
-    if (kb + i < ke) {
+    if (KSS == 1 && kb + i < ke) {
       unsigned t0, t1;
       load_masks(kb + i, t0, t1);
       mA[i] = __builtin_amdgcn_readfirstlane(t0) & mask_and;
       mB[i] = b_half(__builtin_amdgcn_readfirstlane(t1)) & mask_and;
     }
-  if (ke - kb > D) load_masks(kb + D, vA, vB);
+  if (KSS == 1 && ke - kb > D) load_masks(kb + D, vA, vB);
 #pragma unroll
   for (int i = 0; i < D; i++)
-    if (kb + i < ke) issue_stage(kb + i, i, mA[i], mB[i]);
+    if (kb + i * KSS < ke) issue_stage(kb + i * KSS, i, mA[i], mB[i]);
   wait_loads();
   int buf = 0;                 // (kt - kb) % RING
 #ifdef MDG_I8_STAMPS
@@ -1013,8 +1033,8 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
   const int r = lane & 31, h = lane >> 5;
   // fragments of the planes below MIN_DEPTH (always staged, always multiplied): ONE set of reads feeds all their pairs
   i32x4 fa[MIN_DEPTH][WB], fb[MIN_DEPTH];
-  auto load_frags = [&](int stage_buf) {
-    const unsigned char* base = lds + stage_buf * STAGE_BYTES;
+  auto load_frags = [&](int stage_buf, int kk = 0) {
+    const unsigned char* base = lds + stage_buf * STAGE_BYTES + kk * STEP_BYTES;
 #pragma unroll
     for (int s = 0; s < MIN_DEPTH; s++) {
 #pragma unroll
@@ -1060,7 +1080,7 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
   constexpr int N_UNCOND = UNCOND_PAIRS * WB;                               // unconditional MFMAs per wave and k-step
   // of them, held back across the barrier by the loads-first waves (six planes: none -- 37.2 ms per call without, 55 ms with 3 - 5
   // deferred: the loads-first waves then lose their fragment prefetch)
-  constexpr int DEFER = PREFETCH ? 0 : DEFER5;
+  constexpr int DEFER = PREFETCH ? 0 : P == 3 ? MDG_I8_DEFER3 : DEFER5;
   auto rotate = [&]() {
 #pragma unroll
     for (int i = 0; i < D; i++) {
@@ -1076,20 +1096,21 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
   }
   // two loops: the int32 classes are folded into sigma between runs of FLUSH_STEPS k-steps, outside the MFMA loop (a
   // conditional flush inside it makes the compiler shuttle all 160 accumulators between AGPRs and VGPRs every step)
-  for (int k0 = kb; k0 < ke; k0 += FLUSH_STEPS) {
-    const int k1 = min(ke, k0 + FLUSH_STEPS);
+  constexpr int FOLD_STEPS = FLUSH_STEPS - FLUSH_STEPS % KSS;   // (a fold falls between two stages)
+  for (int k0 = kb; k0 < ke; k0 += FOLD_STEPS) {
+    const int k1 = min(ke, k0 + FOLD_STEPS);
     // Roles: the two waves of a SIMD take opposite orders inside a k-step.  Waves 4-7 issue their share of stage kt + D right
     // after the barrier and multiply afterwards; waves 0-3 multiply first and issue at the end of the step (after waiting for
     // their previous loads, a whole k-step old by then) -- one wave's ~450 cycles of LDS-DMA issue run under its partner's MFMAs.
-    for (int kt = k0; kt < k1; kt++) {
+    for (int kt = k0; kt < k1; kt += KSS) {
       MDG_STAMP(ta);
       if (loads_first) wait_loads();  // this wave's loads of the previous step
       __builtin_amdgcn_s_barrier();   // stage kt (PREFETCH: kt + 1 too) complete in LDS, stage kt - 1 no longer read
       auto refill = [&]() {           // stage kt + D into the buffer stage kt - 1 just left; masks of the stage after it behind it
         mA[D] = __builtin_amdgcn_readfirstlane(vA) & mask_and;
         mB[D] = b_half(__builtin_amdgcn_readfirstlane(vB)) & mask_and;
-        if (kt + D < ke) issue_stage(kt + D, ahead(D), mA[D], mB[D]);
-        if (kt + D + 1 < ke) load_masks(kt + D + 1, vA, vB);
+        if (kt + D * KSS < ke) issue_stage(kt + D * KSS, ahead(D), mA[D], mB[D]);
+        if (KSS == 1 && kt + D + 1 < ke) load_masks(kt + D + 1, vA, vB);
       };
       MDG_STAMP(tb);
       // the unconditional MFMAs of a step, in (s, t, block) order; [lo, hi) selects a run of them
@@ -1121,6 +1142,18 @@ __device__ __forceinline__ void i8_syrk_tile(const SyrkArgs& a, const SyrkProble
       }
       MDG_STAMP(tc);
       if (!PREFETCH || (DEFER && loads_first)) load_frags(buf);
+      if (KSS > 1) {
+        // the stage's k-steps but the last, whole: the fragment registers are re-read once their MFMAs are issued (the SIMD's other
+        // wave, a stage's half out of phase, has the matrix pipe meanwhile)
+#pragma unroll
+        for (int kk = 1; kk < KSS; kk++)
+          if (kt + kk < k1) {
+            mfma_run(0, N_UNCOND);
+            executed += UNCOND_PAIRS * WB;
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(buf, kk);
+          }
+      }
       mfma_run(0, N_UNCOND - DEFER);
       if (DEFER == 0 || !loads_first) mfma_run(N_UNCOND - DEFER, N_UNCOND);
       deep_planes(buf, mA[0], mB[0]);
@@ -1188,10 +1221,6 @@ __global__ __launch_bounds__(64 * NW, 1) void i8_syrk_kernel(SyrkArgs a) {
   constexpr int PB = TJ * KS;
   constexpr int GA = TI / 32, GB = TJ / 32;        // 32-row groups (1 KB pieces per plane and stage) of the two operands
   constexpr int WCOLS = TJ / 32;
-  constexpr int STAGE_BYTES = P * (PA + PB);       // 40 KB (P = 5, 128 x 128) / 36 KB (P = 6, 128 x 64)
-  constexpr int PIECES = (GA + GB) * P;            // 1 KB pieces per stage
-  constexpr int RING = ring_depth(P);              // LDS stages
-  constexpr bool PREFETCH = prefetch_frags(P);     // the next step's fragments are read before the barrier (needs RING >= 4)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   // The route is chosen on the DEVICE: mdg_cov_accum_i8 enqueues the five-plane product, the six-plane product and the fp64
   // kernel back to back, and each exits at once unless the depth statistic of this call (i8_depth_kernel) selects it -- the
@@ -2071,7 +2100,7 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
     if (planes_used == 3 && !offer_exact) continue;
     const bool wide = wide_tile(planes_used);                                  // 128 x 128 tiles; six planes: 128 x 64
     const int tj = wide ? 128 : 64;
-    const size_t lds = (size_t)ring_depth(planes_used) * planes_used * (PA + tj * KS);
+    const size_t lds = (size_t)ring_depth(planes_used) * steps_per_stage(planes_used) * planes_used * (PA + tj * KS);
     const int si = planes_used == 6 ? SB6 : SB5;                               // super-block rows (see the kernel)
     const int sr = (rb + si - 1) / si, nsb = sr * (sr + 1) / 2;                // super-block rows, super-blocks
     const int tps = wide ? si * si : 2 * si * si;                              // tiles per super-block

@@ -16,7 +16,7 @@ def gated(seed):
     a = torch.nn.functional.silu(torch.randn(T, n, device=dev, generator=g)); a.mul_(torch.randn(T, n, device=dev, generator=g))
     return a.to(torch.bfloat16)
 S = torch.zeros(n, n, dtype=F64, device=dev)
-only = sys.argv[3] if len(sys.argv) > 3 else None
+only = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] != "all" else None
 routes = {"exact": (True,), "truncated": (False,)}.get(sys.argv[4] if len(sys.argv) > 4 else None, (True, False))
 for name, make, seed in (("gaussian", gaussian, 1), ("silu_gated", gated, 2)):
     if only not in (None, name):
