@@ -140,7 +140,7 @@ int mdg_cov_accum_multi(int n, const mdg_cov_problem* problems, int dtype, void*
  * ev_start / ev_stop: optional hipEvent_t recorded on `stream` right before / after the two product launches (bench.py times
  * the dominant kernel alone with them); NULL otherwise. */
 /* THE EXACT ROUTE (since ABI 9.  flags = 0: taken where it is the faster product -- launches the route kernel classes as six planes,
- * i.e. SiLU- / GELU-gated MLP activations, and five-plane launches whose first statistic has >= 8192 features; MDG_I8_EXACT_ALWAYS:
+ * i.e. SiLU- / GELU-gated MLP activations, and five-plane launches whose first statistic has >= 4096 features; MDG_I8_EXACT_ALWAYS:
  * wherever the remainder lists fit; MDG_I8_NO_EXACT: never).  Planes 3 .. 5 are reached only by elements 17
  * binades and more below their column's maximum -- 3e-5 of the elements of a Gaussian column, 0.5 % of a SiLU-gated one -- so the
  * call lists those elements (token, column, low 24 bits) and, when every list fits (at most 3.1 % of any 32 columns x 2048 tokens),

@@ -1519,9 +1519,10 @@ __device__ __forceinline__ int* lo_totals(const LoProblem& pr, int nch) { return
 // Is the exact route on offer for this launch?  Always when the caller asks for it; by default where it is the faster product:
 // launches of the six-plane class (9 executed plane pairs + the remainder kernel against 15.1), and five-plane launches of a large
 // statistic (9 against 9.4 pairs on a kernel without masks or conditional blocks: 21.6 against 22.2 ms per sigma_mlp call on
-// Gaussian columns) -- below LO_AUTO_MIN_N features the remainder kernel's fixed costs (a workgroup per tile, two list walks, one
-// fold) outweigh 0.4 plane pairs.
-constexpr int LO_AUTO_MIN_N = 8192;
+// Gaussian columns; with two k-steps per stage 20.6) -- below LO_AUTO_MIN_N features the remainder kernel's fixed costs (a workgroup
+// per tile, two list walks, one fold) outweigh 0.4 plane pairs (4096 features, 32768 tokens: 2.13 against 2.15 ms on Gaussian, 3.25
+// against 3.42 on SiLU-gated columns; 8192: 7.18 / 7.72 and 10.6 / 12.5 -- profiles/r04_exact_route_timing.log).
+constexpr int LO_AUTO_MIN_N = 4096;
 __device__ __forceinline__ bool lo_offered(const LoArgs& a) {
   if (a.always) return true;
   if (a.prob[0].n >= LO_AUTO_MIN_N && !a.prob[0].block) return true;
@@ -1733,15 +1734,25 @@ __global__ __launch_bounds__(LO_THREADS) void i8_lo_product_kernel(LoArgs a) {
   __syncthreads();      // an accumulator changes owner between the two passes: the wave of its row, then the wave of its column
   lo_events<true>(pr, a.nch, 4 * bj + g, sub, bi * LO_TILE, g, lane, lo_acc);
   __syncthreads();
-  for (int i = tid; i < LO_TILE * LO_TILE; i += LO_THREADS) {
-    const int r = i / LO_TILE, c = i % LO_TILE;
-    const int row = bi * LO_TILE + r, col = bj * LO_TILE + c;
-    const double v = lo_acc[lo_perm(r) * LO_PITCH + lo_perm(c)];
-    if (col > row || v == 0.) continue;
-    if ((pr.emax[row] | pr.emax[col]) & EMAX_COLUMN_OUT) continue;    // rows / columns of the fp64 column kernel: not ours
-    double* s = pr.sigma + (int64_t)row * pr.ld_sigma + col - (pr.block ? row / pr.block * pr.block : 0);
-    *s += v;
+  // the tile's 16 elements of a thread: all their sigma loads first, then the additions and the stores (written as `*s += v` behind
+  // the tests, every element paid a memory round trip of its own: 16 in series per tile, most of the kernel's time on sparse lists)
+  constexpr int PER = LO_TILE * LO_TILE / LO_THREADS;
+  const int c = tid % LO_TILE, col = bj * LO_TILE + c;
+  const int e_col = col < pr.n ? pr.emax[col] : EMAX_COLUMN_OUT;
+  double* s[PER];
+  double old[PER], v[PER];
+#pragma unroll
+  for (int u = 0; u < PER; u++) {
+    const int r = tid / LO_TILE + u * (LO_THREADS / LO_TILE), row = bi * LO_TILE + r;
+    v[u] = lo_acc[lo_perm(r) * LO_PITCH + lo_perm(c)];
+    // (rows / columns of the fp64 column kernel are not ours)
+    const bool ours = col <= row && row < pr.n && v[u] != 0. && !((pr.emax[row] | e_col) & EMAX_COLUMN_OUT);
+    s[u] = ours ? pr.sigma + (int64_t)row * pr.ld_sigma + col - (pr.block ? row / pr.block * pr.block : 0) : nullptr;
+    old[u] = ours ? *s[u] : 0.;
   }
+#pragma unroll
+  for (int u = 0; u < PER; u++)
+    if (s[u]) *s[u] = old[u] + v[u];
 }
 
 // column maxima (n ints, padded to 8 bytes) + the [NSTAT][n] route statistics + the route kernel's ticket: zeroed together per call

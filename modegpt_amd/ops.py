@@ -176,7 +176,7 @@ def _read_route(lib, count, arr, stat, wsp, stream) -> dict:
 
 # The exact route of the int8 covariance (include/modegpt_hip.h, "THE EXACT ROUTE"): "auto" (default) takes it where it is the
 # faster product -- launches of the six-plane class (the MLP statistic of a gated model) and five-plane launches of a statistic of
-# 8192 features and more; "always" (True) wherever the remainder lists fit (fp64-rounding accuracy for every int8 statistic);
+# 4096 features and more; "always" (True) wherever the remainder lists fit (fp64-rounding accuracy for every int8 statistic);
 # "never" (False) keeps every call on the truncated five- / six-plane product with its bound.  MODEGPT_I8_EXACT=auto|1|0.
 I8_EXACT = {"1": True, "always": True, "0": False, "never": False}.get(os.environ.get("MODEGPT_I8_EXACT", "auto").lower(), "auto")
 

@@ -195,7 +195,7 @@ def route_of(X, chunk=1024, tolerance=1.0, offer_exact=True):
     planes, cols, (sq, x) = route(st, sort=False, tokens=min(X.shape[0], int(nz.min()) if nz.size else X.shape[0]), tolerance=tolerance)
     exact = False
     if offer_exact == "auto":          # the library's default: the exact route where it is the faster product -- the six-plane class,
-        offer_exact = planes == 6 or X.shape[1] >= 8192     # and large five-plane statistics (cov_i8.hip lo_offered)
+        offer_exact = planes == 6 or X.shape[1] >= 4096     # and large five-plane statistics (cov_i8.hip lo_offered)
     if planes and offer_exact and X.shape[1] % 32 == 0:
         lo = np.concatenate(lo, axis=1)
         lo[:, cols] = False                            # the digits of the columns that left are cleared before the lists are made
