@@ -39,14 +39,15 @@ for l in rows:
     m = re.match(r'"(.*i8_syrk_kernelILi(\d)EE.*)",(\d+),(ran_long),(\d+),([0-9.]+),', l)
     if m:
         val[(m.group(2), "avg_ms")] = float(m.group(6))
-# the remainder kernel of the exact route (class "ran": it is not an i8_syrk launch)
+# the remainder kernel of the exact route (class "ran": it is not an i8_syrk launch); of its launch shapes, the sigma_mlp-sized grid
+lo_grid = max([int(m.group(2)) for m in (re.match(r'"(.*i8_lo_product_kernel.*)",(\d+),(ran),', l) for l in rows) if m] or [0])
 for l in rows:
-    m = re.match(r'"(.*i8_lo_product_kernel.*)",(\d+),(ran),(\w+),(\d+),([0-9.e+]+)', l)
+    m = re.match(r'"(.*i8_lo_product_kernel.*)",%d,(ran),(\w+),(\d+),([0-9.e+]+)' % lo_grid, l)
     if m:
-        val[("lo", m.group(4))] = float(m.group(6))
-    m = re.match(r'"(.*i8_lo_product_kernel.*)",(\d+),(ran),(\d+),([0-9.]+),', l)
+        val[("lo", m.group(3))] = float(m.group(5))
+    m = re.match(r'"(.*i8_lo_product_kernel.*)",%d,(ran),(\d+),([0-9.]+),' % lo_grid, l)
     if m:
-        val[("lo", "avg_ms")] = float(m.group(5))
+        val[("lo", "avg_ms")] = float(m.group(4))
 out = {}
 if ("lo", "FETCH_SIZE") in val:
     out["remainder_kernel"] = {"fetch_bytes_corrected": val[("lo", "FETCH_SIZE")] * 1024 * 2, "write_bytes": val.get(("lo", "WRITE_SIZE"), 0.0) * 1024,
