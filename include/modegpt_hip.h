@@ -136,17 +136,19 @@ int mdg_cov_accum_multi(int n, const mdg_cov_problem* problems, int dtype, void*
  *   8e-14, the sigma_mlp launch 29 instead of 37 ms -- and fewer columns on the fp64 column kernel.  The call still computes and
  *   reports its own bound (mdg_cov_accum_i8_route), so what was guaranteed for a given input is known, whatever f.  An argument,
  *   not process state: concurrent callers with different factors do not see each other.  Not in the reference (plain fp64 there).
- * n_feat must be a multiple of 128, n_tokens < 2^28.  ws: mdg_cov_accum_i8_ws_bytes (about 6 bytes per element of x).
+ * n_feat must be a multiple of 128, n_tokens < 2^28.  ws: mdg_cov_accum_i8_ws_bytes (about 9.5 bytes per element of x: six digit planes, the
+ * exact route's event lists and its bf16 copy of x).
  * ev_start / ev_stop: optional hipEvent_t recorded on `stream` right before / after the two product launches (bench.py times
  * the dominant kernel alone with them); NULL otherwise. */
 /* THE EXACT ROUTE (since ABI 9.  flags = 0: taken where it is the faster product -- launches the route kernel classes as six planes,
  * i.e. SiLU- / GELU-gated MLP activations, and five-plane launches whose first statistic has >= 4096 features; MDG_I8_EXACT_ALWAYS:
  * wherever the remainder lists fit; MDG_I8_NO_EXACT: never).  Planes 3 .. 5 are reached only by elements 17
  * binades and more below their column's maximum -- 3e-5 of the elements of a Gaussian column, 0.5 % of a SiLU-gated one -- so the
- * call lists those elements (token, column, low 24 bits) and, when every list fits (at most 3.1 % of any 32 columns x 2048 tokens),
+ * call lists those elements (token, column, low 24 bits) and, when every list fits (at most 6.2 % of any column x 2048 tokens),
  * replaces the truncated product by an exact one:  X^T X = X_d^T X_d + X_lo^T X + X_d^T X_lo  with X_d the top three digit planes --
  * all NINE of their plane pairs on the int8 matrix cores (a product launch of its own: three planes, no piece masks) -- and the two
- * remainder products as fp64 sums over the listed elements (i8_lo_product_kernel).  No plane pair is dropped: the error is fp64
+ * remainder products as fp64 sums over the listed elements (i8_lo_product_kernel for sparse lists, i8_lo_wide_kernel for dense
+ * ones; the device picks).  No plane pair is dropped: the error is fp64
  * rounding (<= MDG_I8_EXACT_ROUNDING of sqrt(sigma_ii sigma_jj)) plus the bound's rho term for elements more than 38 binades under
  * their column maximum, whatever `tolerance` says; 9 executed plane pairs instead of 9.4 (Gaussian) / 15.1 (SiLU-gated).  The route
  * kernel's decisions are unchanged -- which columns leave for the fp64 column kernel, whether the whole statistic goes to

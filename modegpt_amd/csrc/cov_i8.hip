@@ -1469,30 +1469,39 @@ __global__ __launch_bounds__(256) void i8_columns_reduce_kernel(ColArgs a, const
 //     X^T X = X_d^T X_d  +  X_lo^T X  +  X_d^T X_lo
 //   * X_d^T X_d: the NINE plane pairs of the top three planes, all of them (classes 0 .. 4) -- the five-plane product kernel with the
 //     planes below masked off (mask_and in i8_syrk_tile): exact int32 class sums as before, 9 instead of 9.4 / 15.1 executed pairs;
-//   * the two remainder products: every element with L != 0 is an EVENT (token, column, L), listed per 32-column group in token
-//     order by i8_extract_lo_kernel; i8_lo_product_kernel walks the lists of an output tile's row block (sigma[r][c] += x_lo(t, r)
-//     x(t, c), the partner x in full) and of its column block (+= x_d(t, r) x_lo(t, c), the partner's top three planes recomputed
-//     from x: x_d = 2^24 q floor(x / (2^24 q) + 8421504 / 2^24), the balanced digits' rounding), fp64 products of exact operands
-//     summed into a 128 x 128 fp64 tile in LDS, each accumulator owned by ONE wave that adds its events in list order -- run-to-run
-//     bit-identical -- and folded into sigma once.
+//   * the two remainder products: every element with L != 0 is an EVENT (token, column, x_lo = L 2^(E - 172)), listed per COLUMN in
+//     token order by i8_extract_lo_kernel / i8_compact_lo_kernel.  Two implementations, picked on the device from the list lengths
+//     (i8_lo_mode_kernel):
+//       sparse lists (Gaussian columns: two events per column) -- i8_lo_product_kernel, one workgroup per 128 x 128 tile of the lower
+//         triangle: the lists of the tile's row block (sigma[r][c] += x_lo(t, r) x(t, c), the partner x in full) and of its column
+//         block (+= x_d(t, r) x_lo(t, c), the partner's top three planes recomputed from x where it has deeper digits: x_d = 2^24 q
+//         floor(x / (2^24 q) + 8421504 / 2^24), the balanced digits' rounding), summed into an fp64 tile in LDS, sigma read and
+//         written once;
+//       dense lists (SiLU-gated: 156 per column) -- i8_lo_wide_kernel<false / true>, one wave per (column, block of 512 partner
+//         columns), eight partner columns per lane, the sums in registers; the second product reads its partner from a bf16 copy of
+//         x in which every listed element is replaced by x_d (i8_copy_xd_kernel, i8_patch_xd_kernel).
+//     Either way fp64 products of exact operands, every sum owned by ONE wave that adds its events in list order -- run-to-run
+//     bit-identical -- and folded into sigma once per product.
 // Nothing is truncated: what is left is fp64 rounding (one rounding per fold of the class sums and per event sum) and the rho term
 // of the elements more than 38 binades under their column maximum, which the split rounds to an integer (RouteOut::sq keeps it).
 // The route kernel's decisions stay as they are -- which columns leave for the fp64 column kernel, whether the whole statistic
 // does -- and the exact route then REPLACES the truncated five- or six-plane product whenever every remainder list fits its
-// list (LO_CAP events per 8 columns x 2048 tokens = 3.1 % of the elements; cubed Gaussians, Student-t: no -- the truncated
-// product with its bound takes those as before).  Cost at the sigma_mlp shape: extraction 0.2 ms, remainder product ~0.3 ms
-// (Gaussian) ... ~5 ms (SiLU-gated) against 0.4 x 2.3 ... 6.1 x 2.35 ms of plane-pair products saved.
-constexpr int LO_CHUNK_STEPS = 64;       // k-steps (2048 tokens) per segment of a group's event lists
-constexpr int LO_SUB = 4;                // lists per (group, segment): one per residue of the column index mod 4 -- one per wave of the
-                                         // remainder kernel that owns those accumulator rows (columns) exclusively
-constexpr int LO_CAP = 512;              // events per list: 4 x 512 = 3.1 % of a segment's 65536 elements
-constexpr int LO_TILE = 128, LO_PITCH = LO_TILE + 1;
+// list (LO_CAP events per column and 2048 tokens = 6.2 % of the elements; cubed Gaussians, Student-t: no -- the truncated
+// product with its bound takes those as before).  Cost at the sigma_mlp shape (profiles/r04_exact_route_kernels_*.csv): lists 0.08 /
+// 0.25 ms, remainder products 1.0 ms (Gaussian) / 5.4 + 0.5 ms for the copy (SiLU-gated) against 0.4 x 2.1 ... 6.1 x 2.1 ms of
+// plane-pair products saved.
+constexpr int LO_CHUNK_STEPS = 64;       // k-steps (2048 tokens) per segment of a column's event list
+constexpr int LO_CAP = 128;              // events per segment: 6.2 % of its 2048 tokens
 constexpr double LO_ROUND = 8421504.0 / 16777216.0;   // (128 (1 + 256 + 65536)) / 2^24: where the balanced digits d_3 d_4 d_5 round
-constexpr int EXACT_OVERFLOW = 16, EXACT_RAN = 17;    // ints of the workspace's shared block
+constexpr int EXACT_OVERFLOW = 16, EXACT_RAN = 17, EXACT_MODE = 18;    // ints of the workspace's shared block (MODE: 1 sparse lists, 2 dense)
+constexpr int LO_SUB = 4, LO_RCAP = 512;              // sparse lists: one per (32-column group, column mod 4), of at most 8 x 64 events
+constexpr int LO_TILE = 128, LO_PITCH = LO_TILE + 1;
 
 struct __attribute__((aligned(16))) LoEntry {
   double v;                        // x_lo(token, column) = L 2^(E_column - 172): exact (|L| < 2^24)
-  unsigned tok, col;               // token; column within its 32-column group
+  unsigned off, aux;               // byte offset of the token's row in x (token x row pitch x 2);  aux: the same in the x_d copy (token x n x
+                                   // 2) -- in a sparse (group, residue) list: the column's index in its group.  The call refuses the exact
+                                   // route when x spans 4 GB or more: the walk then spends no 64-bit scalar arithmetic on an address
 };
 struct LoProblem {
   const bf16_t* x;
@@ -1500,22 +1509,28 @@ struct LoProblem {
   const signed char* planes;
   const unsigned char* zmask;
   const int* emax;
-  LoEntry* entries;                // [n / 32][LO_SUB][nch][LO_CAP]: written per segment by i8_extract_lo_kernel, then closed up to one contiguous
-                                   // list per (group, residue) by i8_compact_lo_kernel
-  int* counts;                     // [n / 32][LO_SUB][nch] segment lengths, then [n / 32][LO_SUB] list lengths (totals)
+  LoEntry* entries;                // [n][nch][LO_CAP]: one list per COLUMN, written per segment by i8_extract_lo_kernel, then closed up
+                                   // to one contiguous list by i8_compact_lo_kernel
+  int* counts;                     // [n][nch] segment lengths, then [n] list lengths (totals)
   double* sigma;
   int64_t ld_sigma;
-  int n, block, tile0;             // tile0: this statistic's first workgroup of the remainder-product grid
-  int pairs;                       // rows of x are 4-byte addressable: a lane fetches two neighbouring columns with one load
+  bf16_t* xd;                      // [tokens][n]: x with every listed element replaced by its top three digit planes x_d = x - x_lo (which is
+                                   // a bf16 again: a rounding of 8 significant bits to a coarser grid) -- the partner of the second product
+  int n, block;
+  LoEntry* rentries;               // sparse mode: [n / 32][LO_SUB][LO_RCAP] merged lists (i8_residue_lo_kernel) and their lengths
+  int* rtotals;
+  int tile0[3];                    // this statistic's first workgroup in the grids of the two wide products and of the tile kernel
+  int pairs;                       // rows of x are 4-byte addressable: a lane of the tile kernel fetches two neighbouring columns with one load
 };
 struct LoArgs {
   LoProblem prob[MAX_PROBLEMS];
-  int nprob, nk, nch, tiles;
+  int nprob, nk, nch, tiles[3];
+  int64_t n_tokens;
   int always;                      // MDG_I8_EXACT_ALWAYS: the exact route for launches of the five-plane class too
   const int* route_flag;
   int* state;                      // shared block of the workspace: [EXACT_OVERFLOW], [EXACT_RAN]
 };
-__device__ __forceinline__ int* lo_totals(const LoProblem& pr, int nch) { return pr.counts + (int64_t)(pr.n / 32) * LO_SUB * nch; }
+__device__ __forceinline__ int* lo_totals(const LoProblem& pr, int nch) { return pr.counts + (int64_t)pr.n * nch; }
 // Is the exact route on offer for this launch?  Always when the caller asks for it; by default where it is the faster product:
 // launches of the six-plane class (9 executed plane pairs + the remainder kernel against 15.1), and five-plane launches of a large
 // statistic (9 against 9.4 pairs on a kernel without masks or conditional blocks: 21.6 against 22.2 ms per sigma_mlp call on
@@ -1532,8 +1547,8 @@ __device__ __forceinline__ bool lo_offered(const LoArgs& a) {
 }
 
 // One wave per (32-column group, segment of LO_CHUNK_STEPS k-steps): reads the pieces of planes 3 .. 5 the piece masks say are
-// there -- as the product kernel would -- and compacts the elements with L != 0 into the segment's four lists in (k-step,
-// token-in-half, lane) order.
+// there -- as the product kernel would -- and appends every element with L != 0 to ITS COLUMN's segment, in token order (lane r
+// holds tokens 0 .. 15 of a k-step of column r, lane 32 + r tokens 16 .. 31: the second appends behind the first).
 __global__ __launch_bounds__(64) void i8_extract_lo_kernel(LoArgs a) {
   const LoProblem& pr = a.prob[blockIdx.z];
   const int64_t groups = pr.n / 32;
@@ -1541,12 +1556,10 @@ __global__ __launch_bounds__(64) void i8_extract_lo_kernel(LoArgs a) {
   if (!lo_offered(a)) return;
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0) a.state[EXACT_RAN] = 1;
   if (G >= groups || (a.route_flag[blockIdx.z] & 2)) return;     // (a statistic that went to the fp64 kernel has no lists)
-  const int sub = lane & (LO_SUB - 1);
-  LoEntry* out = pr.entries + (((int64_t)G * LO_SUB + sub) * a.nch + ch) * LO_CAP;
-  const unsigned long long below = (1ull << lane) - 1ull;
-  const unsigned long long every4 = 0x1111111111111111ull;
-  const int e_col = pr.emax[G * 32 + (lane & 31)] & 255;
-  int count[LO_SUB] = {0, 0, 0, 0};
+  const int col = G * 32 + (lane & 31);
+  LoEntry* out = pr.entries + ((int64_t)col * a.nch + ch) * LO_CAP;
+  const double scale = ldexp(1.0, (pr.emax[col] & 255) - 172);
+  int count = 0;                                                  // events of this lane's column so far (the same in both of its lanes)
   const int kt1 = min(a.nk, (ch + 1) * LO_CHUNK_STEPS);
   for (int kt = ch * LO_CHUNK_STEPS; kt < kt1; kt++) {
     const unsigned m = pr.zmask[(int64_t)kt * groups + G];
@@ -1556,40 +1569,41 @@ __global__ __launch_bounds__(64) void i8_extract_lo_kernel(LoArgs a) {
     const i32x4 d4 = (m >> 4) ? *((const i32x4*)(pr.planes + ((4 * groups + G) * (int64_t)a.nk + kt) * 1024) + lane) : zero;
     const i32x4 d5 = (m >> 5) ? *((const i32x4*)(pr.planes + ((5 * groups + G) * (int64_t)a.nk + kt) * 1024) + lane) : zero;
     const unsigned tok0 = (unsigned)kt * KS + (lane >> 5) * 16;
+    int L[16], mine = 0;
 #pragma unroll
     for (int q = 0; q < 16; q++) {
       const int sh = 8 * (q & 3);
-      const int L = (int)(signed char)((unsigned)d3[q >> 2] >> sh) * 65536 + (int)(signed char)((unsigned)d4[q >> 2] >> sh) * 256 +
-                    (int)(signed char)((unsigned)d5[q >> 2] >> sh);
-      const unsigned long long b = __ballot(L != 0);
-      if (b == 0) continue;
-      if (L != 0) {
-        const int at = count[sub] + __builtin_popcountll(b & below & (every4 << sub));
-        if (at < LO_CAP) out[at] = LoEntry{ldexp((double)L, e_col - 172), tok0 + q, (unsigned)(lane & 31)};
-      }
-#pragma unroll
-      for (int k = 0; k < LO_SUB; k++) count[k] += __builtin_popcountll(b & (every4 << k));
+      L[q] = (int)(signed char)((unsigned)d3[q >> 2] >> sh) * 65536 + (int)(signed char)((unsigned)d4[q >> 2] >> sh) * 256 +
+             (int)(signed char)((unsigned)d5[q >> 2] >> sh);
+      mine += L[q] != 0;
     }
-  }
-  if (lane < LO_SUB) {
-    int mine = count[0];
+    if (__ballot(mine != 0) == 0) continue;
+    const int other = __shfl_xor(mine, 32);
+    int at = count + ((lane >> 5) ? other : 0);
 #pragma unroll
-    for (int k = 1; k < LO_SUB; k++) mine = lane == k ? count[k] : mine;
-    pr.counts[((int64_t)G * LO_SUB + lane) * a.nch + ch] = min(mine, LO_CAP);
-    if (mine > LO_CAP) a.state[EXACT_OVERFLOW] = 1;
+    for (int q = 0; q < 16; q++)
+      if (L[q] != 0) {
+        if (at < LO_CAP) out[at] = LoEntry{(double)L[q] * scale, (tok0 + q) * (unsigned)(pr.ld * 2), (tok0 + q) * (unsigned)(pr.n * 2)};
+        at++;
+      }
+    count += mine + other;
+  }
+  if (lane < 32) {
+    pr.counts[(int64_t)col * a.nch + ch] = min(count, LO_CAP);
+    if (count > LO_CAP) a.state[EXACT_OVERFLOW] = 1;
   }
 }
 
-// One wave per list (32-column group, residue): closes the segments up into one contiguous list, in place (a segment only ever
-// moves towards the front, and the wave copies in order), and leaves its length in lo_totals.  The remainder kernel then walks
-// full batches whatever the density (a Gaussian column has a handful of events per segment).
+// One wave per column: closes the segments of its list up into one contiguous list, in place (a segment only ever moves towards
+// the front, and the wave copies in order), and leaves its length in lo_totals.  The remainder kernel then walks full batches
+// whatever the density.
 __global__ __launch_bounds__(64) void i8_compact_lo_kernel(LoArgs a) {
   if (!lo_offered(a) || a.state[EXACT_OVERFLOW] != 0) return;
   const LoProblem& pr = a.prob[blockIdx.y];
-  const int list = blockIdx.x, lane = threadIdx.x;
-  if (list >= pr.n / 32 * LO_SUB || (a.route_flag[blockIdx.y] & 2)) return;
-  const int* counts = pr.counts + (int64_t)list * a.nch;
-  LoEntry* base = pr.entries + (int64_t)list * a.nch * LO_CAP;
+  const int col = blockIdx.x, lane = threadIdx.x;
+  if (col >= pr.n || (a.route_flag[blockIdx.y] & 2)) return;
+  const int* counts = pr.counts + (int64_t)col * a.nch;
+  LoEntry* base = pr.entries + (int64_t)col * a.nch * LO_CAP;
   int total = 0;
   for (int ch = 0; ch < a.nch; ch++) {
     const int cnt = counts[ch];
@@ -1602,7 +1616,96 @@ __global__ __launch_bounds__(64) void i8_compact_lo_kernel(LoArgs a) {
       }
     total += cnt;
   }
-  if (lane == 0) lo_totals(pr, a.nch)[list] = total;
+  if (lane == 0) lo_totals(pr, a.nch)[col] = total;
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// Which remainder kernels run, from the list lengths (one workgroup; read by everything below): SPARSE lists -- at most 64 events in
+// any column and LO_SPARSE_MEAN per column on average: Gaussian columns have two -- go to the 128 x 128-tile kernel, where a tile is
+// one chain of memory round trips around a handful of products and sigma is read and written ONCE for both products; anything denser
+// (SiLU-gated: 156 per column) to the wide kernels, which are bound by their instruction stream and need 2.4 x fewer instructions per
+// product.  Measured at the sigma_mlp shape, both products, Gaussian / SiLU-gated: tiles 1.04 / 9.3 ms, wide 1.8 / 5.4 (+ 0.55 for
+// the x_d copy).
+constexpr int LO_SPARSE_MEAN = 8;
+__global__ __launch_bounds__(1024) void i8_lo_mode_kernel(LoArgs a) {
+  if (!lo_offered(a) || a.state[EXACT_OVERFLOW] != 0) return;
+  __shared__ long long sums[16];
+  __shared__ int maxs[16];
+  long long sum = 0, cols = 0;
+  int mx = 0;
+  for (int p = 0; p < a.nprob; p++) {
+    if (a.route_flag[p] & 2) continue;
+    const LoProblem& pr = a.prob[p];
+    cols += pr.n;
+    for (int c = threadIdx.x; c < pr.n; c += 1024) {
+      const int t = lo_totals(pr, a.nch)[c];
+      sum += t;
+      mx = max(mx, t);
+    }
+  }
+  for (int o = 32; o; o >>= 1) {
+    sum += __shfl_xor(sum, o);
+    mx = max(mx, __shfl_xor(mx, o));
+  }
+  if ((threadIdx.x & 63) == 0) { sums[threadIdx.x >> 6] = sum; maxs[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; w++) { sum += sums[w]; mx = max(mx, maxs[w]); }
+    a.state[EXACT_MODE] = (mx <= 64 && sum <= LO_SPARSE_MEAN * cols) ? 1 : 2;
+  }
+}
+
+// SPARSE: the lists of the eight columns 4 k + sub of a group, one behind the other, as ONE list per (group, residue) -- the unit a wave
+// of the tile kernel walks (it owns the accumulators of those rows / columns); `aux` = the column's index in its group.  One wave
+// per list; at most 8 x 64 entries.
+__global__ __launch_bounds__(64) void i8_residue_lo_kernel(LoArgs a) {
+  if (a.state[EXACT_MODE] != 1) return;
+  const LoProblem& pr = a.prob[blockIdx.y];
+  const int id = blockIdx.x, lane = threadIdx.x;
+  if (id >= pr.n / 32 * LO_SUB || (a.route_flag[blockIdx.y] & 2)) return;
+  const int G = id / LO_SUB, sub = id % LO_SUB;
+  LoEntry* out = pr.rentries + (int64_t)id * LO_RCAP;
+  int at = 0;
+  for (int k = 0; k < 8; k++) {
+    const int col = G * 32 + 4 * k + sub;
+    const int cnt = lo_totals(pr, a.nch)[col];           // <= 64 (the mode says so)
+    if (lane < cnt) {
+      LoEntry e = pr.entries[(int64_t)col * a.nch * LO_CAP + lane];
+      e.aux = 4 * k + sub;
+      out[at + lane] = e;
+    }
+    at += cnt;
+  }
+  if (lane == 0) pr.rtotals[id] = at;
+}
+
+// DENSE: x_d starts as a copy of x (16 bytes per thread and step; n is a multiple of 128), then every listed element is replaced by
+// x_d = x - x_lo -- exactly (both are multiples of the column's unit, below 2^48 of them), and a bf16 again (a rounding of 8
+// significant bits to a coarser grid).  One wave per column for the second step.
+__global__ __launch_bounds__(256) void i8_copy_xd_kernel(LoArgs a) {
+  if (a.state[EXACT_MODE] != 2) return;
+  const LoProblem& pr = a.prob[blockIdx.y];
+  if (a.route_flag[blockIdx.y] & 2) return;
+  const int64_t per_row = pr.n / 8, total = a.n_tokens * per_row;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t t = i / per_row, c = (i - t * per_row) * 8;
+    typedef unsigned u32x4u __attribute__((ext_vector_type(4), aligned(2)));
+    const u32x4u v = *(const u32x4u*)(pr.x + t * pr.ld + c);
+    *(u32x4*)(pr.xd + t * pr.n + c) = (u32x4){v[0], v[1], v[2], v[3]};
+  }
+}
+__global__ __launch_bounds__(64) void i8_patch_xd_kernel(LoArgs a) {
+  if (a.state[EXACT_MODE] != 2) return;
+  const LoProblem& pr = a.prob[blockIdx.y];
+  const int col = blockIdx.x, lane = threadIdx.x;
+  if (col >= pr.n || (a.route_flag[blockIdx.y] & 2)) return;
+  const int total = lo_totals(pr, a.nch)[col];
+  const LoEntry* list = pr.entries + (int64_t)col * a.nch * LO_CAP;
+  for (int i = lane; i < total; i += 64) {
+    const LoEntry e = list[i];
+    const double xd = (double)__uint_as_float((unsigned)*(const bf16_t*)((const char*)pr.x + e.off + 2 * col) << 16) - e.v;
+    *(bf16_t*)((char*)pr.xd + e.aux + 2 * col) = (bf16_t)(__float_as_uint((float)xd) >> 16);
+  }
 }
 
 __device__ __forceinline__ void lds_add_f64(double* p, double v) {
@@ -1643,8 +1746,8 @@ __device__ __forceinline__ void lo_events(const LoProblem& pr, const int nch, co
     lim_b = (unsigned)max(eb - 14, 1) << 7;
   }
   const int list_id = G * LO_SUB + sub;
-  const int cnt = lo_totals(pr, nch)[list_id];
-  const LoEntry* list = pr.entries + (int64_t)list_id * nch * LO_CAP;
+  const int cnt = pr.rtotals[list_id];
+  const LoEntry* list = pr.rentries + (int64_t)list_id * LO_RCAP;
   // batch k: events [k LO_UN, ...) -- one entry per lane (lanes beyond the list's end: the last entry's token, v = 0: exact zeros)
   auto fetch = [&](int k, LoEntry& m) {
     m = list[min(k * LO_UN + (lane & (LO_UN - 1)), cnt - 1)];
@@ -1653,8 +1756,8 @@ __device__ __forceinline__ void lo_events(const LoProblem& pr, const int nch, co
   auto issue = [&](const LoEntry& m, unsigned (&xv)[LO_UN]) {
 #pragma unroll
     for (int u = 0; u < LO_UN; u++) {
-      const unsigned tok = (unsigned)__builtin_amdgcn_readlane((int)m.tok, u);
-      const unsigned short* row = xs + (int64_t)tok * pr.ld + partner0 + 2 * lane;
+      const unsigned off = (unsigned)__builtin_amdgcn_readlane((int)m.off, u);
+      const unsigned short* row = (const unsigned short*)((const char*)xs + off) + partner0 + 2 * lane;
       xv[u] = pr.pairs ? *(const unsigned*)row : ((unsigned)row[0] | ((unsigned)row[1] << 16));
     }
   };
@@ -1662,7 +1765,7 @@ __device__ __forceinline__ void lo_events(const LoProblem& pr, const int nch, co
 #pragma unroll
     for (int u = 0; u < LO_UN; u++) {
       const double v = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(m.v), u), __builtin_amdgcn_readlane(__double2loint(m.v), u));
-      const int col = __builtin_amdgcn_readlane((int)m.col, u);
+      const int col = __builtin_amdgcn_readlane((int)m.aux, u);
       double pa = bf16_to_f64(xv[u] & 0xFFFFu), pb = bf16_to_f64(xv[u] >> 16);
       if (COLS) {
         const bool deep = ((xv[u] & 0x7FFFu) - 1u < lim_a - 1u) || (((xv[u] >> 16) & 0x7FFFu) - 1u < lim_b - 1u);
@@ -1706,12 +1809,12 @@ __device__ __forceinline__ void lo_events(const LoProblem& pr, const int nch, co
 constexpr int LO_THREADS = 1024;
 __global__ __launch_bounds__(LO_THREADS) void i8_lo_product_kernel(LoArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lo_acc[];     // [128][LO_PITCH]
-  if (a.state[EXACT_RAN] != 1 || a.state[EXACT_OVERFLOW] != 0) return;
+  if (a.state[EXACT_RAN] != 1 || a.state[EXACT_OVERFLOW] != 0 || a.state[EXACT_MODE] != 1) return;
   int p = 0;
-  while (p + 1 < a.nprob && (int)blockIdx.x >= a.prob[p + 1].tile0) p++;
+  while (p + 1 < a.nprob && (int)blockIdx.x >= a.prob[p + 1].tile0[2]) p++;
   if (a.route_flag[p] & 2) return;
   const LoProblem& pr = a.prob[p];
-  const int t = blockIdx.x - pr.tile0;
+  const int t = blockIdx.x - pr.tile0[2];
   int bi, bj;
   if (pr.block) {
     bi = bj = t;
@@ -1726,7 +1829,7 @@ __global__ __launch_bounds__(LO_THREADS) void i8_lo_product_kernel(LoArgs a) {
   const int g = wave & 3, sub = wave >> 2;
   // anything to do?  (the lists of the tile's four row groups and four column groups)
   int any = 0;
-  if (tid < 8 * LO_SUB) any = lo_totals(pr, a.nch)[(tid < 4 * LO_SUB ? 4 * bi * LO_SUB : 4 * bj * LO_SUB - 4 * LO_SUB) + tid];
+  if (tid < 8 * LO_SUB) any = pr.rtotals[(tid < 4 * LO_SUB ? 4 * bi * LO_SUB : 4 * bj * LO_SUB - 4 * LO_SUB) + tid];
   if (!__syncthreads_or(any)) return;
   for (int i = tid; i < LO_TILE * LO_PITCH; i += LO_THREADS) lo_acc[i] = 0.;
   __syncthreads();
@@ -1753,6 +1856,174 @@ __global__ __launch_bounds__(LO_THREADS) void i8_lo_product_kernel(LoArgs a) {
 #pragma unroll
   for (int u = 0; u < PER; u++)
     if (s[u]) *s[u] = old[u] + v[u];
+}
+
+// The two remainder products.  One workgroup = the 16 columns of group G against a block of LW_BLOCK = 512 partner columns; wave w
+// owns column G 16 + w, and every lane EIGHT neighbouring partner columns (one 16-byte load
+// per event), whose eight sums it keeps in registers while it walks the column's list -- one v_fma_f64 per product, events in list
+// order (run-to-run bit-identical; no atomics, no LDS) -- and adds to sigma when the column is done:
+//   TR = false   sigma[r][c] += sum_t x_lo(t, r) x(t, c)      for the partner columns c <= r   (X_lo^T X, lower part; a contiguous row)
+//   TR = true    sigma[c][r] += sum_t x_lo(t, r) x_d(t, c)    for the partner columns c >= r   (X_d^T X_lo, lower part; partner x_d from
+//                the copy, so both products are the same loop: the first versions recomputed x_d from x whenever a lane met an
+//                element with digits below plane 2 -- at eight columns per lane nearly every event does)
+// Two launches, the second after the first (an entry of sigma gets a sum from each).  Why this shape: the kernel is bound by its
+// INSTRUCTION stream -- per event and wave three broadcasts and an address, then per product an unpack, a conversion and the fma; at
+// two partner columns per lane (the 128 x 128-tile versions: profiles/r04_exact_route_kernels_silu_gated.csv, 9.3 ms) the fixed part
+// and two LDS atomics per event were most of it.  Workgroups run partner block by partner block (P-major): the 256 that are
+// resident walk their lists in token order over the SAME 512 columns of x -- 32 MB that stay in the memory-side cache.
+#ifndef MDG_LW_UN
+#define MDG_LW_UN 8
+#endif
+#ifndef MDG_LW_OCC
+#define MDG_LW_OCC 0      // 8: two workgroups per CU (64 VGPRs)
+#endif
+#if MDG_LW_OCC
+#define LW_OCC_ATTR __attribute__((amdgpu_waves_per_eu(MDG_LW_OCC, MDG_LW_OCC)))
+#else
+#define LW_OCC_ATTR
+#endif
+constexpr int LW_COLS = 8, LW_BLOCK = 64 * LW_COLS, LW_UN = MDG_LW_UN, LW_GROUP = 16, LW_TP = LW_GROUP + 1;
+template <bool TR>
+__global__ __launch_bounds__(LO_THREADS) LW_OCC_ATTR void i8_lo_wide_kernel(LoArgs a) {
+  if (a.state[EXACT_RAN] != 1 || a.state[EXACT_OVERFLOW] != 0 || a.state[EXACT_MODE] != 2) return;
+  int p = 0;
+  while (p + 1 < a.nprob && (int)blockIdx.x >= a.prob[p + 1].tile0[TR]) p++;
+  if (a.route_flag[p] & 2) return;
+  const LoProblem& pr = a.prob[p];
+  const int n = pr.n, nG = n / LW_GROUP;
+  constexpr int PER = LW_BLOCK / LW_GROUP;     // groups per partner block
+  int t = blockIdx.x - pr.tile0[TR], G, P0, P1;
+  if (pr.block) {            // per-head statistics: the one partner block is the head
+    G = t;
+    P0 = 0;
+    P1 = 1;
+  } else {                   // partner block P of 512 columns, then the groups that have a column on the right side of it
+    int P = 0;
+    for (;;) {
+      const int cnt = TR ? min(nG, PER * (P + 1)) : nG - PER * P;
+      if (t < cnt) break;
+      t -= cnt;
+      P++;
+    }
+    G = TR ? t : PER * P + t;
+    P0 = P;
+    P1 = P + 1;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const char* const xs = TR ? (const char*)pr.xd : (const char*)pr.x;
+  typedef unsigned u32x4u __attribute__((ext_vector_type(4), aligned(2)));
+  __shared__ double tr_tile[TR ? LW_BLOCK * LW_TP : 1];      // TR: [partner row][column of the group], for the transposed fold
+  const int r = G * LW_GROUP + wave;
+  const int total = __builtin_amdgcn_readfirstlane(lo_totals(pr, a.nch)[r]);
+  const bool r_ours = total != 0 && !(pr.emax[r] & EMAX_COLUMN_OUT);
+  const LoEntry* list = pr.entries + (int64_t)r * a.nch * LO_CAP;
+  LoEntry m0 = LoEntry{0., 0u, 0u};            // the first 64 entries of the column's list: one per lane
+  if (r_ours) {
+    m0 = list[min(lane, min(total, 64) - 1)];
+    if (lane >= total) m0.v = 0.;              // (padding: the last entry's row, exact zeros)
+  }
+  for (int P = P0; P < P1; P++) {
+    const int p0 = pr.block ? G * LW_GROUP / pr.block * pr.block : P * LW_BLOCK;
+    const int pend = pr.block ? p0 + pr.block : min(n, p0 + LW_BLOCK);
+    const int c0 = p0 + LW_COLS * lane;                                   // this lane's partner columns c0 .. c0 + 7
+    // which of them exist, are ours (columns of the fp64 column kernel are not) and lie on this product's side of the diagonal
+    unsigned mine = 0;
+#pragma unroll
+    for (int j = 0; j < LW_COLS; j++)
+      if (c0 + j < pend && !(pr.emax[c0 + j] & EMAX_COLUMN_OUT) && (TR ? c0 + j >= r : c0 + j <= r)) mine |= 1u << j;
+    const unsigned lane_off = (unsigned)(c0 + LW_COLS <= pend ? c0 : p0) * 2u;   // (lanes beyond the block read its first columns; never used)
+    const bool walk = r_ours && __ballot(mine != 0) != 0;
+    double acc[LW_COLS];
+#pragma unroll
+    for (int j = 0; j < LW_COLS; j++) acc[j] = 0.;
+    if (walk) {
+      // super-batches of 64 entries (one per lane, broadcast with v_readlane), batches of LW_UN events whose partner loads are all
+      // issued before the previous batch is multiplied
+      for (int sb = 0; sb < total; sb += 64) {
+        const int len = min(64, total - sb);
+        LoEntry m = m0;
+        if (sb) {
+          m = list[sb + min(lane, len - 1)];
+          if (lane >= len) m.v = 0.;
+        }
+        const unsigned moff = TR ? m.aux : m.off;
+        u32x4 xa[LW_UN], xb[LW_UN];
+        auto issue = [&](int b, u32x4 (&xv)[LW_UN]) {
+#pragma unroll
+          for (int u = 0; u < LW_UN; u++) {
+            const unsigned o = (unsigned)__builtin_amdgcn_readlane((int)moff, b * LW_UN + u) + lane_off;
+            const u32x4u q = *(const u32x4u*)(xs + o);
+            xv[u] = (u32x4){q[0], q[1], q[2], q[3]};
+          }
+        };
+        auto multiply = [&](int b, const u32x4 (&xv)[LW_UN]) {
+#pragma unroll
+          for (int u = 0; u < LW_UN; u++) {
+            const double v = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(m.v), b * LW_UN + u),
+                                              __builtin_amdgcn_readlane(__double2loint(m.v), b * LW_UN + u));
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              acc[2 * q] = fma(v, (double)__uint_as_float(xv[u][q] << 16), acc[2 * q]);
+              acc[2 * q + 1] = fma(v, (double)__uint_as_float(xv[u][q] & 0xFFFF0000u), acc[2 * q + 1]);
+            }
+          }
+        };
+        const int nb = (len + LW_UN - 1) / LW_UN;      // 1 .. 8 batches
+        issue(0, xa);
+        for (int b = 0; b < nb; b += 2) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (b + 1 < nb) issue(b + 1, xb);
+          __builtin_amdgcn_sched_barrier(0);
+          multiply(b, xa);
+          if (b + 1 >= nb) break;
+          __builtin_amdgcn_sched_barrier(0);
+          if (b + 2 < nb) issue(b + 2, xa);
+          __builtin_amdgcn_sched_barrier(0);
+          multiply(b + 1, xb);
+        }
+      }
+    }
+    if (!TR) {
+      if (!walk) continue;
+      // the column's sums into its row of sigma (64 contiguous bytes per lane): all loads first
+      double* s[LW_COLS];
+      double old[LW_COLS];
+#pragma unroll
+      for (int j = 0; j < LW_COLS; j++) {
+        s[j] = (mine >> j & 1) ? pr.sigma + (int64_t)r * pr.ld_sigma + c0 + j - (pr.block ? r / pr.block * pr.block : 0) : nullptr;
+        old[j] = s[j] ? *s[j] : 0.;
+      }
+#pragma unroll
+      for (int j = 0; j < LW_COLS; j++)
+        if (s[j]) *s[j] = old[j] + acc[j];
+      continue;
+    }
+    // TR: the sums belong to COLUMN r of sigma.  Written from here they are 8-byte accesses a row pitch apart, sixteen waves on the
+    // same 128-byte lines one after the other (measured: the fold's L2 requests were 80 % of the walk's); through LDS every thread
+    // folds eight neighbouring columns of one partner row, 64 contiguous bytes.
+#pragma unroll
+    for (int j = 0; j < LW_COLS; j++) tr_tile[(LW_COLS * lane + j) * LW_TP + wave] = (walk && (mine >> j & 1)) ? acc[j] : 0.;
+    __syncthreads();
+    {
+      const int i = p0 + (threadIdx.x >> 1), half = threadIdx.x & 1;      // partner row i, columns G 16 + 8 half ..
+      if (i < pend && !(pr.emax[i] & EMAX_COLUMN_OUT)) {
+        double v[8], old[8];
+        double* s[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int col = G * LW_GROUP + 8 * half + k;
+          v[k] = tr_tile[(i - p0) * LW_TP + 8 * half + k];
+          s[k] = (v[k] != 0. && col <= i) ? pr.sigma + (int64_t)i * pr.ld_sigma + col - (pr.block ? i / pr.block * pr.block : 0) : nullptr;
+          old[k] = s[k] ? *s[k] : 0.;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+          if (s[k]) *s[k] = old[k] + v[k];
+      }
+    }
+    if (P + 1 < P1) __syncthreads();      // (the tile is written again)
+  }
 }
 
 // column maxima (n ints, padded to 8 bytes) + the [NSTAT][n] route statistics + the route kernel's ticket: zeroed together per call
@@ -1893,7 +2164,7 @@ const Schedule* schedule_for(const std::vector<std::pair<int, int>>& shapes, int
 // then the fp64 fallback's split-K space.
 constexpr size_t SHARED_BYTES = 256;
 struct ProblemWs {
-  size_t planes, ints, vals, route, colpart, zmask, lo_entries, lo_counts;   // byte offsets
+  size_t planes, ints, vals, route, colpart, zmask, lo_entries, lo_counts, lo_xd, lo_rentries, lo_rtotals;   // byte offsets
 };
 int lo_chunks(int64_t T) { return (int)ceil_div(ceil_div(T, (int64_t)KS), (int64_t)LO_CHUNK_STEPS); }
 size_t layout(int count, const mdg_cov_problem* pr, ProblemWs* out, size_t* fallback_off) {
@@ -1913,10 +2184,16 @@ size_t layout(int count, const mdg_cov_problem* pr, ProblemWs* out, size_t* fall
     off += align_up((size_t)ROUTE_JMAX * COLK_CHUNKS * (size_t)cols * sizeof(double), 256);
     w.zmask = off;
     off += zmask_bytes(pr[i].n_tokens, cols);
-    w.lo_entries = off = align_up(off, 256);     // the exact route's event lists: [cols / 32][chunks][LO_CAP] x 8 bytes, then the counts
-    off += (size_t)(cols / 32) * lo_chunks(pr[i].n_tokens) * LO_SUB * LO_CAP * sizeof(LoEntry);
+    w.lo_entries = off = align_up(off, 256);     // the exact route's event lists: [cols][chunks][LO_CAP] x 16 bytes, then the counts
+    off += (size_t)cols * lo_chunks(pr[i].n_tokens) * LO_CAP * sizeof(LoEntry);
     w.lo_counts = off;
-    off += align_up((size_t)(cols / 32) * LO_SUB * (lo_chunks(pr[i].n_tokens) + 1) * sizeof(int), 256);
+    off += align_up((size_t)cols * (lo_chunks(pr[i].n_tokens) + 1) * sizeof(int), 256);
+    w.lo_xd = off;                               // the x_d copy of the exact route: [tokens][cols] bf16
+    off += align_up((size_t)cols * (size_t)pr[i].n_tokens * sizeof(bf16_t), 256);
+    w.lo_rentries = off;                         // sparse mode: the merged (group, residue) lists and their lengths
+    off += (size_t)(cols / 32) * LO_SUB * LO_RCAP * sizeof(LoEntry);
+    w.lo_rtotals = off;
+    off += align_up((size_t)(cols / 32) * LO_SUB * sizeof(int), 256);
     if (out) out[i] = w;
     fb = std::max(fb, mdg_cov_accum_ws_bytes(pr[i].n_tokens, pr[i].n_feat, pr[i].batch));
   }
@@ -1971,7 +2248,9 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
                 tolerance);
   MDG_CHECK_ARG((flags & ~(MDG_I8_NO_EXACT | MDG_I8_EXACT_ALWAYS)) == 0 && flags != (MDG_I8_NO_EXACT | MDG_I8_EXACT_ALWAYS),
                 "mdg_cov_accum_i8_multi: bad flags 0x%x", flags);
-  const bool offer_exact = !(flags & MDG_I8_NO_EXACT);
+  bool offer_exact = !(flags & MDG_I8_NO_EXACT);
+  for (int i = 0; i < count; i++)     // (the event lists address a token's row with a 32-bit byte offset)
+    if ((uint64_t)problems[i].n_tokens * (uint64_t)problems[i].ld * 2ull >= (1ull << 32)) offer_exact = false;
   MDG_CHECK_ARG(problems_ok(count, problems),
                 "mdg_cov_accum_i8_multi: 1..%d statistics of the same token count; full ones need n_feat %% 128 == 0, per-head ones "
                 "head_dim 128 with contiguous [heads][128][128] sigma; leading dimensions at least the widths (use mdg_cov_accum)",
@@ -2048,7 +2327,8 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
     lo.route_flag = pflag;
     lo.state = flag;
     lo.always = (flags & MDG_I8_EXACT_ALWAYS) ? 1 : 0;
-    int tiles = 0, max_groups = 0;
+    lo.n_tokens = n_tokens;
+    int tiles[3] = {0, 0, 0}, max_groups = 0;
     for (int i = 0; i < count; i++) {
       const mdg_cov_problem& q = problems[i];
       const int n = (int)(q.n_feat * q.batch);
@@ -2056,19 +2336,35 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
       l.x = (const bf16_t*)q.x; l.ld = q.ld;
       l.planes = a.prob[i].planes; l.zmask = a.prob[i].zmask; l.emax = a.prob[i].emax;
       l.entries = (LoEntry*)((char*)ws + pw[i].lo_entries);
+      l.xd = (bf16_t*)((char*)ws + pw[i].lo_xd);
+      l.rentries = (LoEntry*)((char*)ws + pw[i].lo_rentries);
+      l.rtotals = (int*)((char*)ws + pw[i].lo_rtotals);
       l.pairs = ((uintptr_t)q.x % 4 == 0) && (q.ld % 2 == 0);
       l.counts = (int*)((char*)ws + pw[i].lo_counts);
       l.sigma = q.sigma; l.ld_sigma = q.ld_sigma;
       l.n = n; l.block = q.batch > 1 ? TI : 0;
-      l.tile0 = tiles;
+      const int nG = n / LW_GROUP, per = LW_BLOCK / LW_GROUP;
+      for (int tr = 0; tr < 2; tr++) {
+        l.tile0[tr] = tiles[tr];
+        if (q.batch > 1) {
+          tiles[tr] += nG;
+        } else {
+          for (int P = 0; P * per < nG; P++) tiles[tr] += tr ? std::min(nG, per * (P + 1)) : nG - per * P;
+        }
+      }
+      l.tile0[2] = tiles[2];
       const int rbi = n / TI;
-      tiles += q.batch > 1 ? rbi : rbi * (rbi + 1) / 2;
+      tiles[2] += q.batch > 1 ? rbi : rbi * (rbi + 1) / 2;
       max_groups = std::max(max_groups, n / 32);
     }
     for (int i = count; i < MAX_PROBLEMS; i++) lo.prob[i] = lo.prob[0];
-    lo.tiles = tiles;
+    for (int k = 0; k < 3; k++) lo.tiles[k] = tiles[k];
     hipLaunchKernelGGL(i8_extract_lo_kernel, dim3((unsigned)max_groups, (unsigned)lo.nch, (unsigned)count), dim3(64), 0, st, lo);
-    hipLaunchKernelGGL(i8_compact_lo_kernel, dim3((unsigned)(max_groups * LO_SUB), (unsigned)count), dim3(64), 0, st, lo);
+    hipLaunchKernelGGL(i8_compact_lo_kernel, dim3((unsigned)(max_groups * 32), (unsigned)count), dim3(64), 0, st, lo);
+    hipLaunchKernelGGL(i8_lo_mode_kernel, dim3(1), dim3(1024), 0, st, lo);
+    hipLaunchKernelGGL(i8_residue_lo_kernel, dim3((unsigned)(max_groups * LO_SUB), (unsigned)count), dim3(64), 0, st, lo);
+    hipLaunchKernelGGL(i8_copy_xd_kernel, dim3(2048u, (unsigned)count), dim3(256), 0, st, lo);
+    hipLaunchKernelGGL(i8_patch_xd_kernel, dim3((unsigned)(max_groups * 32), (unsigned)count), dim3(64), 0, st, lo);
     MDG_LAUNCH_CHECK();
     a.exact_state = flag + EXACT_OVERFLOW;
   }
@@ -2145,7 +2441,9 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
   if (offer_exact) {   // the remainder products of the exact route (every workgroup exits at once when the truncated product ran instead)
     const size_t lds = (size_t)LO_TILE * LO_PITCH * sizeof(double);
     MDG_HIP(hipFuncSetAttribute((const void*)i8_lo_product_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(i8_lo_product_kernel, dim3((unsigned)lo.tiles), dim3(LO_THREADS), lds, st, lo);
+    hipLaunchKernelGGL(i8_lo_product_kernel, dim3((unsigned)lo.tiles[2]), dim3(LO_THREADS), lds, st, lo);          // sparse lists
+    hipLaunchKernelGGL(i8_lo_wide_kernel<false>, dim3((unsigned)lo.tiles[0]), dim3(LO_THREADS), 0, st, lo);        // dense lists
+    hipLaunchKernelGGL(i8_lo_wide_kernel<true>, dim3((unsigned)lo.tiles[1]), dim3(LO_THREADS), 0, st, lo);
     MDG_LAUNCH_CHECK();
   }
   // the columns the route took off the int8 path: their rows / columns of sigma from the fp64 column kernel (both launches exit at

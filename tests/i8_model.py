@@ -158,17 +158,17 @@ def product(d, E, P):
     return acc * sc[:, None] * sc[None, :]
 
 
-LO_CHUNK_TOKENS, LO_SUB, LO_CAP, EXACT_ROUNDING = 64 * 32, 4, 512, 5e-15      # cov_i8.hip: LO_CHUNK_STEPS x KS, LO_SUB, LO_CAP; modegpt_hip.h: MDG_I8_EXACT_ROUNDING
+LO_CHUNK_TOKENS, LO_CAP, EXACT_ROUNDING = 64 * 32, 128, 5e-15      # cov_i8.hip: LO_CHUNK_STEPS x KS, LO_CAP; modegpt_hip.h: MDG_I8_EXACT_ROUNDING
 
 
 def list_counts(lo):
-    """lo [T, n] bool (element has L != 0) -> [segments, n / 32 groups, 4]: the lengths of the exact route's event lists -- one per
-    (2048-token segment, 32-column group, column index mod 4) (i8_extract_lo_kernel)."""
+    """lo [T, n] bool (element has L != 0) -> [segments, n]: the lengths of the exact route's event lists -- one per (2048-token
+    segment, column) (i8_extract_lo_kernel)."""
     T, n = lo.shape
     pad = (-T) % LO_CHUNK_TOKENS
     if pad:
         lo = np.concatenate([lo, np.zeros((pad, n), bool)])
-    return lo.reshape(-1, LO_CHUNK_TOKENS, n // 32, 32 // LO_SUB, LO_SUB).sum(axis=(1, 3))
+    return lo.reshape(-1, LO_CHUNK_TOKENS, n).sum(axis=1)
 
 
 def remainder_counts(d):

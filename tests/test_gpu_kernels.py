@@ -1053,15 +1053,14 @@ def test_exact_route_against_exact_integer_arithmetic(ops, dev, monkeypatch):
 
 
 def test_exact_route_gives_way_when_a_remainder_list_does_not_fit(ops, dev):
-    """The exact route is an optimisation of the route kernel's decision, never a different answer: where one 32-column x 2048-token
-    segment holds more remainder elements than its lists take (4 x 512 = 3.1 %) the call runs the truncated product it would have run
-    anyway -- same planes, same columns, the bound of that product -- and the host model predicts which."""
+    """The exact route is an optimisation of the route kernel's decision, never a different answer: where one column holds more
+    remainder elements in a 2048-token segment than its list takes (128 = 6.2 %) the call runs the truncated product it would have
+    run anyway -- same planes, same columns, the bound of that product -- and the host model predicts which."""
     gen = torch.Generator().manual_seed(5)
     T, n = 6144, 256
-    ref_err = {}
-    for deep_rows, want_exact in ((60, True), (70, False)):
+    for deep_rows, want_exact in ((120, True), (140, False)):
         X = acts(gen, T, n)
-        X[2048:2048 + deep_rows, 64:96] = (X[2048:2048 + deep_rows, 64:96].float() * 2.0 ** -20).to(torch.bfloat16)   # 32 x deep_rows deep elements in ONE segment
+        X[2048:2048 + deep_rows, 64:96] = (X[2048:2048 + deep_rows, 64:96].float() * 2.0 ** -20).to(torch.bfloat16)   # deep_rows deep elements per column in ONE segment
         S = torch.zeros(n, n, dtype=F64, device=dev)
         info = {}
         planes = ops.cov_accum_i8(S, X.to(dev), route_info=info)
