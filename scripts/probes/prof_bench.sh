@@ -18,14 +18,14 @@ DB=$(ls $OUT/*.db $OUT/*/*.db 2>/dev/null | head -1)
 python3 scripts/rocpd_summary.py $DB > gpurun_out/${TAG}_bench_kernel_trace_stats.csv
 python3 scripts/rocpd_summary.py $DB bygrid > gpurun_out/${TAG}_bench_kernel_trace_by_launch_shape.csv
 rm -rf $OUT
-grep -h "i8_syrk_kernelILi\|i8_lo_product" gpurun_out/${TAG}_bench_kernel_trace_by_launch_shape.csv | grep -v gated_out | cut -c1-200
+grep -h "i8_syrk_kernelILi\|i8_lo_" gpurun_out/${TAG}_bench_kernel_trace_by_launch_shape.csv | grep -v gated_out | cut -c1-200
 : > gpurun_out/${TAG}_cov_i8_pmc.csv
 for pass in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT"; do
   rm -rf $OUT
   (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --pmc $pass -d $OUT -o p -- python3 $R/scripts/bench_kernels.py covi8 covi8p6 > $R/gpurun_out/${TAG}_pmc_pass.log 2>&1) || { echo "PMC pass $pass failed"; tail -5 gpurun_out/${TAG}_pmc_pass.log; exit 1; }
   DB=$(ls $OUT/*.db $OUT/*/*.db 2>/dev/null | head -1)
   echo "# pass: $pass" >> gpurun_out/${TAG}_cov_i8_pmc.csv
-  python3 scripts/rocpd_summary.py $DB bygrid | grep -i "i8_syrk\|i8_lo_product\|^kernel" >> gpurun_out/${TAG}_cov_i8_pmc.csv
+  python3 scripts/rocpd_summary.py $DB bygrid | grep -i "i8_syrk\|i8_lo_\|i8_copy_xd\|^kernel" >> gpurun_out/${TAG}_cov_i8_pmc.csv
   rm -rf $OUT
 done
 python3 - <<PY
@@ -39,20 +39,24 @@ for l in rows:
     m = re.match(r'"(.*i8_syrk_kernelILi(\d)EE.*)",(\d+),(ran_long),(\d+),([0-9.]+),', l)
     if m:
         val[(m.group(2), "avg_ms")] = float(m.group(6))
-# the remainder kernel of the exact route (class "ran": it is not an i8_syrk launch); of its launch shapes, the sigma_mlp-sized grid
-lo_grid = max([int(m.group(2)) for m in (re.match(r'"(.*i8_lo_product_kernel.*)",(\d+),(ran),', l) for l in rows) if m] or [0])
-for l in rows:
-    m = re.match(r'"(.*i8_lo_product_kernel.*)",%d,(ran),(\w+),(\d+),([0-9.e+]+)' % lo_grid, l)
-    if m:
-        val[("lo", m.group(3))] = float(m.group(5))
-    m = re.match(r'"(.*i8_lo_product_kernel.*)",%d,(ran),(\d+),([0-9.]+),' % lo_grid, l)
-    if m:
-        val[("lo", "avg_ms")] = float(m.group(4))
+# the remainder kernels of the exact route (class "ran": not i8_syrk launches), each at its sigma_mlp-sized grid: the tile kernel ran on
+# the Gaussian call (sparse lists), the two wide kernels and the x_d copy on the SiLU-gated one (dense lists)
+for key, pat in (("lo", "i8_lo_product_kernel"), ("wide0", "i8_lo_wide_kernelILb0"), ("wide1", "i8_lo_wide_kernelILb1"), ("copy", "i8_copy_xd")):
+    grid = max([int(m.group(2)) for m in (re.match(r'"(.*%s.*)",(\d+),(ran),' % pat, l) for l in rows) if m] or [0])
+    for l in rows:
+        m = re.match(r'"(.*%s.*)",%d,(ran),(\w+),(\d+),([0-9.e+]+)' % (pat, grid), l)
+        if m and not m.group(3).isdigit():
+            val[(key, m.group(3))] = float(m.group(5))
+        m = re.match(r'"(.*%s.*)",%d,(ran),(\d+),([0-9.]+),' % (pat, grid), l)
+        if m:
+            val[(key, "avg_ms")] = float(m.group(4))
 out = {}
-if ("lo", "FETCH_SIZE") in val:
-    out["remainder_kernel"] = {"fetch_bytes_corrected": val[("lo", "FETCH_SIZE")] * 1024 * 2, "write_bytes": val.get(("lo", "WRITE_SIZE"), 0.0) * 1024,
-                               "avg_ms_under_profiler": val.get(("lo", "avg_ms")),
-                               "note": "i8_lo_product_kernel, mean over the Gaussian (near-empty lists) and the SiLU-gated (0.5 % of the elements) calls"}
+for key, name, note in (("lo", "remainder_tile_kernel", "i8_lo_product_kernel (sparse lists: the Gaussian call)"),
+                        ("wide0", "remainder_wide_kernel_rows", "i8_lo_wide_kernel<false> (dense lists: the SiLU-gated call)"),
+                        ("wide1", "remainder_wide_kernel_columns", "i8_lo_wide_kernel<true>"), ("copy", "x_d_copy", "i8_copy_xd_kernel")):
+    if (key, "FETCH_SIZE") in val:
+        out[name] = {"fetch_bytes_corrected": val[(key, "FETCH_SIZE")] * 1024 * 2, "write_bytes": val.get((key, "WRITE_SIZE"), 0.0) * 1024,
+                     "avg_ms_under_profiler": val.get((key, "avg_ms")), "note": note + ", launches that did the work"}
 for P in ("3", "5", "6"):
     if (P, "FETCH_SIZE") in val:
         fetch, write = val[(P, "FETCH_SIZE")] * 1024 * 2, val.get((P, "WRITE_SIZE"), 0.0) * 1024

@@ -1,7 +1,8 @@
 """Summarise a rocprofv3 rocpd .db: per-kernel dispatch stats (and PMC counter sums if present) as CSV on stdout.
 With a second argument `bygrid`, kernels are additionally split by their grid size (one row per launch shape) and by whether
 the launch did work: mdg_cov_accum_i8 enqueues the five-plane product, the six-plane product and the fp64 kernel for every
-call and the device picks one -- the other launches exit on their first instruction (a few microseconds).  Dispatches shorter
+call and the device picks one -- the other launches exit on their first instruction (a few microseconds); the same holds for the
+exact route's remainder kernels (tile kernel for sparse event lists, wide kernels + x_d copy for dense ones).  Dispatches shorter
 than GATE_MS are listed as `gated_out` rows so that the averages of the launches that ran are not diluted.  Since the persistent
 launch gives every product launch the same grid (256 workgroups), the i8_syrk launches that ran are further split by duration:
 `ran_long` (>= LONG_MS: the sigma_mlp-sized statistics) and `ran` (sigma_x-sized)."""
@@ -13,7 +14,8 @@ cur = db.cursor()
 BYGRID = len(sys.argv) > 2 and sys.argv[2] == "bygrid"
 GATE_MS = 0.03
 LONG_MS = 10.0
-GATED = ("(s.kernel_name like '%%i8_syrk_kernel%%' or s.kernel_name like '%%cov_accum_kernel%%') and (d.end-d.start) < %d"
+GATED = ("(s.kernel_name like '%%i8_syrk_kernel%%' or s.kernel_name like '%%cov_accum_kernel%%' or s.kernel_name like '%%i8_lo_%%' or "
+         "s.kernel_name like '%%i8_copy_xd%%' or s.kernel_name like '%%i8_patch_xd%%' or s.kernel_name like '%%i8_residue_lo%%') and (d.end-d.start) < %d"
          % int(GATE_MS * 1e6))
 LONG = "s.kernel_name like '%%i8_syrk_kernel%%' and (d.end-d.start) >= %d" % int(LONG_MS * 1e6)
 CLASS = "case when %s then 'gated_out' when %s then 'ran_long' else 'ran' end" % (GATED, LONG)
