@@ -1892,13 +1892,10 @@ __global__ __launch_bounds__(LO_THREADS) LW_OCC_ATTR void i8_lo_wide_kernel(LoAr
   const LoProblem& pr = a.prob[p];
   const int n = pr.n, nG = n / LW_GROUP;
   constexpr int PER = LW_BLOCK / LW_GROUP;     // groups per partner block
-  int t = blockIdx.x - pr.tile0[TR], G, P0, P1;
+  int t = blockIdx.x - pr.tile0[TR], G, P = 0;
   if (pr.block) {            // per-head statistics: the one partner block is the head
     G = t;
-    P0 = 0;
-    P1 = 1;
   } else {                   // partner block P of 512 columns, then the groups that have a column on the right side of it
-    int P = 0;
     for (;;) {
       const int cnt = TR ? min(nG, PER * (P + 1)) : nG - PER * P;
       if (t < cnt) break;
@@ -1906,8 +1903,6 @@ __global__ __launch_bounds__(LO_THREADS) LW_OCC_ATTR void i8_lo_wide_kernel(LoAr
       P++;
     }
     G = TR ? t : PER * P + t;
-    P0 = P;
-    P1 = P + 1;
   }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1923,7 +1918,7 @@ __global__ __launch_bounds__(LO_THREADS) LW_OCC_ATTR void i8_lo_wide_kernel(LoAr
     m0 = list[min(lane, min(total, 64) - 1)];
     if (lane >= total) m0.v = 0.;              // (padding: the last entry's row, exact zeros)
   }
-  for (int P = P0; P < P1; P++) {
+  {
     const int p0 = pr.block ? G * LW_GROUP / pr.block * pr.block : P * LW_BLOCK;
     const int pend = pr.block ? p0 + pr.block : min(n, p0 + LW_BLOCK);
     const int c0 = p0 + LW_COLS * lane;                                   // this lane's partner columns c0 .. c0 + 7
@@ -1985,7 +1980,7 @@ __global__ __launch_bounds__(LO_THREADS) LW_OCC_ATTR void i8_lo_wide_kernel(LoAr
       }
     }
     if (!TR) {
-      if (!walk) continue;
+      if (!walk) return;
       // the column's sums into its row of sigma (64 contiguous bytes per lane): all loads first
       double* s[LW_COLS];
       double old[LW_COLS];
@@ -1997,7 +1992,7 @@ __global__ __launch_bounds__(LO_THREADS) LW_OCC_ATTR void i8_lo_wide_kernel(LoAr
 #pragma unroll
       for (int j = 0; j < LW_COLS; j++)
         if (s[j]) *s[j] = old[j] + acc[j];
-      continue;
+      return;
     }
     // TR: the sums belong to COLUMN r of sigma.  Written from here they are 8-byte accesses a row pitch apart, sixteen waves on the
     // same 128-byte lines one after the other (measured: the fold's L2 requests were 80 % of the walk's); through LDS every thread
@@ -2022,7 +2017,6 @@ __global__ __launch_bounds__(LO_THREADS) LW_OCC_ATTR void i8_lo_wide_kernel(LoAr
           if (s[k]) *s[k] = old[k] + v[k];
       }
     }
-    if (P + 1 < P1) __syncthreads();      // (the tile is written again)
   }
 }
 
