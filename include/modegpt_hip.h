@@ -172,9 +172,9 @@ int mdg_cov_accum_i8_stats(const void* ws, int64_t n_tokens, int64_t n_feat, uns
 /* The route the LAST mdg_cov_accum_i8 / mdg_cov_accum_i8_multi call on workspace `ws` took for statistic `stat` of `problems` (the
  * array that call was given): *planes = 5, 6, or 0 (whole statistic through mdg_cov_accum); *n_columns and columns[MDG_I8_MAX_COLUMNS]
  * (-1 padded) = the columns the fp64 column kernel computed, in the order the route took them; bound[0] = SQ_P, bound[1] = X_P of
- * the columns that stayed (their sum bounds the entry-wise error relative to sqrt(sigma_ii sigma_jj) of this call's tokens); *exact = 1
- * when the call ran the exact route (then bound[0] = the rho term + MDG_I8_EXACT_ROUNDING, bound[1] = 0).  Any output pointer may be
- * NULL.  Copies device -> host on `stream` and synchronises it: tests and measurements only. */
+ * the columns that stayed (their sum bounds the entry-wise error relative to sqrt(sigma_ii sigma_jj) of this call's tokens); *exact != 0
+ * when the call ran the exact route -- 1: its remainder products on the tile kernel (sparse event lists), 2: on the wide kernels --
+ * and then bound[0] = the rho term + MDG_I8_EXACT_ROUNDING, bound[1] = 0.  Any output pointer may be NULL.  Copies device -> host on `stream` and synchronises it: tests and measurements only. */
 int mdg_cov_accum_i8_route(int count, const mdg_cov_problem* problems, int stat, const void* ws, int* planes, int* n_columns,
                            int* columns, double* bound, int* exact, void* stream);
 /* Up to 4 statistics of ONE calibration batch (the four hooks of a layer) through the int8 digit-plane kernels with ONE

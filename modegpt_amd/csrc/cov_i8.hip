@@ -2562,13 +2562,13 @@ extern "C" int mdg_cov_accum_i8_route(int count, const mdg_cov_problem* problems
   ProblemWs pw[MAX_PROBLEMS];
   layout(count, problems, pw, nullptr);
   RouteOut r;
-  int state[2] = {0, 0};
+  int state[3] = {0, 0, 0};      // EXACT_OVERFLOW, EXACT_RAN, EXACT_MODE
   hipStream_t st = (hipStream_t)stream;
   MDG_HIP(hipMemcpyAsync(&r, (const char*)ws + pw[stat].route, sizeof(r), hipMemcpyDeviceToHost, st));
   MDG_HIP(hipMemcpyAsync(state, (const int*)ws + EXACT_OVERFLOW, sizeof(state), hipMemcpyDeviceToHost, st));
   MDG_HIP(hipStreamSynchronize(st));
   const bool was_exact = r.planes != 0 && state[1] == 1 && state[0] == 0;
-  if (exact) *exact = was_exact ? 1 : 0;
+  if (exact) *exact = was_exact ? state[2] : 0;      // 1: the remainder ran on the tile kernel (sparse lists), 2: on the wide kernels
   if (planes) *planes = r.planes;
   if (n_columns) *n_columns = r.n_out;
   if (columns)

@@ -118,7 +118,8 @@ def cov_accum_i8(sigma: torch.Tensor, x: torch.Tensor, events=None, mfma_stats: 
     i8_route_counts() are updated by the kernels themselves in both modes.  Feature count must be a multiple of 128.
     route_info: optional dict, filled with {"planes", "columns" (those the fp64 column kernel computed), "sq", "x" (the two parts
     of the bound for the columns that stayed), "bound" (their sum), "exact" (the call ran the exact route: no plane pair dropped,
-    the bound is the rounded-element term + fp64 rounding)} -- implies report.
+    the bound is the rounded-element term + fp64 rounding), "remainder" ("tiles" / "wide": which implementation of the exact
+    route's remainder products the device picked; None off the exact route)} -- implies report.
     events: optional pair of torch.cuda.Event(enable_timing=True), each recorded once already, re-recorded around the product
     launches alone.  mfma_stats: optional dict; its "executed" entry is increased by the number of v_mfma instructions the
     product kernel issued (it skips digit planes that are all-zero over a tile panel) and "dense" by what a kernel without
@@ -171,7 +172,8 @@ def _read_route(lib, count, arr, stat, wsp, stream) -> dict:
     check(lib.mdg_cov_accum_i8_route(count, arr, stat, wsp, C.byref(planes), C.byref(ncol), cols, bound, C.byref(exact), stream),
           "mdg_cov_accum_i8_route")
     return {"planes": planes.value, "columns": [cols[i] for i in range(ncol.value)], "sq": bound[0], "x": bound[1],
-            "bound": bound[0] + bound[1], "exact": bool(exact.value)}
+            "bound": bound[0] + bound[1], "exact": bool(exact.value),
+            "remainder": {0: None, 1: "tiles", 2: "wide"}.get(exact.value)}
 
 
 # The exact route of the int8 covariance (include/modegpt_hip.h, "THE EXACT ROUTE"): "auto" (default) takes it where it is the

@@ -1029,6 +1029,8 @@ def test_exact_route_against_exact_integer_arithmetic(ops, dev, monkeypatch):
         info = {}
         assert ops.cov_accum_i8(S, X.to(dev), route_info=info) == 6 and info["exact"] and info["columns"] == [], info
         assert info["x"] == 0.0 and info["bound"] == 5e-15                  # (nothing rounded to an integer: the rho term is zero)
+        # 900 tokens: ~6 listed elements per column -> the tile kernel; 3000 tokens: ~16 -> the wide kernels (both against exact arithmetic)
+        assert info["remainder"] == ("tiles" if T == 900 else "wide"), info
         ops.cov_accum_i8(S2, X.to(dev))
         ex = _exact_sigma(X)
         total = [[a + b for a, b in zip(ra, rb)] for ra, rb in zip(total, ex)]
