@@ -1494,7 +1494,14 @@ constexpr int LO_CHUNK_STEPS = 64;       // k-steps (2048 tokens) per segment of
 constexpr int LO_CAP = 128;              // events per segment: 6.2 % of its 2048 tokens
 constexpr double LO_ROUND = 8421504.0 / 16777216.0;   // (128 (1 + 256 + 65536)) / 2^24: where the balanced digits d_3 d_4 d_5 round
 constexpr int EXACT_OVERFLOW = 16, EXACT_RAN = 17, EXACT_MODE = 18;    // ints of the workspace's shared block (MODE: 1 sparse lists, 2 dense)
-constexpr int LO_SUB = 4, LO_RCAP = 512;              // sparse lists: one per (32-column group, column mod 4), of at most 8 x 64 events
+#ifndef MDG_LO_SPARSE_MEAN
+#define MDG_LO_SPARSE_MEAN 32
+#endif
+#ifndef MDG_LO_SPARSE_MAX
+#define MDG_LO_SPARSE_MAX 256
+#endif
+constexpr int LO_SPARSE_MAX = MDG_LO_SPARSE_MAX;      // sparse lists: at most this many events in any column, LO_SPARSE_MEAN on average
+constexpr int LO_SUB = 4, LO_RCAP = 8 * LO_SPARSE_MAX;   // one merged list per (32-column group, column mod 4)
 constexpr int LO_TILE = 128, LO_PITCH = LO_TILE + 1;
 
 struct __attribute__((aligned(16))) LoEntry {
@@ -1620,13 +1627,15 @@ __global__ __launch_bounds__(64) void i8_compact_lo_kernel(LoArgs a) {
 }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-// Which remainder kernels run, from the list lengths (one workgroup; read by everything below): SPARSE lists -- at most 64 events in
-// any column and LO_SPARSE_MEAN per column on average: Gaussian columns have two -- go to the 128 x 128-tile kernel, where a tile is
-// one chain of memory round trips around a handful of products and sigma is read and written ONCE for both products; anything denser
-// (SiLU-gated: 156 per column) to the wide kernels, which are bound by their instruction stream and need 2.4 x fewer instructions per
-// product.  Measured at the sigma_mlp shape, both products, Gaussian / SiLU-gated: tiles 1.04 / 9.3 ms, wide 1.8 / 5.4 (+ 0.55 for
-// the x_d copy).
-constexpr int LO_SPARSE_MEAN = 8;
+// Which remainder kernels run, from the list lengths (one workgroup; read by everything below): SPARSE lists -- at most LO_SPARSE_MAX
+// events in any column and LO_SPARSE_MEAN per column on average: Gaussian columns have two per 32768 tokens -- go to the 128 x 128-tile
+// kernel, where a tile is one chain of memory round trips around a handful of products and sigma is read and written ONCE for both
+// products; anything denser (SiLU-gated: 164 per column and 32768 tokens) to the wide kernels, which need 2.4 x fewer instructions per
+// product but pay 0.5 ms for the x_d copy and a dependent chain per (column, partner block).  Measured at the sigma_mlp width, whole
+// call, SiLU-gated columns, 2048 / 4096 / 8192 / 16384 / 32768 tokens = 10 / 20 / 41 / 82 / 164 events per column
+// (scripts/probes/lo_mode_crossover.sh, profiles/r04_lo_mode_crossover.log): tiles 3.11 / 4.78 / 8.23 / 15.3 / 29.8 ms, wide 3.79 /
+// 5.25 / 8.15 / 14.0 / 26.6 -- they cross at ~38; Gaussian columns at 32768 tokens: tiles 1.0 ms, wide 1.8 + 0.5.
+constexpr int LO_SPARSE_MEAN = MDG_LO_SPARSE_MEAN;
 __global__ __launch_bounds__(1024) void i8_lo_mode_kernel(LoArgs a) {
   if (!lo_offered(a) || a.state[EXACT_OVERFLOW] != 0) return;
   __shared__ long long sums[16];
@@ -1651,7 +1660,7 @@ __global__ __launch_bounds__(1024) void i8_lo_mode_kernel(LoArgs a) {
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < 16; w++) { sum += sums[w]; mx = max(mx, maxs[w]); }
-    a.state[EXACT_MODE] = (mx <= 64 && sum <= LO_SPARSE_MEAN * cols) ? 1 : 2;
+    a.state[EXACT_MODE] = (mx <= LO_SPARSE_MAX && sum <= LO_SPARSE_MEAN * cols) ? 1 : 2;
   }
 }
 
@@ -1668,11 +1677,11 @@ __global__ __launch_bounds__(64) void i8_residue_lo_kernel(LoArgs a) {
   int at = 0;
   for (int k = 0; k < 8; k++) {
     const int col = G * 32 + 4 * k + sub;
-    const int cnt = lo_totals(pr, a.nch)[col];           // <= 64 (the mode says so)
-    if (lane < cnt) {
-      LoEntry e = pr.entries[(int64_t)col * a.nch * LO_CAP + lane];
+    const int cnt = lo_totals(pr, a.nch)[col];           // <= LO_SPARSE_MAX (the mode says so)
+    for (int i = lane; i < cnt; i += 64) {
+      LoEntry e = pr.entries[(int64_t)col * a.nch * LO_CAP + i];
       e.aux = 4 * k + sub;
-      out[at + lane] = e;
+      out[at + i] = e;
     }
     at += cnt;
   }

@@ -1019,6 +1019,10 @@ def test_exact_route_against_exact_integer_arithmetic(ops, dev, monkeypatch):
         X[8, 4], X[9, 4] = top * 255 * 2.0 ** -23, -top * 255 * 2.0 ** -23  # just under it
         X[10, 5], X[11, 5] = top * 131 * 2.0 ** -23, -top * 2.0 ** -37      # just over it; nearly the deepest exact element
         X[12, 6], X[13, 6] = top * 255 * 2.0 ** -30, -top * 255 * 2.0 ** -30  # N = 255 2^15: digits (.., 1, -128, -128, -128) -> L = -8421376 < -2^23
+        if T > 2200:      # 2 x 90 rows 16 - 17 binades under the column maximum, in two different 2048-token segments: ~200 listed elements per column
+            for r0 in (100, 2100):
+                deep = (torch.rand(90, n, generator=gen) + 0.5) * torch.sign(torch.randn(90, n, generator=gen)) * top * 2.0 ** -16
+                X[r0:r0 + 90] = deep.to(torch.bfloat16)
         return X
     S = torch.zeros(n, n, dtype=F64, device=dev)
     S2 = torch.zeros_like(S)
@@ -1029,7 +1033,7 @@ def test_exact_route_against_exact_integer_arithmetic(ops, dev, monkeypatch):
         info = {}
         assert ops.cov_accum_i8(S, X.to(dev), route_info=info) == 6 and info["exact"] and info["columns"] == [], info
         assert info["x"] == 0.0 and info["bound"] == 5e-15                  # (nothing rounded to an integer: the rho term is zero)
-        # 900 tokens: ~6 listed elements per column -> the tile kernel; 3000 tokens: ~16 -> the wide kernels (both against exact arithmetic)
+        # 900 tokens: ~6 listed elements per column -> the tile kernel; 3000 tokens: ~200 -> the wide kernels (both against exact arithmetic)
         assert info["remainder"] == ("tiles" if T == 900 else "wide"), info
         ops.cov_accum_i8(S2, X.to(dev))
         ex = _exact_sigma(X)
