@@ -9,6 +9,7 @@ from modegpt_amd import ops
 dev = torch.device("cuda:0"); F64 = torch.float64
 g = torch.Generator().manual_seed(int(sys.argv[1]) if len(sys.argv) > 1 else 7)
 worst, routes, bad, worst_ratio, cols_out, worst_bound = 0.0, {}, 0, 0.0, 0, 0.0
+exact_calls = wide_calls = 0
 TMAX = int(sys.argv[3]) if len(sys.argv) > 3 else 6000          # python i8_fuzz.py <seed> <cases> [max tokens] [max width / 128]
 NMAX = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 TOL = float(os.environ.get("MODEGPT_I8_TOLERANCE", "1"))        # (the route's tolerance dial scales the measured-typical limit with it)
@@ -36,10 +37,15 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 120):
     err = (((S8 - S64).abs() / (d[:, None] * d[None]))[low]).max().item()
     worst = max(worst, err)
     if r:
-        worst_ratio = max(worst_ratio, err / max(info["bound"], 1e-300) if err > 4e-16 else 0.0)
+        if not info.get("exact"):
+            worst_ratio = max(worst_ratio, err / max(info["bound"], 1e-300) if err > 4e-16 else 0.0)
         worst_bound = max(worst_bound, info["bound"])
-    if not err < 1e-12 * TOL or (r and err > info["bound"] + 4e-16):
+    # (a call on the exact route is closer to the true sum than the fp64 kernel it is compared with, whose own rounding is up to
+    #  ~2e-13 of sqrt(sigma_ii sigma_jj) at these sizes: tests/i8_limits.REFERENCE_ROUNDING)
+    exact_calls += bool(info.get("exact"))
+    wide_calls += info.get("remainder") == "wide"
+    if not err < 1e-12 * TOL or (r and err > info["bound"] + (3e-13 if info.get("exact") else 4e-16)):
         bad += 1
         print(f"VIOLATION trial {trial}: T={T} n={n} kind={kind} route={r} err={err:.2e} bound={info['bound']:.2e} columns={info['columns']}")
 print(f"routes {routes}; worst error {worst:.2e}; largest bound {worst_bound:.2e}; largest measured / bound {worst_ratio:.3f}; "
-      f"columns sent to the fp64 column kernel {cols_out}; violations {bad}")
+      f"columns sent to the fp64 column kernel {cols_out}; calls on the exact route {exact_calls} (remainder on the wide kernels: {wide_calls}); violations {bad}")
