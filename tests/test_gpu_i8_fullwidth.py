@@ -395,3 +395,40 @@ def test_cov_accum_multi_routes_a_llama_layer(ops, dev, monkeypatch):
     assert c0 == {"i8_5": 1, "i8_6": 1, "fallback_f64": 0, "fp64_columns": 0, "exact": 1}   # separate launches: sigma_mlp, sigma_x; heads fp64
     for i, (a, b) in enumerate(zip(fused, apart)):
         _check_against(a, b, None, "silu_gated" if i == 0 else "gaussian")
+
+
+def test_wide_remainder_kernels_at_their_edges(ops, dev, monkeypatch):
+    """The dense-list implementation of the exact route's remainder (i8_lo_wide_kernel: one wave per column and 512 partner columns)
+    where its indexing is not the plain case: a statistic whose width is not a multiple of 512 (the last partner block holds 128
+    columns), columns the route hands to the fp64 column kernel in the middle of SiLU-gated data (rows / columns the remainder must
+    leave alone), and per-head statistics that are dense themselves (the partner block is the head).  Every statistic against the
+    v_mfma_f64 kernel within its own bound; the calls say the wide kernels ran."""
+    monkeypatch.setattr(ops, "I8_EXACT", True)
+    T = 16384                                               # ~80 listed elements per SiLU-gated column: the wide kernels
+    # (a) 640 = 512 + 128 columns
+    X = silu_gated(dev, T, 640, 31)
+    S, R, info = torch.zeros(640, 640, dtype=F64, device=dev), torch.zeros(640, 640, dtype=F64, device=dev), {}
+    ops.cov_accum_i8(S, X, route_info=info)
+    ops.cov_accum(R, X)
+    assert info["exact"] and info["remainder"] == "wide", info
+    check_i8_error(entrywise_err(S, R), info["bound"], family="silu_gated")
+    # (b) massive-activation columns leave; the others stay exact
+    Xm = massive(silu_gated(dev, T, 2048, 32), [5, 700, 2047], gap=14)
+    S, R, info = torch.zeros(2048, 2048, dtype=F64, device=dev), torch.zeros(2048, 2048, dtype=F64, device=dev), {}
+    ops.cov_accum_i8(S, Xm, route_info=info)
+    ops.cov_accum(R, Xm)
+    assert info["exact"] and info["remainder"] == "wide" and sorted(info["columns"]) == [5, 700, 2047], info
+    check_i8_error(entrywise_err(S, R), info["bound"], family="outliers")
+    # (c) a launch whose per-head statistics are SiLU-gated too
+    items, refs = [(torch.zeros(2048, 2048, dtype=F64, device=dev), silu_gated(dev, T, 2048, 33), 1)], []
+    for j, nh in enumerate((6, 2)):
+        items.append((torch.zeros(nh, 128, 128, dtype=F64, device=dev), silu_gated(dev, T, nh * 128, 34 + j), nh))
+    for sigma, Xi, nh in items:
+        Ri = torch.zeros_like(sigma)
+        ops.cov_accum(Ri, Xi, n_heads=nh)
+        refs.append(Ri)
+    infos = []
+    ops.cov_accum_i8_multi(items, report=True, route_info=infos)
+    assert all(i_["exact"] and i_["remainder"] == "wide" for i_ in infos), infos
+    for (Si, _, _), Ri, i_ in zip(items, refs, infos):
+        _check_against(Si, Ri, i_["bound"], "silu_gated")
