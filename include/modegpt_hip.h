@@ -136,7 +136,7 @@ int mdg_cov_accum_multi(int n, const mdg_cov_problem* problems, int dtype, void*
  *   8e-14, the sigma_mlp launch 29 instead of 37 ms -- and fewer columns on the fp64 column kernel.  The call still computes and
  *   reports its own bound (mdg_cov_accum_i8_route), so what was guaranteed for a given input is known, whatever f.  An argument,
  *   not process state: concurrent callers with different factors do not see each other.  Not in the reference (plain fp64 there).
- * n_feat must be a multiple of 128, n_tokens < 2^28.  ws: mdg_cov_accum_i8_ws_bytes (about 9.5 bytes per element of x: six digit planes, the
+ * n_feat must be a multiple of 128, n_tokens < 2^28.  ws: mdg_cov_accum_i8_ws_bytes (about 10 bytes per element of x: six digit planes, the
  * exact route's event lists and its bf16 copy of x).
  * ev_start / ev_stop: optional hipEvent_t recorded on `stream` right before / after the two product launches (bench.py times
  * the dominant kernel alone with them); NULL otherwise. */
