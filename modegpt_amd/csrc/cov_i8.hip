@@ -1738,9 +1738,27 @@ __device__ __forceinline__ int lo_perm(int i) { return (i >> 1) + 64 * (i & 1); 
 // by the VALU (7 - 14 operations per event): the events go in batches of LO_UN whose loads are all issued before the previous
 // batch is multiplied (two batches in flight per wave, sixteen waves per CU).
 constexpr int LO_UN = 32;
+// The length of list (G, sub) and its first batch of entries, one per lane (lanes beyond the list's end: the last entry's token,
+// v = 0: exact zeros) -- fetched for BOTH passes of a tile before the first one starts, so that the second pass does not begin with
+// two dependent memory round trips of its own.
+struct LoFirst {
+  int cnt;
+  LoEntry m;
+};
+__device__ __forceinline__ LoFirst lo_first(const LoProblem& pr, const int G, const int sub, const int lane) {
+  const int list_id = G * LO_SUB + sub;
+  LoFirst f;
+  f.cnt = __builtin_amdgcn_readfirstlane(pr.rtotals[list_id]);
+  f.m = LoEntry{0., 0u, 0u};
+  if (f.cnt > 0) {
+    f.m = pr.rentries[(int64_t)list_id * LO_RCAP + min(lane & (LO_UN - 1), f.cnt - 1)];
+    if ((lane & (LO_UN - 1)) >= f.cnt) f.m.v = 0.;
+  }
+  return f;
+}
 template <bool COLS>
 __device__ __forceinline__ void lo_events(const LoProblem& pr, const int nch, const int G, const int sub, const int partner0, const int g,
-                                          const int lane, double* acc) {
+                                          const int lane, double* acc, const LoFirst& first) {
   const unsigned short* xs = (const unsigned short*)pr.x;
   unsigned lim_a = 0, lim_b = 0;
   double qa = 1., qb = 1., ia = 1., ib = 1.;
@@ -1755,7 +1773,7 @@ __device__ __forceinline__ void lo_events(const LoProblem& pr, const int nch, co
     lim_b = (unsigned)max(eb - 14, 1) << 7;
   }
   const int list_id = G * LO_SUB + sub;
-  const int cnt = pr.rtotals[list_id];
+  const int cnt = first.cnt;
   const LoEntry* list = pr.rentries + (int64_t)list_id * LO_RCAP;
   // batch k: events [k LO_UN, ...) -- one entry per lane (lanes beyond the list's end: the last entry's token, v = 0: exact zeros)
   auto fetch = [&](int k, LoEntry& m) {
@@ -1792,9 +1810,8 @@ __device__ __forceinline__ void lo_events(const LoProblem& pr, const int nch, co
   };
   if (cnt == 0) return;
   const int nb = (cnt + LO_UN - 1) / LO_UN;
-  LoEntry mA, mB;
+  LoEntry mA = first.m, mB;
   unsigned xA[LO_UN], xB[LO_UN];
-  fetch(0, mA);
   issue(mA, xA);
   for (int k = 0; k < nb; k += 2) {
     if (k + 1 < nb) {
@@ -1840,11 +1857,12 @@ __global__ __launch_bounds__(LO_THREADS) void i8_lo_product_kernel(LoArgs a) {
   int any = 0;
   if (tid < 8 * LO_SUB) any = pr.rtotals[(tid < 4 * LO_SUB ? 4 * bi * LO_SUB : 4 * bj * LO_SUB - 4 * LO_SUB) + tid];
   if (!__syncthreads_or(any)) return;
+  const LoFirst first_rows = lo_first(pr, 4 * bi + g, sub, lane), first_cols = lo_first(pr, 4 * bj + g, sub, lane);
   for (int i = tid; i < LO_TILE * LO_PITCH; i += LO_THREADS) lo_acc[i] = 0.;
   __syncthreads();
-  lo_events<false>(pr, a.nch, 4 * bi + g, sub, bj * LO_TILE, g, lane, lo_acc);
+  lo_events<false>(pr, a.nch, 4 * bi + g, sub, bj * LO_TILE, g, lane, lo_acc, first_rows);
   __syncthreads();      // an accumulator changes owner between the two passes: the wave of its row, then the wave of its column
-  lo_events<true>(pr, a.nch, 4 * bj + g, sub, bi * LO_TILE, g, lane, lo_acc);
+  lo_events<true>(pr, a.nch, 4 * bj + g, sub, bi * LO_TILE, g, lane, lo_acc, first_cols);
   __syncthreads();
   // the tile's 16 elements of a thread: all their sigma loads first, then the additions and the stores (written as `*s += v` behind
   // the tests, every element paid a memory round trip of its own: 16 in series per tile, most of the kernel's time on sparse lists)
