@@ -351,9 +351,9 @@ __global__ __launch_bounds__(256) void lower_abs_rowsum_kernel(const double* X, 
 
 
 // Two-level right-looking Cholesky.  Inner level: 128-wide panels (diagonal block factorised + inverted in LDS,
-// panel solve = GEMM with the inverse), whose rank-128 updates touch only the rest of the current 512-wide OUTER
-// panel.  Outer level: one rank-512 lower-only update of everything behind the outer panel.  A rank-128 update of a
-// 128x128 fp64 tile moves 512 KB for 4.2 MFLOP (8 flop/B: HBM-bound at ~30 TF); rank-512 quadruples the intensity
+// panel solve = GEMM with the inverse), whose rank-128 updates touch only the rest of the current NBO-wide OUTER
+// panel.  Outer level: one rank-NBO lower-only update of everything behind the outer panel.  A rank-128 update of a
+// 128x128 fp64 tile moves 512 KB for 4.2 MFLOP (8 flop/B: HBM-bound at ~30 TF); rank-512 already quadruples the intensity
 // and puts the bulk of the n^3/3 flops back under the MFMA roof.
 #ifndef MDG_CHOL_TILE_KERNELS
 #define MDG_CHOL_TILE_KERNELS 1   // panel solve and rank-128 update as LDS-resident 128^3 tiles (potrf_tile_kernel) instead of the general GEMM
@@ -362,7 +362,11 @@ __global__ __launch_bounds__(256) void lower_abs_rowsum_kernel(const double* X, 
 #define MDG_CHOL_LOOKAHEAD 1      // the update launch of step k factorises diagonal block k + 1 in its first workgroup (see potrf_tile_kernel)
 #endif
 #ifndef MDG_CHOL_NBO
-#define MDG_CHOL_NBO 1024   // (512: 63.0 + 72.2 ms for the ridge scores + Nystrom solve of a Llama-3-8B layer; 1024: 62.5 + 69.7; 256: 66.4 + 76.3)
+#define MDG_CHOL_NBO 2048   // (round 2, ridge scores + Nystrom solve of a Llama-3-8B layer: 256: 66.4 + 76.3 ms; 512: 63.0 + 72.2; 1024: 62.5 + 69.7.
+                            //  Round 4, with the next diagonal block factorised inside the update launch the inner steps got cheaper
+                            //  and the optimum moved: potrf_lower at n = 14336 + 10035: 512: 31.7 + 17.4 ms; 1024: 29.6 + 16.3;
+                            //  1536: 29.3 + 15.7; 2048: 28.8 + 15.2; 2560: 29.2 + 15.3; 3072: 29.6 + 15.6; 4096: 30.4 + 16.1 --
+                            //  profiles/r04_cholesky_outer_block.log)
 #endif
 constexpr int NBO = MDG_CHOL_NBO;
 
