@@ -56,27 +56,40 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const Acc& acc,
                                               int wr, int wc, int lane) {
   const bool c_bf16 = (g.c_dtype == MDG_BF16);
   char* Cb = (char*)g.C + batch * g.c_bs * (c_bf16 ? 2 : 8);
+  const int64_t gc0 = j0 + acc_col(wc, lane, 0);
 #pragma unroll
-  for (int sa = 0; sa < 4; sa++)
+  for (int sa = 0; sa < 4; sa++) {
+    // beta != 0: the 16 values of C this lane updates in this quarter are loaded FIRST, all of them, and added and stored afterwards.
+    // Written as `v += beta * *dst; *dst = v` per element the compiler has to keep every store in front of the next row's load (it
+    // cannot tell the rows apart): 16 dependent memory round trips per tile, ~25 us -- a tenth of a rank-1024 update's tile, which is
+    // what kept those GEMMs (Cholesky trailing updates, substitution carries) at 55 - 60 TF where a beta = 0 product runs at 61 - 70.
+    double old[4][4];
+    if (!c_bf16 && g.beta != 0.) {
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) {
+        const int64_t gr = i0 + acc_row(wr, lane, sa, reg);
+#pragma unroll
+        for (int sb = 0; sb < 4; sb++) old[reg][sb] = (gr < g.M && gc0 + sb < g.N) ? ((const double*)Cb)[gr * g.ldc + gc0 + sb] : 0.;
+      }
+    }
 #pragma unroll
     for (int reg = 0; reg < 4; reg++) {
-      int64_t gr = i0 + acc_row(wr, lane, sa, reg);
+      const int64_t gr = i0 + acc_row(wr, lane, sa, reg);
       if (gr >= g.M) continue;
-      int64_t gc0 = j0 + acc_col(wc, lane, 0);
-      int64_t e0 = gr * g.ldc + gc0;
+      const int64_t e0 = gr * g.ldc + gc0;
 #pragma unroll
       for (int sb = 0; sb < 4; sb++) {
         if (gc0 + sb >= g.N) continue;
         double v = g.alpha * acc.v[sa][sb][reg];
         if (!c_bf16) {
-          double* dst = (double*)Cb + e0 + sb;
-          if (g.beta != 0.) v += g.beta * *dst;
-          *dst = v;
+          if (g.beta != 0.) v += g.beta * old[reg][sb];
+          ((double*)Cb)[e0 + sb] = v;
         } else {
           ((bf16_t*)Cb)[e0 + sb] = f64_to_bf16(v);
         }
       }
     }
+  }
 }
 
 // ---------------------------------------------------------------- vector staging for interior tiles
@@ -209,6 +222,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   int bi, bj;
   if (g.flags & MDG_GEMM_LOWER_ONLY) {
     tri_decode(blockIdx.x, bi, bj);
+  } else if (g.flags & MDG_GEMM_B_LOWER_TRI) {
+    // a tile's k range starts at its first column: the tiles of tile column 0 are the longest, those of the last column 1 / tiles_n of
+    // that.  Longest first (the dispatcher hands workgroups out in index order): in row-major order the last tile ROW's long tiles
+    // start when the launch is nearly over and run on alone -- the triangular inverse's T = L21 X11 at s = 8192 took 9.2 ms for
+    // 6.5 ms of work at the rate of its untriangular twin.
+    bj = blockIdx.x / g.tiles_m;
+    bi = blockIdx.x % g.tiles_m;
+  } else if (g.flags & MDG_GEMM_A_LOWER_TRI) {
+    bi = g.tiles_m - 1 - blockIdx.x / g.tiles_n;     // (k range ends behind the tile's last row: the last tile row is the longest)
+    bj = blockIdx.x % g.tiles_n;
   } else {
     bi = blockIdx.x / g.tiles_n;
     bj = blockIdx.x % g.tiles_n;

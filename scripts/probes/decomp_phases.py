@@ -46,6 +46,21 @@ def potrf(m):
 which = sys.argv[1:] or ["phases", "gemm"]
 if "potrfonly" in which:
     potrf(n)
+if "inverseonly" in which:      # (for a kernel trace of the triangular inverse alone)
+    A = S.clone(); A.diagonal().add_(1e-4)
+    inv = ops.potrf_lower(A)
+    out = torch.empty(n, device=dev, dtype=F64)
+    nbytes = lib.mdg_chol_inverse_diag_ws_bytes(n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    t = timeit(lambda: lib.mdg_chol_inverse_diag(A.data_ptr(), n, n, inv.data_ptr(), out.data_ptr(), ws.data_ptr(), nbytes, st), n=2)
+    print(f"chol_inverse_diag n={n}: {t*1e3:.1f} ms  {n**3/3/t/1e12:.1f} TF (n^3/3)")
+if "potrsonly" in which:        # (for a kernel trace of the Nystrom substitution alone)
+    Ar = S[:r, :r].clone(); Ar.diagonal().add_(1e-4)
+    invr = ops.potrf_lower(Ar)
+    B = torch.randn(r, d, device=dev, generator=g, dtype=F64)
+    t = timeit(lambda: ops.potrs_lower(Ar, invr, B), n=2)
+    print(f"potrs_lower n={r} nrhs={d}: {t*1e3:.1f} ms  {2*r*r*d/t/1e12:.1f} TF")
 if "phases" in which:
     potrf(n)
     A = S.clone(); A.diagonal().add_(1e-4)
