@@ -83,6 +83,11 @@ if "phases" in which:
     Xc = torch.empty(r, d, device=dev, dtype=F64)
     t = timeit(lambda: ops.gemm(S, Wd, Xc, trans_b=True, a_rows=idx), n=2)
     print(f"cross term [{r} x {n}] gathered rows x W_d^T [{n} x {d}]: {t*1e3:.1f} ms  {2*r*n*d/t/1e12:.1f} TF")
+    t = timeit(lambda: ops.gemm(S, Wd.to(F64), Xc, trans_b=True, a_rows=idx), n=2)
+    print(f"   the same with W_d widened to fp64 first (the conversion included): {t*1e3:.1f} ms")
+    Wt = Wd.to(F64).t().contiguous()
+    t = timeit(lambda: ops.gemm(S, Wt, Xc, a_rows=idx), n=2)
+    print(f"   W_d^T as a row-major fp64 [n x d] matrix (conversion and transpose NOT included): {t*1e3:.1f} ms")
 if "gemm" in which:
     A = torch.randn(n, n, device=dev, generator=g, dtype=F64)
     C = torch.zeros(n, n, device=dev, dtype=F64)
