@@ -103,15 +103,18 @@ template <bool KC> struct FastPanel<MDG_F64, KC> {
   d2 r[4];
   unsigned voff[4];  // byte offsets from the stage base
   int lo[4];         // LDS element index of the first value
-  __device__ __forceinline__ void init(int64_t sx, int64_t sk, int64_t x0, const int64_t* rows, int tid) {
+  // xmax: rows / columns of the operand this tile really has (< 128 in the last, ragged tile row or column).  With k contiguous a
+  // thread's loads belong to ONE row, so a row beyond the end simply re-reads the last valid one (its products are never stored);
+  // with x contiguous a 16-byte load spans two rows' worth of x and the caller keeps ragged tiles off this path.
+  __device__ __forceinline__ void init(int64_t sx, int64_t sk, int64_t x0, const int64_t* rows, int tid, int xmax = 128) {
 #pragma unroll
     for (int p = 0; p < 4; p++) {
       const int e = tid + 256 * p;
       if (KC) {
-        const int kp = e & 7, x = e >> 3;
+        const int kp = e & 7, x = min(e >> 3, xmax - 1);
         const int64_t row = rows ? rows[x0 + x] : x0 + x;
         voff[p] = (unsigned)((row * sx + 2 * kp) * 8);
-        lo[p] = (2 * kp) * PITCH + x;
+        lo[p] = (2 * kp) * PITCH + (e >> 3);
       } else {
         const int xp = e & 63, k = e >> 6;
         voff[p] = (unsigned)((k * sk + x0 + 2 * xp) * 8);
@@ -141,12 +144,12 @@ template <bool KC> struct FastPanel<MDG_BF16, KC> {
   uint4 r;
   unsigned voff;
   int lo;
-  __device__ __forceinline__ void init(int64_t sx, int64_t sk, int64_t x0, const int64_t* rows, int tid) {
+  __device__ __forceinline__ void init(int64_t sx, int64_t sk, int64_t x0, const int64_t* rows, int tid, int xmax = 128) {
     if (KC) {
-      const int kp = tid & 1, x = tid >> 1;
+      const int kp = tid & 1, x = min(tid >> 1, xmax - 1);
       const int64_t row = rows ? rows[x0 + x] : x0 + x;
       voff = (unsigned)((row * sx + 8 * kp) * 2);
-      lo = (8 * kp) * PITCH + x;
+      lo = (8 * kp) * PITCH + (tid >> 1);
     } else {
       const int xp = tid & 15, k = tid >> 4;
       voff = (unsigned)((k * sk + x0 + 8 * xp) * 2);
@@ -179,8 +182,8 @@ __device__ __forceinline__ void gemm_tile_fast(const GemmArgs& g, double* lds, c
   // uniform stage bases: tile origin + first k of the range; per-lane offsets cover the row/col and in-stage k
   const int64_t esa = (int64_t)sizeof(typename ElemOf<ADT>::type), esb = (int64_t)sizeof(typename ElemOf<BDT>::type);
   const bool gather = g.a_rows != nullptr;
-  fa.init(g.sa_i, g.sa_k, gather ? i0 : 0, g.a_rows, tid);   // with a gather the row offset is absolute
-  fb.init(g.sb_j, g.sb_k, 0, nullptr, tid);
+  fa.init(g.sa_i, g.sa_k, gather ? i0 : 0, g.a_rows, tid, (int)min((int64_t)TILE, g.M - i0));   // with a gather the row offset is absolute
+  fb.init(g.sb_j, g.sb_k, 0, nullptr, tid, (int)min((int64_t)TILE, g.N - j0));
   const char* pa = Ab + ((gather || !AKC ? 0 : i0 * g.sa_i) + (AKC ? k_begin : k_begin * g.sa_k + i0)) * esa;
   const char* pb = Bb + ((BKC ? j0 * g.sb_j + k_begin : k_begin * g.sb_k + j0)) * esb;
   const int64_t da = FastPanel<ADT, AKC>::stage_bytes(g.sa_k), db = FastPanel<BDT, BKC>::stage_bytes(g.sb_k);
@@ -259,7 +262,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   __syncthreads();
 
   const int64_t n_stage = k_end > k_begin ? (k_end - k_begin + BK - 1) / BK : 0;
-  const bool interior = i0 + TILE <= g.M && j0 + TILE <= g.N;
+  // (a ragged last tile row / column stays on the vector path where that operand is k-contiguous: FastPanel::init)
+  const bool interior = (AKC || i0 + TILE <= g.M) && (BKC || j0 + TILE <= g.N);
   if (g.fast_ok && interior && n_stage > 0 && (k_end - k_begin) % BK == 0 && (AKC || !g.a_rows)) {
     Acc facc;  // separate accumulator set: the two paths never share live registers
     acc_zero(facc);

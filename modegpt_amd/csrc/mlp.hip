@@ -18,8 +18,12 @@ int copy_lower(const double* src, int64_t ld_src, const int64_t* idx, double* ds
 
 using namespace mdg;
 
+// Row pitch of C_kk in the workspace: r rounded up to 16 doubles.  With pitch r an odd rank (10035 of 14336 at 30 %) leaves every
+// second row off a 16-byte boundary, and every GEMM of the factorisation and the substitution on the element-wise staging path --
+// potrf_lower 15.1 -> 14.3 ms, potrs_lower 17.8 -> 16.9 ms at r = 10035 (scripts/probes/decomp_phases.py).
+static int64_t ckk_pitch(int64_t r) { return (r + 15) / 16 * 16; }
 extern "C" size_t mdg_nystrom_down_ws_bytes(int64_t n, int64_t r, int64_t d) {
-  return ((size_t)r * r + mdg_potrf_inv_diag_elems(r) + (size_t)r * d + potrs_ws_elems(r, d)) * sizeof(double);
+  return ((size_t)r * ckk_pitch(r) + mdg_potrf_inv_diag_elems(r) + (size_t)r * d + potrs_ws_elems(r, d)) * sizeof(double);
 }
 
 static int nystrom_down(const double* C, int64_t n, int64_t ldc, const int64_t* idx, int64_t r, const void* Wd, int64_t d, int64_t ld_wd,
@@ -54,11 +58,12 @@ static int nystrom_down(const double* C, int64_t n, int64_t ldc, const int64_t* 
                 ws_bytes, mdg_nystrom_down_ws_bytes(n, r, d));
   hipStream_t st = (hipStream_t)stream;
   double* Ckk = (double*)ws;
-  double* inv = Ckk + (size_t)r * r;
+  const int64_t ldk = ckk_pitch(r);
+  double* inv = Ckk + (size_t)r * ldk;
   double* X = inv + mdg_potrf_inv_diag_elems(r);
   double* solve_ws = X + (size_t)r * d;
   // C_kk + eps I  (lower)                                           compress_mlp.py:52,56
-  MDG_TRY(copy_lower(C, ldc, idx, Ckk, r, r, eps, st));
+  MDG_TRY(copy_lower(C, ldc, idx, Ckk, ldk, r, eps, st));
   // cross = C[idx,:] @ W_d^T  -> [r, d]                             compress_mlp.py:54
   // (with a second stream: beside the factorisation of C_kk, which does not need it -- the chain of 79 diagonal-block steps
   // leaves most of the chip idle between its GEMMs, the 1.2 TFLOP product fills it: 36 -> 27 ms for the two)
@@ -70,10 +75,10 @@ static int nystrom_down(const double* C, int64_t n, int64_t ldc, const int64_t* 
   }
   MDG_TRY(gemm_f64(r, d, n, 1.0, C, MDG_F64, ldc, 1, idx, Wd, w_dtype, 1, ld_wd, 0.0, X, MDG_F64, d, 1, 0, 0, 0, 0, cross_st));
   if (side_stream) MDG_HIP(hipEventRecord((hipEvent_t)ev_join, cross_st));
-  const int rc_potrf = potrf_lower(Ckk, r, r, inv, st);           // compress_mlp.py:56
+  const int rc_potrf = potrf_lower(Ckk, r, ldk, inv, st);         // compress_mlp.py:56
   if (side_stream) MDG_HIP(hipStreamWaitEvent(st, (hipEvent_t)ev_join, 0));   // (also on failure: the workspace is the caller's to free)
   if (rc_potrf != MDG_OK) return rc_potrf;
-  MDG_TRY(potrs_lower(Ckk, r, r, inv, X, d, d, solve_ws, st));    // compress_mlp.py:57
+  MDG_TRY(potrs_lower(Ckk, r, ldk, inv, X, d, d, solve_ws, st));  // compress_mlp.py:57
   if (down_f64) MDG_HIP(hipMemcpyAsync(down_f64, X, (size_t)r * d * sizeof(double), hipMemcpyDeviceToDevice, st));
   // [r, d] fp64 -> [d, r] bf16                                      compress_mlp.py:61,97
   return mdg_cast_transpose_f64_bf16(X, r, d, d, down_out, ld_out, stream);

@@ -33,8 +33,14 @@ del X
 lib = _lib.load()
 
 
+def padded(m):
+    """[m, m] view of a buffer whose row pitch is m rounded up to 16 doubles (what mdg_nystrom_down gives C_kk: an odd pitch puts the
+    GEMMs on their element-wise staging path)."""
+    return torch.empty(m, (m + 15) // 16 * 16, device=dev, dtype=F64)[:, :m]
+
+
 def potrf(m):
-    A = S[:m, :m].clone()
+    A = padded(m); A.copy_(S[:m, :m])
     A.diagonal().add_(1e-4)
     t = timeit(lambda: (A.copy_(S[:m, :m]), A.diagonal().add_(1e-4), ops.potrf_lower(A)), n=2)
     tc = timeit(lambda: (A.copy_(S[:m, :m]), A.diagonal().add_(1e-4)), n=2)
@@ -56,7 +62,7 @@ if "inverseonly" in which:      # (for a kernel trace of the triangular inverse 
     t = timeit(lambda: lib.mdg_chol_inverse_diag(A.data_ptr(), n, n, inv.data_ptr(), out.data_ptr(), ws.data_ptr(), nbytes, st), n=2)
     print(f"chol_inverse_diag n={n}: {t*1e3:.1f} ms  {n**3/3/t/1e12:.1f} TF (n^3/3)")
 if "potrsonly" in which:        # (for a kernel trace of the Nystrom substitution alone)
-    Ar = S[:r, :r].clone(); Ar.diagonal().add_(1e-4)
+    Ar = padded(r); Ar.copy_(S[:r, :r]); Ar.diagonal().add_(1e-4)
     invr = ops.potrf_lower(Ar)
     B = torch.randn(r, d, device=dev, generator=g, dtype=F64)
     t = timeit(lambda: ops.potrs_lower(Ar, invr, B), n=2)
@@ -73,7 +79,7 @@ if "phases" in which:
     print(f"chol_inverse_diag n={n}: {t*1e3:.1f} ms  {n**3/3/t/1e12:.1f} TF (n^3/3)")
     del ws
     potrf(r)
-    Ar = S[:r, :r].clone(); Ar.diagonal().add_(1e-4)
+    Ar = padded(r); Ar.copy_(S[:r, :r]); Ar.diagonal().add_(1e-4)
     invr = ops.potrf_lower(Ar)
     B = torch.randn(r, d, device=dev, generator=g, dtype=F64)
     t = timeit(lambda: ops.potrs_lower(Ar, invr, B), n=2)
