@@ -155,6 +155,14 @@ def test_gemm_fast_path_bf16_and_gather(ops, dev):
     out2 = torch.empty(256, 384, dtype=torch.bfloat16, device=dev)
     ops.gemm(A[:256].to(dev), Bn.to(dev), out2)
     assert torch.equal(out2.cpu(), want2.to(torch.bfloat16))
+    # a ragged last tile row AND column on that path (k-contiguous operands: rows beyond the end re-read the last valid one)
+    rows3 = torch.randperm(700, generator=gen)[:300].sort().values      # 300 = 2 x 128 + 44 gathered rows
+    Bt3 = torch.randn(200, 512, generator=gen).to(torch.bfloat16)       # 200 = 128 + 72 columns, used transposed
+    C3 = torch.randn(300, 200, generator=gen, dtype=F64)
+    want4 = A[rows3] @ Bt3.double().T - 1.5 * C3
+    out4 = C3.to(dev)
+    ops.gemm(A.to(dev), Bt3.to(dev), out4, beta=-1.5, trans_b=True, a_rows=rows3.to(dev))
+    assert rel(out4, want4) < 1e-13
     Ab = torch.randn(256, 512, generator=gen).to(torch.bfloat16)      # bf16 A as in the VO stage
     want3 = Ab.double() @ A[:512, :256].contiguous()
     out3 = torch.zeros(256, 256, dtype=F64, device=dev)
