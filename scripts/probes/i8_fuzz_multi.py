@@ -32,6 +32,7 @@ def err_of(S, R):
 
 
 worst, routes, bad, cols_out, worst_ratio = 0.0, {}, 0, 0, 0.0
+exact_stats = wide_stats = 0
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 80):
     T = int(torch.randint(1, 9000, (1,), generator=g))
     count = int(torch.randint(1, 5, (1,), generator=g))
@@ -55,11 +56,16 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 80):
         ops.cov_accum(R, X, n_heads=nh)
         e = err_of(S, R) if S.dim() == 2 else max(err_of(S[h], R[h]) for h in range(nh))
         worst = max(worst, e)
-        over_bound = info["planes"] != 0 and e > info["bound"] + 4e-16       # (the guaranteed part: must never happen)
+        # (the guaranteed part: must never happen; a statistic on the exact route is closer to the true sum than the fp64 kernel it is
+        #  compared with, whose own rounding is up to ~2e-13 of sqrt(sigma_ii sigma_jj): tests/i8_limits.REFERENCE_ROUNDING)
+        over_bound = info["planes"] != 0 and e > info["bound"] + (3e-13 if info.get("exact") else 4e-16)
+        exact_stats += bool(info.get("exact")); wide_stats += info.get("remainder") == "wide"
         if info["planes"] and e > 4e-16:
-            worst_ratio = max(worst_ratio, e / max(info["bound"], 1e-300))
+            if not info.get("exact"):
+                worst_ratio = max(worst_ratio, e / max(info["bound"], 1e-300))
         if not e < 1e-12 or over_bound:
             bad += 1
             print(f"VIOLATION trial {trial}: T={T} shape={tuple(S.shape)} kind={k} route={r} of {count} statistics err={e:.2e} "
                   f"bound={info['bound']:.2e} columns={info['columns']}")
-print(f"routes {routes}; worst error {worst:.2e}; largest measured / bound {worst_ratio:.3f}; columns sent to the fp64 column kernel {cols_out}; violations {bad}")
+print(f"routes {routes}; worst error {worst:.2e}; largest measured / bound {worst_ratio:.3f}; columns sent to the fp64 column kernel {cols_out}; "
+      f"statistics on the exact route {exact_stats} (remainder on the wide kernels: {wide_stats}); violations {bad}")
