@@ -218,33 +218,32 @@ __global__ __launch_bounds__(1024) void potrf_tile_kernel(double* A, int64_t lda
   }
   const int ct = wave & 7, rt0 = (wave >> 3) * 4;             // wave -> column tile ct, four row tiles
   const int bcol = ct * SB + mi;
-  double cold[4][4];
-  if (MODE == 1) {
-    double* C = A + row0 * lda + col0;
-#pragma unroll
-    for (int t = 0; t < 4; t++)
-#pragma unroll
-      for (int reg = 0; reg < 4; reg++) {
-        const int row = (rt0 + t) * SB + kq + 4 * reg;
-        cold[t][reg] = (row < nr && bcol < nc) ? C[(int64_t)row * lda + bcol] : 0.;
-      }
-  }
   __syncthreads();
   d4 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; t++) acc[t] = (d4){0., 0., 0., 0.};
   // the wave's B fragments, 8 k-steps per batch of loads (one round trip to L2 per batch instead of one per step; 16 waves of
   // 1024 threads leave 128 registers per lane, so not all 32 at once)
-  constexpr int KB = 8;
-  for (int kb = 0; kb < NB / 4; kb += KB) {
-    double bv[KB];
+  // (and the next batch's loads are issued before this batch is multiplied: a tile is then ONE round trip to L2 for its B operand
+  //  plus three that run under the matrix cores, instead of four in series -- the arithmetic and its order do not change)
+  constexpr int KB = 8, NBATCH = NB / 4 / KB;
+  double bv[2][KB];
+  auto load_b = [&](int kb, double (&v)[KB]) {
 #pragma unroll
-    for (int u = 0; u < KB; u++) bv[u] = bcol < nc ? Bp[(int64_t)bcol * ldb + (kb + u) * 4 + kq] : 0.;
+    for (int u = 0; u < KB; u++) v[u] = bcol < nc ? Bp[(int64_t)bcol * ldb + (kb + u) * 4 + kq] : 0.;
+  };
+  // (MODE 1 only: the panel solve, a launch of at most 112 workgroups, measured 2 - 3 us SLOWER with it)
+  load_b(0, bv[0]);
+#pragma unroll
+  for (int q = 0; q < NBATCH; q++) {
+    if (MODE == 1 && q + 1 < NBATCH) load_b((q + 1) * KB, bv[(q + 1) & 1]);
+    if (MODE == 0 && q > 0) load_b(q * KB, bv[q & 1]);
+    if (MODE == 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < KB; u++) {
-      const int kk = (kb + u) * 4 + kq;
+      const int kk = (q * KB + u) * 4 + kq;
 #pragma unroll
-      for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[((rt0 + t) * SB + mi) * DP + kk], bv[u], acc[t], 0, 0, 0);
+      for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[((rt0 + t) * SB + mi) * DP + kk], bv[q & 1][u], acc[t], 0, 0, 0);
     }
   }
   if (MODE == 0) {
@@ -257,7 +256,17 @@ __global__ __launch_bounds__(1024) void potrf_tile_kernel(double* A, int64_t lda
         if (row < nr) Ai[(int64_t)row * lda + bcol] = acc[t][reg];
       }
   } else {
+    // (the tile of C is read here, in one batch, rather than ahead of the products: with two batches of B fragments in flight its 32
+    //  registers no longer fit beside them, and one exposed round trip replaces three)
     double* C = A + row0 * lda + col0;
+    double cold[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) {
+        const int row = (rt0 + t) * SB + kq + 4 * reg;
+        cold[t][reg] = (row < nr && bcol < nc) ? C[(int64_t)row * lda + bcol] : 0.;
+      }
 #pragma unroll
     for (int t = 0; t < 4; t++)
 #pragma unroll
