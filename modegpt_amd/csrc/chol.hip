@@ -56,19 +56,22 @@ __device__ __forceinline__ void potrf_diag_block(double* A, int64_t lda, int nb,
       const int li = lane & 15;
 #pragma unroll
       for (int c = 0; c < SB; c++) row[c] = (lane < SB && c <= li) ? a[(kb + li) * DP + kb + c] : 0.;
+      int first_bad = SB;                            // first column of this sub-block whose pivot is not positive (or NaN)
 #pragma unroll
       for (int j = 0; j < SB; j++) {
         double d = readlane_f64(row[j], j);
-        if (!(d > 0.)) {  // also catches NaN; uniform across the wave
-          if (lane == 0 && kb + j < nb) atomicCAS(info, 0, (int)(k0 + kb + j + 1));
-          d = 1.;
-        }
+        // (no branch per column: the 16 columns stay one basic block, whose rsqrt chains and rank-1 updates the scheduler may then
+        //  interleave; the report happens once, behind the loop)
+        const bool bad = !(d > 0.);                  // also catches NaN; uniform across the wave
+        first_bad = (bad && first_bad == SB) ? j : first_bad;
+        d = bad ? 1. : d;
         const double rs = rsqrt(d);                 // one reciprocal square root instead of a sqrt and a divide
         rdiag[j] = rs;
         row[j] = (li == j) ? d * rs : row[j] * rs;  // l_jj = sqrt(d), l_ij = a_ij / sqrt(d)
 #pragma unroll
         for (int c = j + 1; c < SB; c++) row[c] -= row[j] * readlane_f64(row[j], c);
       }
+      if (first_bad < SB && lane == 0 && kb + first_bad < nb) atomicCAS(info, 0, (int)(k0 + kb + first_bad + 1));
 #pragma unroll
       for (int i = 0; i < SB; i++) {  // lane j solves L x = e_j
         double sacc = (i == li) ? 1. : 0.;
