@@ -196,6 +196,9 @@ __device__ __forceinline__ int bf16_ee_if_nonzero(unsigned b) {  // effective ex
   return (b & 0x7FFF) ? (e ? e : 1) : 0;
 }
 
+#ifndef MDG_COLMAX_WGS
+#define MDG_COLMAX_WGS 4096
+#endif
 __global__ __launch_bounds__(256) void i8_colmax_vec_kernel(const bf16_t* x, int64_t ld, int64_t T, int64_t rows_per_block, int* emax) {
   __shared__ int best_lds[128];
   const int cg = threadIdx.x & 15, tl = threadIdx.x >> 4;  // 16 column groups of 8 columns x 16 token lanes
@@ -2306,8 +2309,12 @@ extern "C" int mdg_cov_accum_i8_multi(int count, const mdg_cov_problem* problems
     const bool vec = ((uintptr_t)q.x % 16 == 0) && (q.ld % 8 == 0);
     const int64_t rows_per_block = 2048;
     if (vec) {
-      hipLaunchKernelGGL(i8_colmax_vec_kernel, dim3((unsigned)(n / 128), (unsigned)ceil_div(n_tokens, rows_per_block)), dim3(256), 0,
-                         st, (const bf16_t*)q.x, q.ld, n_tokens, rows_per_block, emax);
+      // (the maximum pass of a NARROW statistic: with 2048 tokens per workgroup 1024 columns are 128 workgroups walking 128 dependent
+      //  16-byte loads each -- 82 us for 67 MB.  Token slabs sized for ~MDG_COLMAX_WGS workgroups in all, 64 tokens at least)
+      const int64_t slabs = std::min(ceil_div(n_tokens, (int64_t)64), std::max((int64_t)1, (int64_t)MDG_COLMAX_WGS / (n / 128)));
+      const int64_t rows_vec = ceil_div(ceil_div(n_tokens, slabs), (int64_t)16) * 16;
+      hipLaunchKernelGGL(i8_colmax_vec_kernel, dim3((unsigned)(n / 128), (unsigned)ceil_div(n_tokens, rows_vec)), dim3(256), 0,
+                         st, (const bf16_t*)q.x, q.ld, n_tokens, rows_vec, emax);
       hipLaunchKernelGGL(i8_split_vec_kernel, dim3((unsigned)(n / 128), (unsigned)ceil_div(nk, 2 * SPLIT_TILES)), dim3(256), 0, st,
                          (const bf16_t*)q.x, q.ld, n_tokens, n, nk, emax, planes, stats, zmask);
     } else {
